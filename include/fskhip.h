@@ -1,0 +1,183 @@
+/*
+ * fskhip.h -- C ABI of libfskhip.so: the MI355X (gfx950) batch FSK DSP engine.
+ *
+ * This is the drop-in boundary for ONE path of cho45/WebAudio-Modem: FSKCore.modulateData /
+ * demodulateData (src/modems/fsk.ts:190-222, 377-424) and the dsp/filters.ts IIR chain they
+ * call, batched over independent streams (one GPU lane per stream).  Plain pointers and sizes
+ * only.  Every entry point cites the reference interface it replaces; the binding a
+ * maintainer adds on the reference side (N-API) is shown in INTEGRATION.md.
+ *
+ * All functions return FSKHIP_OK (0) or a negative FSKHIP_E_* code; fskhip_last_error()
+ * returns a thread-local message for the last failure.  There is NO CPU fallback: without a
+ * usable HIP device fskhip_create() fails with FSKHIP_E_NO_DEVICE.
+ */
+#ifndef FSKHIP_H
+#define FSKHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSKHIP_ABI_VERSION 1
+#define FSKHIP_MAX_PATTERN_BYTES 16
+
+enum {
+  FSKHIP_OK = 0,
+  FSKHIP_E_INVALID = -1,        /* bad argument */
+  FSKHIP_E_NOT_CONFIGURED = -2, /* reference: throws 'FSK (de)modulator not configured' fsk.ts:191-193,378-380 */
+  FSKHIP_E_UNSUPPORTED = -3,    /* configuration outside what the kernels implement (see fskhip_create) */
+  FSKHIP_E_NO_DEVICE = -4,      /* no HIP device / HIP runtime failure at create */
+  FSKHIP_E_HIP = -5,            /* HIP runtime error during a call */
+  FSKHIP_E_NOMEM = -6,
+  FSKHIP_E_OVERFLOW = -7        /* an output slab was too small; counts still report the true size */
+};
+
+/* arithmetic the demodulator chain computes in */
+enum {
+  FSKHIP_PRECISION_F32 = 0, /* throughput path: fp32 VALU, hardware sin/cos/rcp/sqrt */
+  FSKHIP_PRECISION_F64 = 1  /* parity path: fp64, op-for-op with the reference's double arithmetic */
+};
+
+/* FSKConfig (fsk.ts:5-17) + BaseModulatorConfig (core.ts:3-6), field for field. */
+typedef struct fskhip_config {
+  double sampleRate;
+  double baudRate;
+  double markFrequency;
+  double spaceFrequency;
+  int32_t preamblePattern[FSKHIP_MAX_PATTERN_BYTES];
+  int32_t preambleLen;
+  int32_t sfdPattern[FSKHIP_MAX_PATTERN_BYTES];
+  int32_t sfdLen;
+  int32_t startBits;
+  int32_t stopBits;
+  int32_t parity; /* 0 'none', 1 'even', 2 'odd' */
+  double syncThreshold;
+  int32_t agcEnabled;
+  double preFilterBandwidth;
+  int32_t adaptiveThreshold; /* accepted and ignored, as in the reference (fsk.ts:16,32: never read) */
+} fskhip_config;
+
+/* getStatus() (fsk.ts:481-493) for one stream, plus the AGC gain and the eod total. */
+typedef struct fskhip_status {
+  int32_t ready;
+  int32_t frameStarted;
+  double globalSampleCounter;
+  double receivedBitsLength;
+  double byteBufferLength;       /* always 0 between calls: demodulateData drains it (fsk.ts:210-214) */
+  double demodulationCalls;
+  double syncDetections;
+  double silenceThreshold;
+  double totalSamplesProcessed;
+  double agcGain;                /* NaN when AGC is disabled */
+  double eodCount;               /* 'eod' events since create (fsk.ts:289) */
+} fskhip_status;
+
+typedef struct fskhip_engine fskhip_engine;
+
+/* DEFAULT_FSK_CONFIG (fsk.ts:19-33). */
+void fskhip_default_config(fskhip_config *cfg);
+
+/*
+ * new FSKCore() + configure(cfg) for n_streams independent demodulator/modulator instances
+ * (fsk.ts:133-157).  n_cfgs is 1 (all streams share cfgs[0]) or n_streams (per-stream
+ * markFrequency / spaceFrequency / preFilterBandwidth; every other field must be equal across
+ * streams -- BASELINE config #4).  `device` is the HIP device ordinal.  `precision` is
+ * FSKHIP_PRECISION_*.
+ * FSKHIP_E_UNSUPPORTED: a fractional sync-ring capacity (maxSyncBits*dsSPB*1.1 not an integer,
+ * e.g. 44.1 kHz; the reference's ring stops working after one wrap there, fsk.ts:149 /
+ * utils.ts:38-48), more than 31 preamble+SFD pattern bits, or dsSPB too large for LDS.
+ */
+int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams, int device,
+                  int precision, fskhip_engine **out);
+int fskhip_destroy(fskhip_engine *e);
+
+uint32_t fskhip_n_streams(const fskhip_engine *e);
+
+/*
+ * demodulateData(samples) (fsk.ts:190-222) for every stream: `samples` is [n_streams][pitch]
+ * float32 (stream-major, `pitch` in floats >= n_per_stream), all streams advance by
+ * n_per_stream samples; per-stream state persists across calls like one FSKCore instance per
+ * stream.  Decoded bytes of stream s go to out[s*out_pitch ...], their number to
+ * out_counts[s] (the true count, even if it exceeds out_pitch -> FSKHIP_E_OVERFLOW), the number
+ * of 'eod' events emitted during the call to eod_counts[s] (may be NULL).
+ * flags: FSKHIP_DEMOD_WRITEBACK_AGC writes the AGC-scaled samples back into `samples`, which
+ * the reference does as a side effect (fsk.ts:55,201).
+ * The _host form takes host pointers (H2D/D2H inside, synchronous); the _device form takes
+ * device pointers, is asynchronous on `hip_stream` (a hipStream_t, NULL = default stream) and
+ * moves nothing over PCIe.
+ */
+#define FSKHIP_DEMOD_WRITEBACK_AGC 1u
+int fskhip_demodulate_host(fskhip_engine *e, float *samples, size_t n_per_stream, size_t pitch,
+                           uint8_t *out, size_t out_pitch, uint32_t *out_counts,
+                           uint32_t *eod_counts, uint32_t flags);
+int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n_per_stream, size_t pitch,
+                             uint8_t *d_out, size_t out_pitch, uint32_t *d_out_counts,
+                             uint32_t *d_eod_counts, uint32_t flags, void *hip_stream);
+
+/*
+ * modulateData(bytes) (fsk.ts:377-424) for every stream.  Stream s modulates
+ * payloads[s*payload_pitch .. + lens[s]) with ITS configuration into out[s*out_pitch ...];
+ * out_lens[s] receives the signal length: totalBytes*bitsPerByte*spb + 2*spb + bitsPerByte*spb
+ * (fsk.ts:391-394).  fskhip_modulated_length() gives that length for a payload size.
+ */
+size_t fskhip_modulated_length(const fskhip_engine *e, size_t n_bytes);
+int fskhip_modulate_host(fskhip_engine *e, const uint8_t *payloads, const uint32_t *lens,
+                         size_t payload_pitch, float *out, size_t out_pitch, uint32_t *out_lens);
+int fskhip_modulate_device(fskhip_engine *e, const uint8_t *d_payloads, const uint32_t *d_lens,
+                           size_t payload_pitch, float *d_out, size_t out_pitch,
+                           uint32_t *d_out_lens, void *hip_stream);
+
+/* reset() (fsk.ts:464-469) for one stream, or all when stream < 0. */
+int fskhip_reset(fskhip_engine *e, int64_t stream);
+/* getStatus() (fsk.ts:481-493). Synchronises with outstanding work of the engine. */
+int fskhip_get_status(fskhip_engine *e, uint32_t stream, fskhip_status *st);
+
+/*
+ * Synthetic multi-stream workload generator (measurement tooling): stream s
+ * = lead_s zero samples, then back-to-back frames, each exactly what modulateData() returns for
+ * a payload of payload_len bytes drawn from splitmix64(seed, s, frame, i), the whole stream
+ * scaled by amp_s in [amp_lo, amp_hi]; lead_s = splitmix64(seed,s) mod (lead_max+1).
+ * d_out is [n_streams][pitch] float32 on the device.  Payload byte (s, frame, i) and lead_s/amp_s
+ * are reproducible on the host with fskhip_synth_payload_byte / fskhip_synth_stream_params.
+ */
+int fskhip_synth_device(fskhip_engine *e, float *d_out, size_t n_per_stream, size_t pitch,
+                        uint32_t payload_len, uint64_t seed, uint32_t lead_max, double amp_lo,
+                        double amp_hi, void *hip_stream);
+uint8_t fskhip_synth_payload_byte(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t i);
+void fskhip_synth_stream_params(uint64_t seed, uint32_t stream, uint32_t lead_max, double amp_lo,
+                                double amp_hi, uint32_t *lead, double *amp);
+/* Adds white Gaussian noise in place: sigma_s^2 = mean_square(stream s over n_per_stream) /
+ * 10^(snr_db/10) (the reference tests' definition, tests/modems/fsk-demodulation.node.test.ts:
+ * 1184-1205), counter-based generator keyed by (seed, stream, sample). */
+int fskhip_add_awgn_device(fskhip_engine *e, float *d_buf, size_t n_per_stream, size_t pitch,
+                           double snr_db, uint64_t seed, void *hip_stream);
+
+/* FilterDesign.butterworth* (filters.ts:180-234): the configure-time designs the engine uses. */
+void fskhip_butterworth_lowpass(double cutoff, double sampleRate, double b[3], double a[3]);
+void fskhip_butterworth_highpass(double cutoff, double sampleRate, double b[3], double a[3]);
+void fskhip_butterworth_bandpass(double center, double bandwidth, double sampleRate, double b[3], double a[3]);
+
+/* Raw device memory helpers for hosts without a HIP binding of their own (ctypes / N-API). */
+int fskhip_device_malloc(fskhip_engine *e, size_t bytes, void **d_ptr);
+int fskhip_device_free(fskhip_engine *e, void *d_ptr);
+int fskhip_memcpy_h2d(fskhip_engine *e, void *d_dst, const void *src, size_t bytes);
+int fskhip_memcpy_d2h(fskhip_engine *e, void *dst, const void *d_src, size_t bytes);
+int fskhip_synchronize(fskhip_engine *e);
+
+/* Timing of the dominant kernel with HIP events on the stream the launches went to:
+ * fskhip_timing_begin() arms it, every fskhip_demodulate_device() after that is bracketed by
+ * an event pair, fskhip_timing_end() synchronises and returns launches and total kernel ms. */
+int fskhip_timing_begin(fskhip_engine *e);
+int fskhip_timing_end(fskhip_engine *e, uint32_t *n_launches, double *total_ms);
+
+const char *fskhip_last_error(void);
+int fskhip_abi_version(void);
+int fskhip_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSKHIP_H */

@@ -1,0 +1,78 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """tests/golden/: vectors captured from the real reference (oracle/refrun/make_golden.py)."""
+
+    def __init__(self):
+        with open(os.path.join(GOLDEN_DIR, "manifest.json")) as fh:
+            self.manifest = json.load(fh)
+        self.arrays = np.load(os.path.join(GOLDEN_DIR, "golden.npz"))
+        self.cases = {c["name"]: c for c in self.manifest["cases"]}
+
+    def array(self, name):
+        return self.arrays[name]
+
+    def case_input(self, case):
+        return self.arrays[case["input"]]
+
+
+_GOLDEN = None
+
+
+def golden():
+    global _GOLDEN
+    if _GOLDEN is None:
+        _GOLDEN = Golden()
+    return _GOLDEN
+
+
+@pytest.fixture(scope="session")
+def gold():
+    return golden()
+
+
+def case_names():
+    return [c["name"] for c in golden().manifest["cases"]]
+
+
+def run_chunked(demod_call, x, chunk):
+    """Feed x through demod_call(chunk_array) -> (bytes, eod) in the fixture's chunking.
+    Returns (all_bytes, eod_total, nonempty_calls, n_calls) in the manifest's format."""
+    chunk = chunk or max(1, x.size)
+    out = b""
+    eod_total = 0
+    nonempty = []
+    off = 0
+    i = 0
+    while True:
+        n = min(chunk, x.size - off)
+        b, e = demod_call(x[off:off + n])
+        if len(b) or e:
+            nonempty.append({"i": i, "bytes": list(b), "eod": int(e)})
+        out += bytes(b)
+        eod_total += int(e)
+        off += n
+        i += 1
+        if off >= x.size:
+            break
+    return out, eod_total, nonempty, i
+
+
+STATUS_EXACT_KEYS = ["frameStarted", "globalSampleCounter", "receivedBitsLength", "demodulationCalls",
+                     "syncDetections", "totalSamplesProcessed"]

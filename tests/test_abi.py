@@ -1,0 +1,105 @@
+"""CPU-side checks of the drop-in boundary: libfskhip.so loads, exports every symbol that
+include/fskhip.h declares, its configure-time host functions agree with the reference's golden
+vectors, and -- without a GPU -- every compute entry point FAILS LOUDLY (there is no fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+
+
+def _built():
+    import __graft_entry__ as ge
+    ge.build()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _built()
+    from webaudio_modem_amd import _lib
+    return _lib
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, "include", "fskhip.h")) as fh:
+        src = fh.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fskhip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported(lib):
+    L = C.CDLL(lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(L, name), "libfskhip.so does not export %s" % name
+    # and the ctypes table binds exactly the header's set
+    assert sorted(lib.SYMBOL_NAMES) == declared
+
+
+def test_abi_version_and_default_config(lib):
+    L = lib.lib()
+    assert L.fskhip_abi_version() == 1
+    c = lib.Config()
+    L.fskhip_default_config(C.byref(c))
+    # DEFAULT_FSK_CONFIG fsk.ts:19-33
+    assert (c.sampleRate, c.baudRate, c.markFrequency, c.spaceFrequency) == (48000, 1200, 1650, 1850)
+    assert list(c.preamblePattern)[:c.preambleLen] == [0x55, 0x55] and list(c.sfdPattern)[:c.sfdLen] == [0x7E]
+    assert (c.startBits, c.stopBits, c.parity, c.syncThreshold, c.agcEnabled, c.preFilterBandwidth) == (1, 1, 0, 0.85, 1, 800)
+
+
+def test_config_struct_layout_matches_oracle(lib):
+    """fskhip_config and the oracle's fsko_config are the same FSKConfig layout."""
+    from oracle import pyoracle as po
+    assert C.sizeof(lib.Config) == C.sizeof(po.Config)
+    assert [f[0] for f in lib.Config._fields_] == [f[0] for f in po.Config._fields_]
+    assert C.sizeof(lib.Status) == C.sizeof(po.Status)
+
+
+def test_filter_design_host_functions_match_reference(lib):
+    from webaudio_modem_amd import FilterDesign
+    for fd in golden().manifest["filter_design"]:
+        if not fd["fn"].startswith("butterworth"):
+            continue
+        got = getattr(FilterDesign, fd["fn"])(*fd["args"])
+        assert got == fd["out"], fd  # bit-exact doubles
+
+
+def test_synth_helpers_are_deterministic(lib):
+    L = lib.lib()
+    a = [L.fskhip_synth_payload_byte(0xF5C0DE, 3, 1, i) for i in range(16)]
+    b = [L.fskhip_synth_payload_byte(0xF5C0DE, 3, 1, i) for i in range(16)]
+    assert a == b and len(set(a)) > 8
+    lead, amp = C.c_uint32(), C.c_double()
+    L.fskhip_synth_stream_params(0xF5C0DE, 5, 400, 0.1, 1.0, C.byref(lead), C.byref(amp))
+    assert 0 <= lead.value <= 400 and 0.1 <= amp.value <= 1.0
+
+
+def test_no_gpu_means_loud_failure(lib):
+    """On a box without a HIP device the product must refuse to run, not fall back."""
+    import webaudio_modem_amd as wm
+    if lib.lib().fskhip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(wm.FskHipError) as ei:
+        wm.FSKEngine(1, {})
+    assert ei.value.code == -4  # FSKHIP_E_NO_DEVICE
+    assert "no CPU fallback" in str(ei.value)
+    core = wm.FSKCore()
+    with pytest.raises(RuntimeError, match="not configured"):
+        core.demodulateData(np.zeros(4, np.float32))
+    with pytest.raises(wm.FskHipError):
+        core.configure({})
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under webaudio_modem_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "webaudio_modem_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".cc", ".js", ".ts")):
+                with open(os.path.join(dirpath, f), encoding="utf-8") as fh:
+                    src = fh.read()
+                assert "oracle" not in src.lower(), os.path.join(dirpath, f)

@@ -1,0 +1,12 @@
+"""webaudio_modem_amd: MI355X-native batch FSK DSP engine behind the reference's FSKCore surface.
+
+Everything that computes goes through libfskhip.so (hand-written HIP for gfx950, C ABI in
+include/fskhip.h).  There is no CPU path in this package.
+"""
+from ._lib import FskHipError, PRECISION_F32, PRECISION_F64, LIB_PATH  # noqa: F401
+from .engine import FSKEngine, DEFAULT_FSK_CONFIG, make_config  # noqa: F401
+from .fsk_core import FSKCore, Event, EventEmitter  # noqa: F401
+from .filters import FilterDesign  # noqa: F401
+
+__all__ = ["FSKEngine", "FSKCore", "FilterDesign", "DEFAULT_FSK_CONFIG", "FskHipError",
+           "PRECISION_F32", "PRECISION_F64"]

@@ -1,0 +1,109 @@
+"""ctypes loader for libfskhip.so (the C ABI in include/fskhip.h).
+
+There is no fallback of any kind: if the HIP extension is missing this raises, and every
+compute entry point fails with FSKHIP_E_NO_DEVICE when no GPU is present.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfskhip.so")
+
+MAX_PATTERN_BYTES = 16
+OK = 0
+E_INVALID, E_NOT_CONFIGURED, E_UNSUPPORTED, E_NO_DEVICE, E_HIP, E_NOMEM, E_OVERFLOW = -1, -2, -3, -4, -5, -6, -7
+PRECISION_F32, PRECISION_F64 = 0, 1
+DEMOD_WRITEBACK_AGC = 1
+
+
+class Config(C.Structure):
+    """fskhip_config == FSKConfig (reference src/modems/fsk.ts:5-17)."""
+    _fields_ = [
+        ("sampleRate", C.c_double), ("baudRate", C.c_double),
+        ("markFrequency", C.c_double), ("spaceFrequency", C.c_double),
+        ("preamblePattern", C.c_int32 * MAX_PATTERN_BYTES), ("preambleLen", C.c_int32),
+        ("sfdPattern", C.c_int32 * MAX_PATTERN_BYTES), ("sfdLen", C.c_int32),
+        ("startBits", C.c_int32), ("stopBits", C.c_int32), ("parity", C.c_int32),
+        ("syncThreshold", C.c_double), ("agcEnabled", C.c_int32),
+        ("preFilterBandwidth", C.c_double), ("adaptiveThreshold", C.c_int32),
+    ]
+
+
+class Status(C.Structure):
+    """fskhip_status == getStatus() (fsk.ts:481-493) + agcGain + eodCount."""
+    _fields_ = [
+        ("ready", C.c_int32), ("frameStarted", C.c_int32),
+        ("globalSampleCounter", C.c_double), ("receivedBitsLength", C.c_double),
+        ("byteBufferLength", C.c_double), ("demodulationCalls", C.c_double),
+        ("syncDetections", C.c_double), ("silenceThreshold", C.c_double),
+        ("totalSamplesProcessed", C.c_double), ("agcGain", C.c_double), ("eodCount", C.c_double),
+    ]
+
+
+# every symbol include/fskhip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SYMBOLS = [
+    ("fskhip_default_config", None, [C.POINTER(Config)]),
+    ("fskhip_create", C.c_int, [C.POINTER(Config), C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("fskhip_destroy", C.c_int, [_P]),
+    ("fskhip_n_streams", C.c_uint32, [_P]),
+    ("fskhip_demodulate_host", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P, _P, C.c_uint32]),
+    ("fskhip_demodulate_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P, _P, C.c_uint32, _P]),
+    ("fskhip_modulated_length", C.c_size_t, [_P, C.c_size_t]),
+    ("fskhip_modulate_host", C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_size_t, _P]),
+    ("fskhip_modulate_device", C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_size_t, _P, _P]),
+    ("fskhip_reset", C.c_int, [_P, C.c_int64]),
+    ("fskhip_get_status", C.c_int, [_P, C.c_uint32, C.POINTER(Status)]),
+    ("fskhip_synth_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint32,
+                                      C.c_double, C.c_double, _P]),
+    ("fskhip_synth_payload_byte", C.c_uint8, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("fskhip_synth_stream_params", None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
+                                          C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
+    ("fskhip_add_awgn_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, C.c_uint64, _P]),
+    ("fskhip_butterworth_lowpass", None, [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("fskhip_butterworth_highpass", None, [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("fskhip_butterworth_bandpass", None, [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double)]),
+    ("fskhip_device_malloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    ("fskhip_device_free", C.c_int, [_P, _P]),
+    ("fskhip_memcpy_h2d", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("fskhip_memcpy_d2h", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("fskhip_synchronize", C.c_int, [_P]),
+    ("fskhip_timing_begin", C.c_int, [_P]),
+    ("fskhip_timing_end", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
+    ("fskhip_last_error", C.c_char_p, []),
+    ("fskhip_abi_version", C.c_int, []),
+    ("fskhip_device_count", C.c_int, []),
+]
+SYMBOL_NAMES = [s[0] for s in _SYMBOLS]
+
+_lib = None
+
+
+class FskHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("fskhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load libfskhip.so; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libfskhip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C webaudio_modem_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in _SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise FskHipError(rc, lib().fskhip_last_error().decode("utf-8", "replace"))
+    return rc

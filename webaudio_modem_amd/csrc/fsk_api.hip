@@ -1,0 +1,640 @@
+// fsk_api.hip -- C ABI of libfskhip.so (include/fskhip.h): configure-time parameter derivation,
+// device state management and kernel launches.  No torch types, no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fskhip.h"
+#include "fsk_params.h"
+
+namespace fsk {
+hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, const DemodParams &P, const DemodState &S,
+                        float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch,
+                        uint32_t *out_counts, uint32_t *eod_counts, hipStream_t stream);
+hipError_t set_demod_lds_limit(size_t lds_bytes);
+hipError_t launch_modulate(const ModParams &M, const double *coef, const uint8_t *payloads, const uint32_t *lens,
+                           size_t payload_pitch, float *out, size_t out_pitch, uint32_t *out_lens, hipStream_t st);
+hipError_t launch_synth(const ModParams &M, const double *coef, float *out, size_t n, size_t pitch,
+                        uint32_t payload_len, uint64_t seed, uint32_t lead_max, double amp_lo, double amp_hi,
+                        hipStream_t st);
+hipError_t launch_awgn(float *buf, size_t n, size_t pitch, uint32_t n_streams, double snr_db, uint64_t seed,
+                       double *sigma, hipStream_t st);
+uint8_t host_synth_payload_byte(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t i);
+void host_synth_stream_params(uint64_t seed, uint32_t stream, uint32_t lead_max, double amp_lo, double amp_hi,
+                              uint32_t *lead, double *amp);
+}  // namespace fsk
+
+using namespace fsk;
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) return fail(FSKHIP_E_HIP, "%s: %s", #expr, hipGetErrorString(_e));      \
+  } while (0)
+
+// ---- small device kernels for state management --------------------------------------------------
+namespace {
+
+struct StatusRaw {
+  double agc_gain, sil_thr;
+  uint32_t started, gsc, ring_len, sync_det, eod_total, ds_cnt;
+};
+
+template <typename Real>
+__global__ void status_kernel(DemodState S, uint32_t n, uint32_t s, StatusRaw *out) {
+  const Real *rs = (const Real *)S.rs;
+  out->agc_gain = (double)rs[(size_t)RF_agc_gain * n + s];
+  out->sil_thr = (double)rs[(size_t)RF_sil_thr * n + s];
+  out->started = S.is[(size_t)IF_started * n + s];
+  out->gsc = S.is[(size_t)IF_gsc * n + s];
+  out->ring_len = S.is[(size_t)IF_ring_len * n + s];
+  out->sync_det = S.is[(size_t)IF_sync_det * n + s];
+  out->eod_total = S.is[(size_t)IF_eod_total * n + s];
+  out->ds_cnt = S.is[(size_t)IF_ds_cnt * n + s];
+}
+
+// configure(): fresh FSKCore state for every stream (fsk.ts:101-131, 175-188; AGC gain 1.0 fsk.ts:46;
+// silence.threshold 0.01 fsk.ts:128).  `matched` starts at its value for an all-zero bit history.
+template <typename Real>
+__global__ void init_kernel(DemodState S, uint32_t n, uint32_t matched_zero) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  Real *rs = (Real *)S.rs;
+  for (int f = 0; f < RF_COUNT; f++) rs[(size_t)f * n + s] = (Real)0;
+  for (int f = 0; f < IF_COUNT; f++) S.is[(size_t)f * n + s] = 0u;
+  rs[(size_t)RF_agc_gain * n + s] = (Real)1.0;
+  rs[(size_t)RF_sil_thr * n + s] = (Real)0.01;
+  S.is[(size_t)IF_matched * n + s] = matched_zero;
+}
+
+// reset() fsk.ts:464-469 = resetState() + syncSamplesBuffer.clear() (+ host-side counters).
+// stream < 0: all streams.
+template <typename Real>
+__global__ void reset_kernel(DemodState S, uint32_t n, int64_t stream) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  if (stream >= 0 && (int64_t)s != stream) return;
+  Real *rs = (Real *)S.rs;
+  const int rz[] = {RF_li_x1, RF_li_x2, RF_li_y1, RF_li_y2, RF_lq_x1, RF_lq_x2, RF_lq_y1, RF_lq_y2,
+                    RF_po_x1, RF_po_x2, RF_po_y1, RF_po_y2, RF_acc_i,  RF_acc_q,  RF_last_phase, RF_nco_phase};
+  for (int f : rz) rs[(size_t)f * n + s] = (Real)0;
+  const int iz[] = {IF_nco_lo, IF_nco_hi, IF_ds_cnt, IF_gsc, IF_cad_ctr, IF_sil_cnt, IF_started, IF_bit_acc,
+                    IF_bit_cnt, IF_bit_sample_ctr, IF_next_bit_idx, IF_byte_cur, IF_bit_pos, IF_ring_len, IF_sync_det};
+  for (int f : iz) S.is[(size_t)f * n + s] = 0u;
+}
+
+}  // namespace
+
+// ---- engine -------------------------------------------------------------------------------------
+struct fskhip_engine {
+  int device = 0;
+  int precision = 0;
+  uint32_t n_streams = 0;
+  fskhip_config cfg0{};
+  DemodParams P{};
+  ModParams M{};
+  DemodState S{};
+  size_t lds_bytes = 0;
+  uint32_t n_blocks = 0;
+  // modulator geometry (doubles as in the reference)
+  double spb = 0, bpb = 0;
+  // host-side debug counters (fsk.ts:131): engine-wide totals minus per-stream baselines
+  uint64_t calls = 0, total_samples = 0;
+  std::vector<uint64_t> base_calls, base_samples;
+  bool ds_uniform = true;
+  // scratch for the _host entry points
+  hipStream_t stream = nullptr;
+  float *d_samples = nullptr; size_t d_samples_cap = 0;
+  uint8_t *d_out = nullptr; size_t d_out_cap = 0;
+  uint32_t *d_counts = nullptr, *d_eod = nullptr, *d_lens = nullptr;
+  uint8_t *d_payloads = nullptr; size_t d_payloads_cap = 0;
+  StatusRaw *d_status = nullptr;
+  double *d_sigma = nullptr;
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used = 0;
+  hipStream_t timing_stream = nullptr;
+};
+
+static void ref_butter_lp(double cutoff, double sr, double b[3], double a[3]) {  // filters.ts:180-192
+  double nyquist = sr / 2;
+  double nc = cutoff / nyquist;
+  double c = std::tan(M_PI * nc / 2);
+  double c2 = c * c;
+  double s2c = M_SQRT2 * c;
+  double den = 1 + s2c + c2;
+  b[0] = c2 / den; b[1] = 2 * c2 / den; b[2] = c2 / den;
+  a[0] = 1; a[1] = (2 * c2 - 2) / den; a[2] = (1 - s2c + c2) / den;
+}
+static void ref_butter_hp(double cutoff, double sr, double b[3], double a[3]) {  // filters.ts:200-212
+  double nyquist = sr / 2;
+  double nc = cutoff / nyquist;
+  double c = std::tan(M_PI * nc / 2);
+  double c2 = c * c;
+  double s2c = M_SQRT2 * c;
+  double den = 1 + s2c + c2;
+  b[0] = 1 / den; b[1] = -2 / den; b[2] = 1 / den;
+  a[0] = 1; a[1] = (2 * c2 - 2) / den; a[2] = (1 - s2c + c2) / den;
+}
+static void ref_butter_bp(double fc, double bwHz, double sr, double b[3], double a[3]) {  // filters.ts:221-234
+  double omega = 2 * M_PI * fc / sr;
+  double bw = 2 * M_PI * bwHz / sr;
+  double c = std::tan(bw / 2);
+  double d = 2 * std::cos(omega);
+  double c2 = c * c;
+  double den = 1 + c + c2;
+  b[0] = c / den; b[1] = 0; b[2] = -c / den;
+  a[0] = 1; a[1] = (-d * (1 + c2)) / den; a[2] = (1 - c + c2) / den;
+}
+
+template <typename T>
+static int ensure(T *&p, size_t &cap, size_t need) {
+  if (need <= cap) return FSKHIP_OK;
+  if (p) (void)hipFree(p);
+  p = nullptr; cap = 0;
+  hipError_t err = hipMalloc((void **)&p, need * sizeof(T));
+  if (err != hipSuccess) return fail(FSKHIP_E_NOMEM, "hipMalloc(%zu): %s", need * sizeof(T), hipGetErrorString(err));
+  cap = need;
+  return FSKHIP_OK;
+}
+
+extern "C" {
+
+void fskhip_butterworth_lowpass(double cutoff, double sr, double b[3], double a[3]) { ref_butter_lp(cutoff, sr, b, a); }
+void fskhip_butterworth_highpass(double cutoff, double sr, double b[3], double a[3]) { ref_butter_hp(cutoff, sr, b, a); }
+void fskhip_butterworth_bandpass(double fc, double bw, double sr, double b[3], double a[3]) { ref_butter_bp(fc, bw, sr, b, a); }
+
+const char *fskhip_last_error(void) { return g_err.c_str(); }
+int fskhip_abi_version(void) { return FSKHIP_ABI_VERSION; }
+int fskhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void fskhip_default_config(fskhip_config *c) {  // fsk.ts:19-33
+  std::memset(c, 0, sizeof(*c));
+  c->sampleRate = 48000; c->baudRate = 1200; c->markFrequency = 1650; c->spaceFrequency = 1850;
+  c->preamblePattern[0] = 0x55; c->preamblePattern[1] = 0x55; c->preambleLen = 2;
+  c->sfdPattern[0] = 0x7E; c->sfdLen = 1;
+  c->startBits = 1; c->stopBits = 1; c->parity = 0;
+  c->syncThreshold = 0.85; c->agcEnabled = 1; c->preFilterBandwidth = 800; c->adaptiveThreshold = 1;
+}
+
+static bool shared_fields_equal(const fskhip_config &a, const fskhip_config &b) {
+  if (a.sampleRate != b.sampleRate || a.baudRate != b.baudRate) return false;
+  if (a.preambleLen != b.preambleLen || a.sfdLen != b.sfdLen) return false;
+  if (std::memcmp(a.preamblePattern, b.preamblePattern, sizeof(int32_t) * a.preambleLen)) return false;
+  if (std::memcmp(a.sfdPattern, b.sfdPattern, sizeof(int32_t) * a.sfdLen)) return false;
+  if (a.startBits != b.startBits || a.stopBits != b.stopBits || a.parity != b.parity) return false;
+  if (a.syncThreshold != b.syncThreshold || (a.agcEnabled != 0) != (b.agcEnabled != 0)) return false;
+  return true;
+}
+
+int fskhip_destroy(fskhip_engine *e) {
+  if (!e) return FSKHIP_OK;
+  (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();
+  void *bufs[] = {e->S.rs, e->S.is, e->S.poly, e->S.amp_ring, (void *)e->S.coef, (void *)e->S.nco_inc, e->d_samples,
+                  e->d_out, e->d_counts, e->d_eod, e->d_lens, e->d_payloads, e->d_status, e->d_sigma};
+  for (void *b : bufs)
+    if (b) (void)hipFree(b);
+  for (auto ev : e->ev) (void)hipEventDestroy(ev);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return FSKHIP_OK;
+}
+
+int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams, int device, int precision,
+                  fskhip_engine **out) {
+  if (!cfgs || !out || n_streams == 0) return fail(FSKHIP_E_INVALID, "fskhip_create: null/zero argument");
+  if (n_cfgs != 1 && n_cfgs != n_streams) return fail(FSKHIP_E_INVALID, "n_cfgs must be 1 or n_streams");
+  if (precision != FSKHIP_PRECISION_F32 && precision != FSKHIP_PRECISION_F64)
+    return fail(FSKHIP_E_INVALID, "unknown precision %d", precision);
+  const fskhip_config &c0 = cfgs[0];
+  if (c0.preambleLen < 0 || c0.preambleLen > FSKHIP_MAX_PATTERN_BYTES || c0.sfdLen < 0 ||
+      c0.sfdLen > FSKHIP_MAX_PATTERN_BYTES || c0.startBits < 0 || c0.stopBits < 0 || c0.startBits > 8 ||
+      c0.stopBits > 8 || c0.parity < 0 || c0.parity > 2)
+    return fail(FSKHIP_E_INVALID, "bad framing fields");
+  if (!(c0.sampleRate > 0) || !(c0.baudRate > 0)) return fail(FSKHIP_E_INVALID, "sampleRate/baudRate must be > 0");
+  for (uint32_t i = 1; i < n_cfgs; i++)
+    if (!shared_fields_equal(c0, cfgs[i]))
+      return fail(FSKHIP_E_UNSUPPORTED, "per-stream configs may differ only in mark/space/preFilterBandwidth (stream %u)", i);
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(FSKHIP_E_NO_DEVICE, "no HIP device available (the engine has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(FSKHIP_E_NO_DEVICE, "device %d out of range (%d devices)", device, ndev);
+  if (hipSetDevice(device) != hipSuccess) return fail(FSKHIP_E_NO_DEVICE, "hipSetDevice(%d) failed", device);
+
+  fskhip_engine *e = new (std::nothrow) fskhip_engine();
+  if (!e) return fail(FSKHIP_E_NOMEM, "out of host memory");
+  e->device = device; e->precision = precision; e->n_streams = n_streams; e->cfg0 = c0;
+
+  // calculateParameters (fsk.ts:426-444), in doubles like the reference
+  const double downsampleRate = c0.sampleRate / 2;
+  e->spb = std::floor(c0.sampleRate / c0.baudRate);
+  e->bpb = 8 + c0.startBits + c0.stopBits + (c0.parity != 0 ? 1 : 0);
+  const double dsSPB = std::floor(downsampleRate / c0.baudRate);
+  if (dsSPB < 1) { delete e; return fail(FSKHIP_E_UNSUPPORTED, "downsampledSamplesPerBit < 1"); }
+
+  // preambleSfdBits via addByteToPattern (fsk.ts:159-173)
+  std::vector<int> pat;
+  auto add_byte = [&](int byte) {
+    for (int i = 0; i < c0.startBits; i++) pat.push_back(0);
+    for (int i = 7; i >= 0; i--) pat.push_back((byte >> i) & 1);
+    if (c0.parity != 0) {
+      int par = 0;
+      for (int i = 0; i < 8; i++) par ^= (byte >> i) & 1;
+      pat.push_back(c0.parity == 1 ? par : 1 - par);
+    }
+    for (int i = 0; i < c0.stopBits; i++) pat.push_back(1);
+  };
+  for (int i = 0; i < c0.preambleLen; i++) add_byte(c0.preamblePattern[i]);
+  for (int i = 0; i < c0.sfdLen; i++) add_byte(c0.sfdPattern[i]);
+  const uint32_t n_bits = (uint32_t)pat.size();
+  if (n_bits > 31) { delete e; return fail(FSKHIP_E_UNSUPPORTED, "%u preamble+SFD pattern bits (max 31)", n_bits); }
+
+  const double ring_cap = ((double)n_bits + 32) * dsSPB * 1.1;  // fsk.ts:145,149
+  if (ring_cap != std::floor(ring_cap) || ring_cap > 4.0e9) {
+    delete e;
+    return fail(FSKHIP_E_UNSUPPORTED,
+                "sync ring capacity %.17g is not an integer: the reference's RingBuffer degenerates there "
+                "(fsk.ts:149, utils.ts:38-48) and this engine does not emulate it", ring_cap);
+  }
+  DemodParams &P = e->P;
+  P.n_streams = n_streams;
+  P.d = (uint32_t)dsSPB;
+  P.cadence = (uint32_t)std::floor(dsSPB / 4 + 0.5);  // Math.round
+  P.n_bits = n_bits;
+  P.sample_count = n_bits * P.d;
+  P.ring_cap = (uint32_t)ring_cap;
+  P.amp_cap = 8 * P.d;
+  {
+    const double total = (double)P.sample_count;
+    P.matched_min = 0xFFFFFFFFu;
+    if (P.sample_count > 0)
+      for (uint32_t m = 0; m <= P.sample_count; m++)
+        if ((double)m / total > c0.syncThreshold) { P.matched_min = m; break; }
+  }
+  {
+    const double for_eod = e->bpb * dsSPB * 0.7;  // fsk.ts:148
+    double m = std::ceil(for_eod);
+    P.eod_min = m <= 0 ? 0u : (uint32_t)m;
+  }
+  P.pat_q = 0; P.pat_mask = 0;
+  for (uint32_t j = 1; j + 1 <= n_bits && j < n_bits; j++) {
+    P.pat_mask |= 1u << j;
+    if (pat[n_bits - j]) P.pat_q |= 1u << j;
+  }
+  const uint32_t matched_zero = P.d * (uint32_t)__builtin_popcount(~P.pat_q & P.pat_mask);
+  P.stop_pos = c0.parity == 0 ? 9 : 10;  // fsk.ts:348
+  P.parity_on = c0.parity != 0;
+  P.agc_on = c0.agcEnabled != 0;
+  {
+    double b[3], a[3];
+    ref_butter_lp(c0.baudRate, c0.sampleRate, b, a);  // fsk.ts:458-461
+    P.lp_b0 = b[0]; P.lp_b1 = b[1]; P.lp_b2 = b[2]; P.lp_a1 = a[1]; P.lp_a2 = a[2];
+  }
+  P.agc_attack = 1.0 - std::exp(-1.0 / (c0.sampleRate * 0.001));  // fsk.ts:48-49
+  P.agc_release = 1.0 - std::exp(-1.0 / (c0.sampleRate * 0.01));
+
+  ModParams &M = e->M;
+  M.n_streams = n_streams;
+  M.spb = (uint32_t)e->spb;
+  M.bits_per_byte = (uint32_t)e->bpb;
+  M.start_bits = c0.startBits; M.stop_bits = c0.stopBits; M.parity = c0.parity;
+  M.n_pre = c0.preambleLen + c0.sfdLen;
+  for (int i = 0; i < c0.preambleLen; i++) M.pre[i] = (uint8_t)c0.preamblePattern[i];
+  for (int i = 0; i < c0.sfdLen; i++) M.pre[c0.preambleLen + i] = (uint8_t)c0.sfdPattern[i];
+
+  e->n_blocks = (n_streams + 63) / 64;
+  e->lds_bytes = sizeof(float) * 4 * kChunks * kSlotStride + sizeof(uint32_t) * 64 * P.d;
+  if (e->lds_bytes > 160 * 1024) {
+    delete e;
+    return fail(FSKHIP_E_UNSUPPORTED, "dsSPB %u needs %zu B of LDS per wave (> 160 KiB)", P.d, e->lds_bytes);
+  }
+
+  // per-stream constants (fsk.ts:451-456, 228, 404)
+  std::vector<double> coef((size_t)CF_COUNT * n_streams);
+  std::vector<uint64_t> inc(n_streams);
+  for (uint32_t s = 0; s < n_streams; s++) {
+    const fskhip_config &c = cfgs[n_cfgs == 1 ? 0 : s];
+    const double center = (c.markFrequency + c.spaceFrequency) / 2;
+    const double span = std::fabs(c.spaceFrequency - c.markFrequency);
+    const double carson = 2 * (span / 2 + c.baudRate);
+    const double bw = c.preFilterBandwidth > carson ? c.preFilterBandwidth : carson;
+    double b[3], a[3];
+    ref_butter_bp(center, bw, c.sampleRate, b, a);
+    coef[(size_t)CF_bp_b0 * n_streams + s] = b[0];
+    coef[(size_t)CF_bp_a1 * n_streams + s] = a[1];
+    coef[(size_t)CF_bp_a2 * n_streams + s] = a[2];
+    coef[(size_t)CF_omega * n_streams + s] = 2 * M_PI * center / c.sampleRate;
+    coef[(size_t)CF_mark_w * n_streams + s] = 2 * M_PI * c.markFrequency / c.sampleRate;
+    coef[(size_t)CF_space_w * n_streams + s] = 2 * M_PI * c.spaceFrequency / c.sampleRate;
+    // NCO increment as a 64-bit fraction of a turn: frac(center/sr) * 2^64
+    long double turns = (long double)center / (long double)c.sampleRate;
+    turns -= std::floor(turns);
+    long double scaled = turns * 18446744073709551616.0L;
+    inc[s] = scaled >= 18446744073709551615.0L ? 0xFFFFFFFFFFFFFFFFull : (uint64_t)(scaled + 0.5L);
+  }
+
+#define CREATE_TRY(expr)                                                                          \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      int rc = fail(_e == hipErrorOutOfMemory ? FSKHIP_E_NOMEM : FSKHIP_E_HIP, "%s: %s", #expr,   \
+                    hipGetErrorString(_e));                                                       \
+      fskhip_destroy(e);                                                                          \
+      return rc;                                                                                  \
+    }                                                                                             \
+  } while (0)
+  const size_t rsz = precision == FSKHIP_PRECISION_F64 ? sizeof(double) : sizeof(float);
+  CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipMalloc(&e->S.rs, rsz * RF_COUNT * n_streams));
+  CREATE_TRY(hipMalloc((void **)&e->S.is, sizeof(uint32_t) * IF_COUNT * n_streams));
+  CREATE_TRY(hipMalloc((void **)&e->S.poly, sizeof(uint32_t) * 64 * (size_t)P.d * e->n_blocks));
+  CREATE_TRY(hipMalloc((void **)&e->S.amp_ring, sizeof(float) * (size_t)P.amp_cap * n_streams));
+  CREATE_TRY(hipMalloc((void **)&e->S.coef, sizeof(double) * coef.size()));
+  CREATE_TRY(hipMalloc((void **)&e->S.nco_inc, sizeof(uint64_t) * n_streams));
+  CREATE_TRY(hipMalloc((void **)&e->d_status, sizeof(StatusRaw)));
+  CREATE_TRY(hipMalloc((void **)&e->d_counts, sizeof(uint32_t) * n_streams));
+  CREATE_TRY(hipMalloc((void **)&e->d_eod, sizeof(uint32_t) * n_streams));
+  CREATE_TRY(hipMalloc((void **)&e->d_lens, sizeof(uint32_t) * n_streams));
+  CREATE_TRY(hipMalloc((void **)&e->d_sigma, sizeof(double) * n_streams));
+  CREATE_TRY(hipMemcpy((void *)e->S.coef, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
+  CREATE_TRY(hipMemcpy((void *)e->S.nco_inc, inc.data(), sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice));
+  CREATE_TRY(hipMemset(e->S.poly, 0, sizeof(uint32_t) * 64 * (size_t)P.d * e->n_blocks));
+  CREATE_TRY(hipMemset(e->S.amp_ring, 0, sizeof(float) * (size_t)P.amp_cap * n_streams));
+  {
+    dim3 g((n_streams + 255) / 256), b(256);
+    if (precision == FSKHIP_PRECISION_F64) hipLaunchKernelGGL(init_kernel<double>, g, b, 0, 0, e->S, n_streams, matched_zero);
+    else hipLaunchKernelGGL(init_kernel<float>, g, b, 0, 0, e->S, n_streams, matched_zero);
+    CREATE_TRY(hipGetLastError());
+    CREATE_TRY(hipDeviceSynchronize());
+  }
+  if (e->lds_bytes > 48 * 1024) CREATE_TRY(set_demod_lds_limit(e->lds_bytes));
+#undef CREATE_TRY
+  e->base_calls.assign(n_streams, 0);
+  e->base_samples.assign(n_streams, 0);
+  *out = e;
+  return FSKHIP_OK;
+}
+
+uint32_t fskhip_n_streams(const fskhip_engine *e) { return e ? e->n_streams : 0; }
+
+int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_t pitch, uint8_t *d_out,
+                             size_t out_pitch, uint32_t *d_out_counts, uint32_t *d_eod_counts, uint32_t flags,
+                             void *hip_stream) {
+  if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "FSK demodulator not configured");
+  if (!d_out_counts || (n > 0 && !d_samples) || (out_pitch > 0 && !d_out))
+    return fail(FSKHIP_E_INVALID, "fskhip_demodulate_device: null buffer");
+  if (pitch < n) return fail(FSKHIP_E_INVALID, "pitch %zu < n_per_stream %zu", pitch, n);
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  const bool timed = e->timing;
+  if (timed) {
+    if (e->ev_used + 2 > e->ev.size()) {
+      hipEvent_t a, b;
+      HIP_TRY(hipEventCreate(&a));
+      HIP_TRY(hipEventCreate(&b));
+      e->ev.push_back(a); e->ev.push_back(b);
+    }
+    e->timing_stream = st;
+    HIP_TRY(hipEventRecord(e->ev[e->ev_used], st));
+  }
+  HIP_TRY(launch_demod(e->precision, e->ds_uniform, (flags & FSKHIP_DEMOD_WRITEBACK_AGC) != 0, e->P, e->S, d_samples,
+                       n, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+  if (timed) {
+    HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], st));
+    e->ev_used += 2;
+  }
+  e->calls += 1;
+  e->total_samples += n;
+  return FSKHIP_OK;
+}
+
+int fskhip_demodulate_host(fskhip_engine *e, float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch,
+                           uint32_t *out_counts, uint32_t *eod_counts, uint32_t flags) {
+  if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "FSK demodulator not configured");
+  if (!out_counts || (n > 0 && !samples) || (out_pitch > 0 && !out)) return fail(FSKHIP_E_INVALID, "null buffer");
+  if (pitch < n) return fail(FSKHIP_E_INVALID, "pitch %zu < n_per_stream %zu", pitch, n);
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t S = e->n_streams;
+  // device copy keeps the caller's row pitch rounded up to 4 floats so the 16-B tile loads apply
+  const size_t dpitch = (n + 3) & ~(size_t)3;
+  int rc;
+  if ((rc = ensure(e->d_samples, e->d_samples_cap, (dpitch ? dpitch : 4) * S)) != FSKHIP_OK) return rc;
+  if ((rc = ensure(e->d_out, e->d_out_cap, (out_pitch ? out_pitch : 1) * S)) != FSKHIP_OK) return rc;
+  if (n > 0)
+    HIP_TRY(hipMemcpy2DAsync(e->d_samples, dpitch * sizeof(float), samples, pitch * sizeof(float), n * sizeof(float), S,
+                             hipMemcpyHostToDevice, e->stream));
+  rc = fskhip_demodulate_device(e, e->d_samples, n, dpitch ? dpitch : 4, e->d_out, out_pitch, e->d_counts, e->d_eod,
+                                flags, e->stream);
+  if (rc != FSKHIP_OK) return rc;
+  if (out_pitch > 0) HIP_TRY(hipMemcpyAsync(out, e->d_out, out_pitch * S, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(out_counts, e->d_counts, sizeof(uint32_t) * S, hipMemcpyDeviceToHost, e->stream));
+  if (eod_counts) HIP_TRY(hipMemcpyAsync(eod_counts, e->d_eod, sizeof(uint32_t) * S, hipMemcpyDeviceToHost, e->stream));
+  if ((flags & FSKHIP_DEMOD_WRITEBACK_AGC) && n > 0)
+    HIP_TRY(hipMemcpy2DAsync(samples, pitch * sizeof(float), e->d_samples, dpitch * sizeof(float), n * sizeof(float), S,
+                             hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (size_t s = 0; s < S; s++)
+    if (out_counts[s] > out_pitch) return fail(FSKHIP_E_OVERFLOW, "stream %zu produced %u bytes, slab holds %zu", s, out_counts[s], out_pitch);
+  return FSKHIP_OK;
+}
+
+size_t fskhip_modulated_length(const fskhip_engine *e, size_t n_bytes) {  // fsk.ts:391-394
+  if (!e) return 0;
+  const double total_bytes = (double)e->cfg0.preambleLen + (double)e->cfg0.sfdLen + (double)n_bytes;
+  const double padding = total_bytes > 0 ? e->spb * 2 : 0;
+  const double silence = e->bpb * e->spb;
+  return (size_t)(total_bytes * e->bpb * e->spb + padding + silence);
+}
+
+int fskhip_modulate_device(fskhip_engine *e, const uint8_t *d_payloads, const uint32_t *d_lens, size_t payload_pitch,
+                           float *d_out, size_t out_pitch, uint32_t *d_out_lens, void *hip_stream) {
+  if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "FSK modulator not configured");
+  if (!d_lens || !d_out || !d_out_lens) return fail(FSKHIP_E_INVALID, "null buffer");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(launch_modulate(e->M, e->S.coef, d_payloads, d_lens, payload_pitch, d_out, out_pitch, d_out_lens,
+                          (hipStream_t)hip_stream));
+  return FSKHIP_OK;
+}
+
+int fskhip_modulate_host(fskhip_engine *e, const uint8_t *payloads, const uint32_t *lens, size_t payload_pitch,
+                         float *out, size_t out_pitch, uint32_t *out_lens) {
+  if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "FSK modulator not configured");
+  if (!lens || !out || !out_lens) return fail(FSKHIP_E_INVALID, "null buffer");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t S = e->n_streams;
+  const size_t dpitch = (out_pitch + 3) & ~(size_t)3;
+  int rc;
+  if ((rc = ensure(e->d_samples, e->d_samples_cap, (dpitch ? dpitch : 4) * S)) != FSKHIP_OK) return rc;
+  if ((rc = ensure(e->d_payloads, e->d_payloads_cap, (payload_pitch ? payload_pitch : 1) * S)) != FSKHIP_OK) return rc;
+  for (size_t s = 0; s < S; s++)
+    if (lens[s] > payload_pitch) return fail(FSKHIP_E_INVALID, "lens[%zu] = %u exceeds payload_pitch %zu", s, lens[s], payload_pitch);
+  if (payload_pitch > 0 && payloads)
+    HIP_TRY(hipMemcpyAsync(e->d_payloads, payloads, payload_pitch * S, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->d_lens, lens, sizeof(uint32_t) * S, hipMemcpyHostToDevice, e->stream));
+  rc = fskhip_modulate_device(e, e->d_payloads, e->d_lens, payload_pitch, e->d_samples, dpitch, e->d_counts, e->stream);
+  if (rc != FSKHIP_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(out_lens, e->d_counts, sizeof(uint32_t) * S, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpy2DAsync(out, out_pitch * sizeof(float), e->d_samples, dpitch * sizeof(float),
+                           out_pitch * sizeof(float), S, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (size_t s = 0; s < S; s++)
+    if (out_lens[s] > out_pitch) return fail(FSKHIP_E_OVERFLOW, "stream %zu needs %u samples, slab holds %zu", s, out_lens[s], out_pitch);
+  return FSKHIP_OK;
+}
+
+int fskhip_reset(fskhip_engine *e, int64_t stream) {
+  if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "not configured");
+  if (stream >= (int64_t)e->n_streams) return fail(FSKHIP_E_INVALID, "stream out of range");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  dim3 g((e->n_streams + 255) / 256), b(256);
+  if (e->precision == FSKHIP_PRECISION_F64) hipLaunchKernelGGL(reset_kernel<double>, g, b, 0, 0, e->S, e->n_streams, stream);
+  else hipLaunchKernelGGL(reset_kernel<float>, g, b, 0, 0, e->S, e->n_streams, stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  if (stream < 0) {
+    for (auto &v : e->base_calls) v = e->calls;
+    for (auto &v : e->base_samples) v = e->total_samples;
+    e->ds_uniform = true;
+  } else {
+    e->base_calls[stream] = e->calls;
+    e->base_samples[stream] = e->total_samples;
+    // the other streams may sit mid-pair of the /2 decimator: per-lane decimation from now on
+    if (e->n_streams > 1 && (e->total_samples & 1)) e->ds_uniform = false;
+  }
+  return FSKHIP_OK;
+}
+
+int fskhip_get_status(fskhip_engine *e, uint32_t stream, fskhip_status *st) {
+  if (!st) return fail(FSKHIP_E_INVALID, "null status");
+  std::memset(st, 0, sizeof(*st));
+  if (!e) return FSKHIP_OK;  // unconfigured FSKCore: ready = false
+  if (stream >= e->n_streams) return fail(FSKHIP_E_INVALID, "stream out of range");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (e->precision == FSKHIP_PRECISION_F64) hipLaunchKernelGGL(status_kernel<double>, dim3(1), dim3(1), 0, 0, e->S, e->n_streams, stream, e->d_status);
+  else hipLaunchKernelGGL(status_kernel<float>, dim3(1), dim3(1), 0, 0, e->S, e->n_streams, stream, e->d_status);
+  HIP_TRY(hipGetLastError());
+  StatusRaw r;
+  HIP_TRY(hipMemcpy(&r, e->d_status, sizeof(r), hipMemcpyDeviceToHost));
+  st->ready = 1;
+  st->frameStarted = r.started != 0;
+  st->globalSampleCounter = r.gsc;
+  st->receivedBitsLength = r.ring_len;
+  st->byteBufferLength = 0;
+  st->demodulationCalls = (double)(e->calls - e->base_calls[stream]);
+  st->syncDetections = r.sync_det;
+  st->silenceThreshold = r.sil_thr;
+  st->totalSamplesProcessed = (double)(e->total_samples - e->base_samples[stream]);
+  st->agcGain = e->P.agc_on ? r.agc_gain : std::numeric_limits<double>::quiet_NaN();
+  st->eodCount = r.eod_total;
+  return FSKHIP_OK;
+}
+
+int fskhip_synth_device(fskhip_engine *e, float *d_out, size_t n, size_t pitch, uint32_t payload_len, uint64_t seed,
+                        uint32_t lead_max, double amp_lo, double amp_hi, void *hip_stream) {
+  if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "not configured");
+  if (!d_out || pitch < n) return fail(FSKHIP_E_INVALID, "bad buffer");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(launch_synth(e->M, e->S.coef, d_out, n, pitch, payload_len, seed, lead_max, amp_lo, amp_hi,
+                       (hipStream_t)hip_stream));
+  return FSKHIP_OK;
+}
+uint8_t fskhip_synth_payload_byte(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t i) {
+  return host_synth_payload_byte(seed, stream, frame, i);
+}
+void fskhip_synth_stream_params(uint64_t seed, uint32_t stream, uint32_t lead_max, double amp_lo, double amp_hi,
+                                uint32_t *lead, double *amp) {
+  host_synth_stream_params(seed, stream, lead_max, amp_lo, amp_hi, lead, amp);
+}
+int fskhip_add_awgn_device(fskhip_engine *e, float *d_buf, size_t n, size_t pitch, double snr_db, uint64_t seed,
+                           void *hip_stream) {
+  if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "not configured");
+  if (!d_buf || pitch < n) return fail(FSKHIP_E_INVALID, "bad buffer");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(launch_awgn(d_buf, n, pitch, e->n_streams, snr_db, seed, e->d_sigma, (hipStream_t)hip_stream));
+  return FSKHIP_OK;
+}
+
+int fskhip_device_malloc(fskhip_engine *e, size_t bytes, void **d_ptr) {
+  if (!e || !d_ptr) return fail(FSKHIP_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  hipError_t err = hipMalloc(d_ptr, bytes ? bytes : 1);
+  if (err != hipSuccess) return fail(FSKHIP_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(err));
+  return FSKHIP_OK;
+}
+int fskhip_device_free(fskhip_engine *e, void *d_ptr) {
+  if (!e) return fail(FSKHIP_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipFree(d_ptr));
+  return FSKHIP_OK;
+}
+int fskhip_memcpy_h2d(fskhip_engine *e, void *d_dst, const void *src, size_t bytes) {
+  if (!e) return fail(FSKHIP_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+  return FSKHIP_OK;
+}
+int fskhip_memcpy_d2h(fskhip_engine *e, void *dst, const void *d_src, size_t bytes) {
+  if (!e) return fail(FSKHIP_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return FSKHIP_OK;
+}
+int fskhip_synchronize(fskhip_engine *e) {
+  if (!e) return fail(FSKHIP_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  return FSKHIP_OK;
+}
+
+int fskhip_timing_begin(fskhip_engine *e) {
+  if (!e) return fail(FSKHIP_E_INVALID, "null engine");
+  e->timing = true;
+  e->ev_used = 0;
+  return FSKHIP_OK;
+}
+int fskhip_timing_end(fskhip_engine *e, uint32_t *n_launches, double *total_ms) {
+  if (!e) return fail(FSKHIP_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  e->timing = false;
+  double tot = 0;
+  uint32_t n = 0;
+  for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+    HIP_TRY(hipEventSynchronize(e->ev[i + 1]));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+    tot += ms;
+    n++;
+  }
+  e->ev_used = 0;
+  if (n_launches) *n_launches = n;
+  if (total_ms) *total_ms = tot;
+  return FSKHIP_OK;
+}
+
+}  // extern "C"

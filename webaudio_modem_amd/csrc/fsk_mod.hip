@@ -1,0 +1,294 @@
+// fsk_mod.hip -- FSK modulator (FSKCore.modulateData, src/modems/fsk.ts:377-424), the synthetic
+// multi-frame workload generator and the AWGN kernels, for gfx950.
+//
+// One lane per stream, like the demodulator: the reference's phase is an UNWRAPPED f64 that is
+// advanced by `phase += 2*pi*f/sr` once per sample and carried across bits (fsk.ts:398-406), so
+// reproducing its roundings means performing the same chain of f64 additions in order; the
+// samples of a stream are therefore produced sequentially by one lane, 32 at a time into an
+// LDS tile that the wave then stores as coalesced 16-B/lane row segments (the mirror image of
+// the demodulator's tile load).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fsk_params.h"
+
+namespace fsk {
+
+__host__ __device__ inline uint64_t fmix64(uint64_t z) {  // splitmix64 finaliser
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return z;
+}
+static constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+
+__host__ __device__ inline uint8_t synth_payload_byte(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t i) {
+  uint64_t x = fmix64(seed + kGolden * (1ull + stream));
+  x = fmix64(x ^ (kGolden * (1ull + frame)));
+  x = fmix64(x + kGolden * (1ull + i));
+  return (uint8_t)(x >> 56);
+}
+__host__ __device__ inline void synth_stream_params(uint64_t seed, uint32_t stream, uint32_t lead_max,
+                                                    double amp_lo, double amp_hi, uint32_t *lead, double *amp) {
+  uint64_t a = fmix64((seed ^ 0xA5A5A5A5A5A5A5A5ull) + kGolden * (1ull + stream));
+  uint64_t b = fmix64(a + kGolden);
+  *lead = (uint32_t)(a % ((uint64_t)lead_max + 1ull));
+  double u = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+  *amp = amp_lo + (amp_hi - amp_lo) * u;
+}
+
+// Sequential generator of one frame = what generateFSKSignalInternal() writes (fsk.ts:389-424):
+// 2*spb zeros, then for preamble|sfd|data bytes: start bits (0), 8 data bits MSB first, optional
+// parity, stop bits (1), each bit spb samples of sin(phase) with phase += w(bit); then
+// bitsPerByte*spb zeros.
+struct FrameGen {
+  double phase, w_mark, w_space;
+  uint32_t pos;        // sample position inside the frame
+  uint32_t frame_len;  // total samples
+  uint32_t sig_begin, sig_end;  // [begin, end) carries tones
+  uint32_t in_bit;     // samples emitted of the current bit
+  uint32_t bit_idx;    // index of the current bit inside the frame
+  uint32_t cur_bit;
+
+  __device__ void start(const ModParams &M, double wm, double ws, uint32_t n_payload) {
+    uint32_t total_bytes = M.n_pre + n_payload;
+    uint32_t padding = total_bytes > 0 ? 2u * M.spb : 0u;
+    phase = 0.0; w_mark = wm; w_space = ws;
+    pos = 0;
+    sig_begin = padding;
+    sig_end = padding + total_bytes * M.bits_per_byte * M.spb;
+    frame_len = sig_end + M.bits_per_byte * M.spb;
+    in_bit = M.spb;  // forces a bit fetch at the first tone sample
+    bit_idx = 0xFFFFFFFFu;
+    cur_bit = 0;
+  }
+};
+
+template <typename ByteFn>
+__device__ inline uint32_t frame_bit(const ModParams &M, uint32_t bit_idx, ByteFn payload_byte) {
+  uint32_t byte_i = bit_idx / M.bits_per_byte;
+  uint32_t p = bit_idx - byte_i * M.bits_per_byte;
+  uint32_t byte = byte_i < M.n_pre ? (uint32_t)M.pre[byte_i] : (uint32_t)payload_byte(byte_i - M.n_pre);
+  if (p < M.start_bits) return 0u;
+  p -= M.start_bits;
+  if (p < 8u) return (byte >> (7u - p)) & 1u;
+  p -= 8u;
+  if (M.parity != 0u) {
+    if (p == 0u) {
+      uint32_t par = __builtin_popcount(byte & 0xFFu) & 1u;
+      return M.parity == 1u ? par : 1u - par;
+    }
+    p -= 1u;
+  }
+  return 1u;  // stop bits
+}
+
+// next sample of the frame (f32 like the Float32Array store, fsk.ts:403)
+template <typename ByteFn>
+__device__ inline float frame_next(FrameGen &G, const ModParams &M, ByteFn payload_byte) {
+  float v = 0.0f;
+  if (G.pos >= G.sig_begin && G.pos < G.sig_end) {
+    if (G.in_bit == M.spb) {
+      G.in_bit = 0;
+      G.bit_idx++;
+      G.cur_bit = frame_bit(M, G.bit_idx, payload_byte);
+    }
+    v = (float)sin(G.phase);
+    G.phase += G.cur_bit ? G.w_mark : G.w_space;
+    G.in_bit++;
+  }
+  G.pos++;
+  return v;
+}
+
+// coalesced store of a 64-row x 32-sample LDS tile (rows = this wave's streams)
+__device__ inline void store_tile(const float4 *stage, float *out, size_t pitch, size_t t0, size_t row_len_limit,
+                                  uint32_t n_streams, const uint32_t *row_lens_lds, int vec_ok) {
+  const uint32_t lane = threadIdx.x, sub_row = lane >> 3, chunk = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint32_t lr = 8u * i + sub_row;
+    uint32_t r = blockIdx.x * 64u + lr;
+    if (r >= n_streams) continue;
+    size_t lim = row_lens_lds ? (size_t)row_lens_lds[lr] : row_len_limit;
+    size_t c0 = t0 + 4u * chunk;
+    if (c0 >= lim) continue;
+    float4 v = stage[chunk * kSlotStride + lr];
+    float *dst = out + (size_t)r * pitch + c0;
+    if (vec_ok && c0 + 4 <= lim) {
+      *reinterpret_cast<float4 *>(dst) = v;
+    } else {
+      dst[0] = v.x;
+      if (c0 + 1 < lim) dst[1] = v.y;
+      if (c0 + 2 < lim) dst[2] = v.z;
+      if (c0 + 3 < lim) dst[3] = v.w;
+    }
+  }
+}
+
+// modulateData for every stream: payloads [n_streams][payload_pitch] bytes, lens[s] bytes used.
+__global__ __launch_bounds__(64) void modulate_kernel(ModParams M, const double *__restrict__ coef,
+                                                      const uint8_t *__restrict__ payloads,
+                                                      const uint32_t *__restrict__ lens, size_t payload_pitch,
+                                                      float *__restrict__ out, size_t out_pitch, int vec_ok,
+                                                      uint32_t *__restrict__ out_lens) {
+  __shared__ float4 stage[kChunks * kSlotStride];
+  __shared__ uint32_t row_len[64];
+  __shared__ uint32_t max_len_s;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t stream = blockIdx.x * 64u + lane;
+  const bool valid = stream < M.n_streams;
+  const uint32_t row = valid ? stream : M.n_streams - 1;
+  const size_t ns = M.n_streams;
+  const uint32_t n_payload = lens[row];
+  const uint8_t *prow = payloads + (size_t)row * payload_pitch;
+  auto pb = [&](uint32_t i) -> uint8_t { return prow[i]; };
+
+  FrameGen G;
+  G.start(M, coef[(size_t)CF_mark_w * ns + row], coef[(size_t)CF_space_w * ns + row], n_payload);
+  uint32_t my_len = G.frame_len;
+  if ((size_t)my_len > out_pitch) my_len = (uint32_t)out_pitch;  // caller reports overflow from out_lens
+  row_len[lane] = valid ? my_len : 0u;
+  if (valid) out_lens[stream] = G.frame_len;
+  uint32_t mx = my_len;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(mx, o, 64); mx = t > mx ? t : mx; }
+  if (lane == 0) max_len_s = mx;
+  __syncthreads();
+  const uint32_t max_len = max_len_s;
+
+  float *stage_f = reinterpret_cast<float *>(stage);
+  for (uint32_t t0 = 0; t0 < max_len; t0 += kTile) {
+    __syncthreads();
+    for (uint32_t c = 0; c < (uint32_t)kChunks; c++) {
+      float4 v;
+      v.x = G.pos < G.frame_len ? frame_next(G, M, pb) : 0.0f;
+      v.y = G.pos < G.frame_len ? frame_next(G, M, pb) : 0.0f;
+      v.z = G.pos < G.frame_len ? frame_next(G, M, pb) : 0.0f;
+      v.w = G.pos < G.frame_len ? frame_next(G, M, pb) : 0.0f;
+      stage[c * kSlotStride + lane] = v;
+    }
+    __syncthreads();
+    store_tile(stage, out, out_pitch, t0, 0, M.n_streams, row_len, vec_ok);
+  }
+  (void)stage_f;
+}
+
+// synthetic workload: see fskhip_synth_device in include/fskhip.h
+__global__ __launch_bounds__(64) void synth_kernel(ModParams M, const double *__restrict__ coef,
+                                                   float *__restrict__ out, size_t n, size_t pitch, int vec_ok,
+                                                   uint32_t payload_len, uint64_t seed, uint32_t lead_max,
+                                                   double amp_lo, double amp_hi) {
+  __shared__ float4 stage[kChunks * kSlotStride];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t stream = blockIdx.x * 64u + lane;
+  const bool valid = stream < M.n_streams;
+  const uint32_t row = valid ? stream : M.n_streams - 1;
+  const size_t ns = M.n_streams;
+  const double wm = coef[(size_t)CF_mark_w * ns + row], ws = coef[(size_t)CF_space_w * ns + row];
+
+  uint32_t lead;
+  double amp;
+  synth_stream_params(seed, row, lead_max, amp_lo, amp_hi, &lead, &amp);
+  uint32_t frame = 0;
+  auto pb = [&](uint32_t i) -> uint8_t { return synth_payload_byte(seed, row, frame, i); };
+  FrameGen G;
+  G.start(M, wm, ws, payload_len);
+  uint64_t t = 0;  // absolute sample index
+
+  auto next = [&]() -> float {
+    float v = 0.0f;
+    if (t >= lead) {
+      if (G.pos >= G.frame_len) { frame++; G.start(M, wm, ws, payload_len); }
+      float s = frame_next(G, M, pb);
+      v = (float)((double)s * amp);
+    }
+    t++;
+    return v;
+  };
+
+  for (size_t t0 = 0; t0 < n; t0 += kTile) {
+    __syncthreads();
+    for (uint32_t c = 0; c < (uint32_t)kChunks; c++) {
+      float4 v;
+      v.x = next(); v.y = next(); v.z = next(); v.w = next();
+      stage[c * kSlotStride + lane] = v;
+    }
+    __syncthreads();
+    store_tile(stage, out, pitch, t0, n, M.n_streams, nullptr, vec_ok);
+  }
+}
+
+// ---- AWGN ------------------------------------------------------------------------------------
+// pass 1: one wave per stream, coalesced row sweep, f64 sum of squares -> sigma[s]
+__global__ __launch_bounds__(64) void power_kernel(const float *__restrict__ buf, size_t n, size_t pitch,
+                                                   uint32_t n_streams, double snr_db, double *__restrict__ sigma) {
+  const uint32_t s = blockIdx.x;
+  if (s >= n_streams) return;
+  const float *row = buf + (size_t)s * pitch;
+  double acc = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += 64) { double v = (double)row[i]; acc += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (threadIdx.x == 0) {
+    double p = n ? acc / (double)n : 0.0;
+    sigma[s] = sqrt(p / pow(10.0, snr_db / 10.0));
+  }
+}
+// pass 2: elementwise, Box-Muller on a counter-based hash of (seed, stream, sample)
+__global__ __launch_bounds__(256) void awgn_kernel(float *__restrict__ buf, size_t n, size_t pitch, uint32_t s_base,
+                                                   uint32_t n_streams, const double *__restrict__ sigma, uint64_t seed) {
+  const uint32_t s = s_base + blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (s >= n_streams || i >= n) return;
+  uint64_t h = fmix64(fmix64(seed + kGolden * (1ull + s)) ^ (kGolden * (1ull + (uint64_t)i)));
+  uint64_t h2 = fmix64(h + kGolden);
+  double u1 = ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740992.0);  // (0,1]
+  double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
+  double g = sqrt(-2.0 * log(u1)) * cos(2.0 * 3.14159265358979323846 * u2);
+  float *p = buf + (size_t)s * pitch + i;
+  *p = (float)((double)*p + sigma[s] * g);
+}
+
+hipError_t launch_modulate(const ModParams &M, const double *coef, const uint8_t *payloads, const uint32_t *lens,
+                           size_t payload_pitch, float *out, size_t out_pitch, uint32_t *out_lens, hipStream_t st) {
+  const uint32_t blocks = (M.n_streams + 63u) / 64u;
+  const int vec_ok = (out_pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+  hipLaunchKernelGGL(modulate_kernel, dim3(blocks), dim3(64), 0, st, M, coef, payloads, lens, payload_pitch, out,
+                     out_pitch, vec_ok, out_lens);
+  return hipGetLastError();
+}
+hipError_t launch_synth(const ModParams &M, const double *coef, float *out, size_t n, size_t pitch,
+                        uint32_t payload_len, uint64_t seed, uint32_t lead_max, double amp_lo, double amp_hi,
+                        hipStream_t st) {
+  const uint32_t blocks = (M.n_streams + 63u) / 64u;
+  const int vec_ok = (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+  hipLaunchKernelGGL(synth_kernel, dim3(blocks), dim3(64), 0, st, M, coef, out, n, pitch, vec_ok, payload_len, seed,
+                     lead_max, amp_lo, amp_hi);
+  return hipGetLastError();
+}
+hipError_t launch_awgn(float *buf, size_t n, size_t pitch, uint32_t n_streams, double snr_db, uint64_t seed,
+                       double *sigma, hipStream_t st) {
+  hipLaunchKernelGGL(power_kernel, dim3(n_streams), dim3(64), 0, st, buf, n, pitch, n_streams, snr_db, sigma);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // grid.y is limited to 65535: sweep streams in slabs
+  for (uint32_t s0 = 0; s0 < n_streams; s0 += 32768u) {
+    uint32_t cnt = n_streams - s0 < 32768u ? n_streams - s0 : 32768u;
+    dim3 g((unsigned)((n + 255) / 256), cnt);
+    hipLaunchKernelGGL(awgn_kernel, g, dim3(256), 0, st, buf, n, pitch, s0, n_streams, sigma, seed);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+uint8_t host_synth_payload_byte(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t i) {
+  return synth_payload_byte(seed, stream, frame, i);
+}
+void host_synth_stream_params(uint64_t seed, uint32_t stream, uint32_t lead_max, double amp_lo, double amp_hi,
+                              uint32_t *lead, double *amp) {
+  synth_stream_params(seed, stream, lead_max, amp_lo, amp_hi, lead, amp);
+}
+
+}  // namespace fsk

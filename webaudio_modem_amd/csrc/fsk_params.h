@@ -1,0 +1,106 @@
+// fsk_params.h -- launch parameters and persistent per-stream state layout shared by the host
+// API (fsk_api.hip) and the kernels (fsk_demod.hip / fsk_mod.hip).
+//
+// State is struct-of-arrays in HBM: field-major [field][stream] so that a wave (64 consecutive
+// streams) loads/stores each field with one coalesced 256-B (f32/u32) or 512-B (f64) access.
+#pragma once
+#include <stdint.h>
+
+namespace fsk {
+
+// ---- real-valued per-stream state (f32 or f64 depending on engine precision) -----------------
+// Names follow the reference members they hold (src/modems/fsk.ts:87-128, src/dsp/filters.ts:11-12).
+#define FSK_REAL_FIELDS(X)                                                                  \
+  X(agc_gain)   /* AGCProcessor.currentGain fsk.ts:40 */                                    \
+  X(bp_x1) X(bp_x2) X(bp_y1) X(bp_y2)   /* preFilter history filters.ts:11-12 */            \
+  X(li_x1) X(li_x2) X(li_y1) X(li_y2)   /* iqFilters.i */                                   \
+  X(lq_x1) X(lq_x2) X(lq_y1) X(lq_y2)   /* iqFilters.q */                                   \
+  X(po_x1) X(po_x2) X(po_y1) X(po_y2)   /* postFilter */                                    \
+  X(acc_i) X(acc_q)                     /* downsample.{i,q}Accumulator fsk.ts:105-109 */    \
+  X(last_phase)                         /* iqState.lastPhase fsk.ts:102 */                  \
+  X(nco_phase)                          /* iqState.localOscPhase (f64 path only) */         \
+  X(sil_thr)                            /* silence.threshold fsk.ts:128 */
+
+// ---- integer per-stream state ----------------------------------------------------------------
+#define FSK_INT_FIELDS(X)                                                                   \
+  X(nco_lo) X(nco_hi)   /* f32 path: NCO phase as a 64-bit fraction of a turn */            \
+  X(ds_cnt)             /* downsample.counter fsk.ts:106 */                                 \
+  X(gsc)                /* bitSync.globalSampleCounter fsk.ts:113 */                        \
+  X(cad_ctr)            /* gsc % round(dsSPB/4), kept incrementally (fsk.ts:302) */         \
+  X(sil_cnt)            /* silence.sampleCount */                                           \
+  X(started)            /* frame.started */                                                 \
+  X(bit_acc) X(bit_cnt) X(bit_sample_ctr) X(next_bit_idx)   /* bitSync.* fsk.ts:113-114 */  \
+  X(byte_cur) X(bit_pos)                /* byteState fsk.ts:125 */                          \
+  X(ring_len)           /* syncSamplesBuffer.length (utils.ts:10) */                        \
+  X(poly_phase)         /* pushes into the sync ring mod dsSPB (polyphase register index) */\
+  X(matched)            /* running value of the fsk.ts:304-312 match count */               \
+  X(amp_pos) X(amp_len) /* syncAmplitudeBuffer write index / length */                      \
+  X(sync_det)           /* debug.syncDetections */                                          \
+  X(eod_total)          /* 'eod' events since create */
+
+enum RealField {
+#define X(n) RF_##n,
+  FSK_REAL_FIELDS(X)
+#undef X
+  RF_COUNT
+};
+enum IntField {
+#define X(n) IF_##n,
+  FSK_INT_FIELDS(X)
+#undef X
+  IF_COUNT
+};
+
+// per-stream configure-time constants, [field][stream] doubles (converted in-kernel for f32)
+enum CoefField {
+  CF_bp_b0,   // butterworthBandpass b[0]   (b[1] = 0, b[2] = -b[0], filters.ts:230)
+  CF_bp_a1,
+  CF_bp_a2,
+  CF_omega,   // 2*pi*centerFreq/sampleRate (fsk.ts:228)
+  CF_mark_w,  // 2*pi*markFrequency/sampleRate  (modulator, fsk.ts:404)
+  CF_space_w, // 2*pi*spaceFrequency/sampleRate
+  CF_COUNT
+};
+
+struct DemodParams {
+  uint32_t n_streams;
+  uint32_t d;             // downsampledSamplesPerBit (fsk.ts:442)
+  uint32_t cadence;       // Math.round(dsSPB/4) (fsk.ts:299); 0 = the % never hits
+  uint32_t n_bits;        // preambleSfdBits.length
+  uint32_t sample_count;  // n_bits * d (fsk.ts:298)
+  uint32_t ring_cap;      // syncSamplesBuffer capacity (integer, checked at create)
+  uint32_t amp_cap;       // syncAmplitudeBuffer capacity = 8*d (fsk.ts:150)
+  uint32_t matched_min;   // smallest integer `matched` with matched/total > syncThreshold in f64
+  uint32_t eod_min;       // ceil(silence.samplesForEOD) (fsk.ts:148, 288)
+  uint32_t pat_q;         // bit j (1..n_bits-1) = preambleSfdBits[n_bits - j] (fsk.ts:307)
+  uint32_t pat_mask;      // bits 1..n_bits-1
+  uint32_t stop_pos;      // 9 or 10 (fsk.ts:348)
+  uint32_t parity_on;
+  uint32_t agc_on;
+  double lp_b0, lp_b1, lp_b2, lp_a1, lp_a2;  // butterworthLowpass(baud, sr) (fsk.ts:458-461)
+  double agc_attack, agc_release;            // fsk.ts:48-49
+};
+
+struct DemodState {
+  void *rs;           // Real   [RF_COUNT][n_streams]
+  uint32_t *is;       // u32    [IF_COUNT][n_streams]
+  uint32_t *poly;     // u32    [n_blocks][d][64]   polyphase sync-bit registers
+  float *amp_ring;    // f32    [amp_cap][n_streams] syncAmplitudeBuffer storage
+  const double *coef; // double [CF_COUNT][n_streams]
+  const uint64_t *nco_inc; // u64 [n_streams]: round(centerFreq/sampleRate * 2^64)
+};
+
+struct ModParams {
+  uint32_t n_streams;
+  uint32_t spb;           // samplesPerBit (fsk.ts:438)
+  uint32_t bits_per_byte; // fsk.ts:439
+  uint32_t start_bits, stop_bits, parity; // parity 0/1/2
+  uint32_t n_pre;         // preamble + sfd bytes
+  uint8_t pre[2 * 16];
+};
+
+static constexpr int kTile = 32;            // samples per stream per LDS tile (128 B per row)
+static constexpr int kChunks = kTile / 4;   // 16-B chunks per row per tile
+static constexpr int kSlotStride = 65;      // 16-B slots per chunk column (64 lanes + 1 pad)
+
+}  // namespace fsk
