@@ -86,9 +86,12 @@ void fskhip_default_config(fskhip_config *cfg);
  * markFrequency / spaceFrequency / preFilterBandwidth; every other field must be equal across
  * streams -- BASELINE config #4).  `device` is the HIP device ordinal.  `precision` is
  * FSKHIP_PRECISION_*.
- * FSKHIP_E_UNSUPPORTED: a fractional sync-ring capacity (maxSyncBits*dsSPB*1.1 not an integer,
- * e.g. 44.1 kHz; the reference's ring stops working after one wrap there, fsk.ts:149 /
- * utils.ts:38-48), more than 31 preamble+SFD pattern bits, or dsSPB too large for LDS.
+ * The modulator supports every configuration.  The demodulator does not implement: a fractional
+ * sync-ring capacity (maxSyncBits*dsSPB*1.1 not an integer, e.g. 44.1 kHz; the reference's ring
+ * stops working after one wrap there, fsk.ts:149 / utils.ts:38-48), more than 63 preamble+SFD
+ * pattern bits, or dsSPB too large for LDS: create succeeds, fskhip_demod_supported() is 0 and
+ * fskhip_demodulate_* return FSKHIP_E_UNSUPPORTED with the reason (loud, no fallback).
+ * FSKHIP_E_UNSUPPORTED at create: per-stream configs that differ in a shared field.
  */
 int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams, int device,
                   int precision, fskhip_engine **out);
@@ -154,6 +157,18 @@ void fskhip_synth_stream_params(uint64_t seed, uint32_t stream, uint32_t lead_ma
  * 1184-1205), counter-based generator keyed by (seed, stream, sample). */
 int fskhip_add_awgn_device(fskhip_engine *e, float *d_buf, size_t n_per_stream, size_t pitch,
                            double snr_db, uint64_t seed, void *hip_stream);
+
+/* 1 if the demodulator kernels implement this engine's configuration (see fskhip_create). */
+int fskhip_demod_supported(const fskhip_engine *e);
+
+/*
+ * Intermediate capture for parity tests: records, for ONE stream, every decimated sample's I/Q
+ * magnitude sqrt(avgI^2+avgQ^2) (fsk.ts:252), post-filter output (fsk.ts:261) and slicer bit
+ * (fsk.ts:264) of the following demodulate calls, up to `capacity` samples.  stream < 0
+ * disables.  fskhip_trace_read copies out what was captured (n = count).
+ */
+int fskhip_trace_enable(fskhip_engine *e, int64_t stream, size_t capacity);
+int fskhip_trace_read(fskhip_engine *e, double *amp, double *post, uint8_t *bit, size_t cap, size_t *n);
 
 /* FilterDesign.butterworth* (filters.ts:180-234): the configure-time designs the engine uses. */
 void fskhip_butterworth_lowpass(double cutoff, double sampleRate, double b[3], double a[3]);

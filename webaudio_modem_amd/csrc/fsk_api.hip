@@ -19,6 +19,7 @@ hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, const De
                         float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch,
                         uint32_t *out_counts, uint32_t *eod_counts, hipStream_t stream);
 hipError_t set_demod_lds_limit(size_t lds_bytes);
+size_t demod_lds_bytes(const DemodParams &P);
 hipError_t launch_modulate(const ModParams &M, const double *coef, const uint8_t *payloads, const uint32_t *lens,
                            size_t payload_pitch, float *out, size_t out_pitch, uint32_t *out_lens, hipStream_t st);
 hipError_t launch_synth(const ModParams &M, const double *coef, float *out, size_t n, size_t pitch,
@@ -119,6 +120,9 @@ struct fskhip_engine {
   uint64_t calls = 0, total_samples = 0;
   std::vector<uint64_t> base_calls, base_samples;
   bool ds_uniform = true;
+  bool demod_ok = true;          // false: configuration the demodulator kernels do not implement
+  std::string demod_why;
+  uint32_t trace_cap = 0;
   // scratch for the _host entry points
   hipStream_t stream = nullptr;
   float *d_samples = nullptr; size_t d_samples_cap = 0;
@@ -214,7 +218,8 @@ int fskhip_destroy(fskhip_engine *e) {
   (void)hipSetDevice(e->device);
   (void)hipDeviceSynchronize();
   void *bufs[] = {e->S.rs, e->S.is, e->S.poly, e->S.amp_ring, (void *)e->S.coef, (void *)e->S.nco_inc, e->d_samples,
-                  e->d_out, e->d_counts, e->d_eod, e->d_lens, e->d_payloads, e->d_status, e->d_sigma};
+                  e->d_out, e->d_counts, e->d_eod, e->d_lens, e->d_payloads, e->d_status, e->d_sigma,
+                  e->S.trace_amp, e->S.trace_post, e->S.trace_bit, e->S.trace_n, e->S.poly_u};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (auto ev : e->ev) (void)hipEventDestroy(ev);
@@ -271,14 +276,38 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   for (int i = 0; i < c0.preambleLen; i++) add_byte(c0.preamblePattern[i]);
   for (int i = 0; i < c0.sfdLen; i++) add_byte(c0.sfdPattern[i]);
   const uint32_t n_bits = (uint32_t)pat.size();
-  if (n_bits > 31) { delete e; return fail(FSKHIP_E_UNSUPPORTED, "%u preamble+SFD pattern bits (max 31)", n_bits); }
-
+  char why[256];
+  if (n_bits > 63) {
+    snprintf(why, sizeof(why), "%u preamble+SFD pattern bits (max 63)", n_bits);
+    e->demod_ok = false; e->demod_why = why;
+  }
   const double ring_cap = ((double)n_bits + 32) * dsSPB * 1.1;  // fsk.ts:145,149
-  if (ring_cap != std::floor(ring_cap) || ring_cap > 4.0e9) {
-    delete e;
-    return fail(FSKHIP_E_UNSUPPORTED,
-                "sync ring capacity %.17g is not an integer: the reference's RingBuffer degenerates there "
-                "(fsk.ts:149, utils.ts:38-48) and this engine does not emulate it", ring_cap);
+  bool frac = false;
+  if (e->demod_ok && ring_cap > 4.0e9) {
+    snprintf(why, sizeof(why), "sync ring capacity %.17g too large", ring_cap);
+    e->demod_ok = false; e->demod_why = why;
+  }
+  if (e->demod_ok && ring_cap != std::floor(ring_cap)) {
+    // Fractional capacity: the reference's RingBuffer freezes after floor(cap) pushes (see
+    // fsk_demod.hip).  That model holds while the index sequence w -> (w+1) % cap stays
+    // non-integral: w = p - n*cap exactly (all values sit on cap's ulp grid), so it turns integral
+    // again after n = 2^k/gcd(m,2^k) wraps where frac(cap) = m/2^k.  Refuse if that can happen
+    // within 2^40 pushes.
+    frac = true;
+    double f = ring_cap - std::floor(ring_cap);
+    int k = 0;
+    while (f != std::floor(f) && k < 80) { f *= 2; k++; }
+    // f is now the odd-or-even integer m scaled by 2^k; strip common factors of two
+    double m = f;
+    int v2 = 0;
+    while (k - v2 > 0 && std::fmod(m, 2.0) == 0.0) { m /= 2; v2++; }
+    const double wraps = std::ldexp(1.0, k - v2);
+    if (wraps * std::floor(ring_cap) < 1.0995e12) {
+      snprintf(why, sizeof(why),
+               "sync ring capacity %.17g: the reference's fractional ring index turns integral again after "
+               "%.0f wraps (fsk.ts:149, utils.ts:38-48); not emulated", ring_cap, wraps);
+      e->demod_ok = false; e->demod_why = why;
+    }
   }
   DemodParams &P = e->P;
   P.n_streams = n_streams;
@@ -286,7 +315,10 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   P.cadence = (uint32_t)std::floor(dsSPB / 4 + 0.5);  // Math.round
   P.n_bits = n_bits;
   P.sample_count = n_bits * P.d;
-  P.ring_cap = (uint32_t)ring_cap;
+  P.frac = frac ? 1u : 0u;
+  P.ring_int = e->demod_ok ? (uint32_t)std::floor(ring_cap) : 0u;
+  // utils.ts:42-43: _length grows while < maxLength, so it saturates at floor(cap)+1 when fractional
+  P.ring_cap = e->demod_ok ? (uint32_t)std::floor(ring_cap) + (frac ? 1u : 0u) : 0u;
   P.amp_cap = 8 * P.d;
   {
     const double total = (double)P.sample_count;
@@ -301,11 +333,12 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     P.eod_min = m <= 0 ? 0u : (uint32_t)m;
   }
   P.pat_q = 0; P.pat_mask = 0;
-  for (uint32_t j = 1; j + 1 <= n_bits && j < n_bits; j++) {
-    P.pat_mask |= 1u << j;
-    if (pat[n_bits - j]) P.pat_q |= 1u << j;
+  for (uint32_t j = 1; j < n_bits && j < 64; j++) {
+    P.pat_mask |= 1ull << j;
+    if (pat[n_bits - j]) P.pat_q |= 1ull << j;
   }
-  const uint32_t matched_zero = P.d * (uint32_t)__builtin_popcount(~P.pat_q & P.pat_mask);
+  P.wide = (n_bits > 31 || frac) ? 1u : 0u;
+  const uint32_t matched_zero = P.d * (uint32_t)__builtin_popcountll(~P.pat_q & P.pat_mask);
   P.stop_pos = c0.parity == 0 ? 9 : 10;  // fsk.ts:348
   P.parity_on = c0.parity != 0;
   P.agc_on = c0.agcEnabled != 0;
@@ -327,12 +360,11 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   for (int i = 0; i < c0.sfdLen; i++) M.pre[c0.preambleLen + i] = (uint8_t)c0.sfdPattern[i];
 
   e->n_blocks = (n_streams + 63) / 64;
-  e->lds_bytes = sizeof(float) * 4 * kChunks * kSlotStride + sizeof(uint32_t) * 64 * P.d;
-  if (e->lds_bytes > 160 * 1024) {
-    delete e;
-    return fail(FSKHIP_E_UNSUPPORTED, "dsSPB %u needs %zu B of LDS per wave (> 160 KiB)", P.d, e->lds_bytes);
+  e->lds_bytes = demod_lds_bytes(P);
+  if (e->demod_ok && e->lds_bytes > 160 * 1024) {
+    snprintf(why, sizeof(why), "dsSPB %u needs %zu B of LDS per wave (> 160 KiB)", P.d, e->lds_bytes);
+    e->demod_ok = false; e->demod_why = why;
   }
-
   // per-stream constants (fsk.ts:451-456, 228, 404)
   std::vector<double> coef((size_t)CF_COUNT * n_streams);
   std::vector<uint64_t> inc(n_streams);
@@ -371,7 +403,8 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   CREATE_TRY(hipMalloc(&e->S.rs, rsz * RF_COUNT * n_streams));
   CREATE_TRY(hipMalloc((void **)&e->S.is, sizeof(uint32_t) * IF_COUNT * n_streams));
-  CREATE_TRY(hipMalloc((void **)&e->S.poly, sizeof(uint32_t) * 64 * (size_t)P.d * e->n_blocks));
+  const size_t poly_bytes = (P.wide ? sizeof(uint64_t) : sizeof(uint32_t)) * 64 * (size_t)P.d * e->n_blocks;
+  CREATE_TRY(hipMalloc((void **)&e->S.poly, poly_bytes));
   CREATE_TRY(hipMalloc((void **)&e->S.amp_ring, sizeof(float) * (size_t)P.amp_cap * n_streams));
   CREATE_TRY(hipMalloc((void **)&e->S.coef, sizeof(double) * coef.size()));
   CREATE_TRY(hipMalloc((void **)&e->S.nco_inc, sizeof(uint64_t) * n_streams));
@@ -382,7 +415,11 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   CREATE_TRY(hipMalloc((void **)&e->d_sigma, sizeof(double) * n_streams));
   CREATE_TRY(hipMemcpy((void *)e->S.coef, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
   CREATE_TRY(hipMemcpy((void *)e->S.nco_inc, inc.data(), sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice));
-  CREATE_TRY(hipMemset(e->S.poly, 0, sizeof(uint32_t) * 64 * (size_t)P.d * e->n_blocks));
+  CREATE_TRY(hipMemset(e->S.poly, 0, poly_bytes));
+  if (P.frac) {
+    CREATE_TRY(hipMalloc((void **)&e->S.poly_u, poly_bytes));
+    CREATE_TRY(hipMemset(e->S.poly_u, 0, poly_bytes));
+  }
   CREATE_TRY(hipMemset(e->S.amp_ring, 0, sizeof(float) * (size_t)P.amp_cap * n_streams));
   {
     dim3 g((n_streams + 255) / 256), b(256);
@@ -391,7 +428,8 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     CREATE_TRY(hipGetLastError());
     CREATE_TRY(hipDeviceSynchronize());
   }
-  if (e->lds_bytes > 48 * 1024) CREATE_TRY(set_demod_lds_limit(e->lds_bytes));
+  if (e->demod_ok && e->lds_bytes > 48 * 1024) CREATE_TRY(set_demod_lds_limit(e->lds_bytes));
+  e->S.trace_stream = 0xFFFFFFFFu;
 #undef CREATE_TRY
   e->base_calls.assign(n_streams, 0);
   e->base_samples.assign(n_streams, 0);
@@ -408,6 +446,7 @@ int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_
   if (!d_out_counts || (n > 0 && !d_samples) || (out_pitch > 0 && !d_out))
     return fail(FSKHIP_E_INVALID, "fskhip_demodulate_device: null buffer");
   if (pitch < n) return fail(FSKHIP_E_INVALID, "pitch %zu < n_per_stream %zu", pitch, n);
+  if (!e->demod_ok) return fail(FSKHIP_E_UNSUPPORTED, "demodulator unsupported for this configuration: %s", e->demod_why.c_str());
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)hip_stream;
   const bool timed = e->timing;
@@ -609,6 +648,47 @@ int fskhip_synchronize(fskhip_engine *e) {
   if (!e) return fail(FSKHIP_E_INVALID, "null engine");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
+  return FSKHIP_OK;
+}
+
+int fskhip_demod_supported(const fskhip_engine *e) { return e && e->demod_ok ? 1 : 0; }
+
+int fskhip_trace_enable(fskhip_engine *e, int64_t stream, size_t capacity) {
+  if (!e) return fail(FSKHIP_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  void *old[] = {e->S.trace_amp, e->S.trace_post, e->S.trace_bit, e->S.trace_n};
+  for (void *b : old)
+    if (b) (void)hipFree(b);
+  e->S.trace_amp = nullptr; e->S.trace_post = nullptr; e->S.trace_bit = nullptr; e->S.trace_n = nullptr;
+  e->S.trace_stream = 0xFFFFFFFFu; e->S.trace_cap = 0; e->trace_cap = 0;
+  if (stream < 0) return FSKHIP_OK;
+  if (stream >= (int64_t)e->n_streams) return fail(FSKHIP_E_INVALID, "stream out of range");
+  const size_t cap = capacity ? capacity : 1;
+  HIP_TRY(hipMalloc((void **)&e->S.trace_amp, sizeof(double) * cap));
+  HIP_TRY(hipMalloc((void **)&e->S.trace_post, sizeof(double) * cap));
+  HIP_TRY(hipMalloc((void **)&e->S.trace_bit, cap));
+  HIP_TRY(hipMalloc((void **)&e->S.trace_n, sizeof(uint32_t)));
+  HIP_TRY(hipMemset(e->S.trace_n, 0, sizeof(uint32_t)));
+  e->S.trace_stream = (uint32_t)stream;
+  e->S.trace_cap = (uint32_t)cap;
+  e->trace_cap = (uint32_t)cap;
+  return FSKHIP_OK;
+}
+
+int fskhip_trace_read(fskhip_engine *e, double *amp, double *post, uint8_t *bit, size_t cap, size_t *n) {
+  if (!e || !n) return fail(FSKHIP_E_INVALID, "null argument");
+  if (!e->S.trace_n) return fail(FSKHIP_E_INVALID, "trace not enabled");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  uint32_t cnt = 0;
+  HIP_TRY(hipMemcpy(&cnt, e->S.trace_n, sizeof(cnt), hipMemcpyDeviceToHost));
+  size_t m = cnt < e->trace_cap ? cnt : e->trace_cap;
+  if (m > cap) m = cap;
+  if (amp && m) HIP_TRY(hipMemcpy(amp, e->S.trace_amp, sizeof(double) * m, hipMemcpyDeviceToHost));
+  if (post && m) HIP_TRY(hipMemcpy(post, e->S.trace_post, sizeof(double) * m, hipMemcpyDeviceToHost));
+  if (bit && m) HIP_TRY(hipMemcpy(bit, e->S.trace_bit, m, hipMemcpyDeviceToHost));
+  *n = m;
   return FSKHIP_OK;
 }
 

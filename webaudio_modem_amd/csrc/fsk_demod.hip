@@ -21,6 +21,18 @@
 // at times == p mod dsSPB, newest in bit 0), so the 30 window slots' entering/leaving bits at
 // each step are two masked popcounts of ONE register; `matched` is carried incrementally and is
 // at every step exactly the count the reference's double loop would produce.
+//
+// Fractional ring capacities (FRAC kernels).  The reference sizes its sync ring
+// maxSyncBits*dsSPB*1.1 (fsk.ts:149), which is often NOT an integer in f64 (44.1 kHz; 48 kHz with
+// parity, two stop bits or a longer preamble: 65*20*1.1 = 1430.0000000000002).  Its RingBuffer
+// (utils.ts:28-48) then works for the first A = floor(capacity) pushes after configure()/clear()
+// and degenerates: the write index turns fractional, every later store is dropped and every
+// later slot reads `undefined`, which equals nothing but the equally undefined
+// preambleSfdBits[length] of window slot 0 (fsk.ts:306-307).  That is reproduced exactly: once a
+// stream has pushed A samples, pushes mark their tap UNDEFINED in a second register set; slots
+// 1.. count only defined matching taps and slot 0 counts undefined ones.  (The host verifies at
+// create time that the fractional index sequence cannot become integral again within 2^40
+// pushes; otherwise the configuration is refused.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -41,11 +53,13 @@ struct Consts;
 
 template <>
 struct Consts<float> {
-  float lp_b0, lp_a1, lp_a2, agc_att, agc_rel;
+  float lp_b0, lp_a2, lp_delta, agc_att, agc_rel;
   float bp_b0, bp_a1, bp_a2;
   uint32_t inc_lo, inc_hi;
   __device__ void init(const DemodParams &P, const DemodState &S, uint32_t row) {
-    lp_b0 = (float)P.lp_b0; lp_a1 = (float)P.lp_a1; lp_a2 = (float)P.lp_a2;
+    // delta = 1 + a1 + a2 (= b0+b1+b2 for the unity-DC-gain Butterworth) is formed in f64 and only
+    // then rounded: rounding a1 ~ -1.94 itself to f32 would move the DC gain by ~1e-4 at 300 baud
+    lp_b0 = (float)P.lp_b0; lp_a2 = (float)P.lp_a2; lp_delta = (float)(1.0 + P.lp_a1 + P.lp_a2);
     agc_att = (float)P.agc_attack; agc_rel = (float)P.agc_release;
     size_t n = P.n_streams;
     bp_b0 = (float)S.coef[(size_t)CF_bp_b0 * n + row];
@@ -149,7 +163,7 @@ __device__ inline void front(Lane<double> &L, const Consts<double> &C, bool agc_
 }
 
 // decimated-rate discriminator (fsk.ts:245-264): returns the slicer bit, amplitude by reference
-__device__ inline uint32_t discriminate(Lane<double> &L, const Consts<double> &C, double &amp) {
+__device__ inline uint32_t discriminate(Lane<double> &L, const Consts<double> &C, double &amp, double &post) {
   const double PI = 3.14159265358979323846;
   double avg_i = L.acc_i / 2.0;
   double avg_q = L.acc_q / 2.0;
@@ -161,6 +175,7 @@ __device__ inline uint32_t discriminate(Lane<double> &L, const Consts<double> &C
   L.last_phase = phase;
   double f = biquad64(C.lp_b0, C.lp_b1, C.lp_b2, C.lp_a1, C.lp_a2, L.po_x1, L.po_x2, L.po_y1, L.po_y2, dphi);
   L.acc_i = 0.0; L.acc_q = 0.0;
+  post = f;
   return f > 0.0 ? 1u : 0u;
 }
 
@@ -171,13 +186,18 @@ __device__ inline void nco_reset(Lane<double> &L) { L.nco_phase = 0.0; }
 // folded, FMAs are explicit, 1/x is v_rcp_f32, the NCO is a 64-bit turn accumulator feeding
 // v_sin_f32 / v_cos_f32 (which take revolutions).
 
-__device__ inline float lp32(float b0, float a1, float a2, float &x1, float &x2, float &y1, float &y2, float x) {
+// Low-pass biquad in "velocity" form.  With v = y[n-1] - y[n-2] kept as state,
+//   y[n] = y[n-1] + a2*v + (b0*(x + 2*x1 + x2) - delta*y[n-1]),   delta = 1 + a1 + a2
+// is algebraically the reference's Direct Form I (filters.ts:47-76) but the poles sit close to
+// z = 1 (cutoff = baud << fs), where DF-I in f32 amplifies both coefficient and state rounding by
+// 1/|A(1)| ~ 700 (300 baud); here the rounding of y is fed back only through delta ~ 1.5e-3.
+// State: y1 holds y[n-1], y2 holds v.
+__device__ inline float lp32(float b0, float a2, float delta, float &x1, float &x2, float &y, float &v, float x) {
   float t = __builtin_fmaf(2.0f, x1, x) + x2;
-  float y = b0 * t;
-  y = __builtin_fmaf(-a1, y1, y);
-  y = __builtin_fmaf(-a2, y2, y);
+  float u = __builtin_fmaf(-delta, y, b0 * t);
+  v = __builtin_fmaf(a2, v, u);
+  y = y + v;
   x2 = x1; x1 = x;
-  y2 = y1; y1 = y;
   return y;
 }
 
@@ -206,13 +226,13 @@ __device__ inline void front(Lane<float> &L, const Consts<float> &C, bool agc_on
   uint32_t lo = L.nco_lo + C.inc_lo;
   L.nco_hi = L.nco_hi + C.inc_hi + (lo < L.nco_lo ? 1u : 0u);
   L.nco_lo = lo;
-  float fi = lp32(C.lp_b0, C.lp_a1, C.lp_a2, L.li_x1, L.li_x2, L.li_y1, L.li_y2, y * c);
-  float fq = lp32(C.lp_b0, C.lp_a1, C.lp_a2, L.lq_x1, L.lq_x2, L.lq_y1, L.lq_y2, y * s);
+  float fi = lp32(C.lp_b0, C.lp_a2, C.lp_delta, L.li_x1, L.li_x2, L.li_y1, L.li_y2, y * c);
+  float fq = lp32(C.lp_b0, C.lp_a2, C.lp_delta, L.lq_x1, L.lq_x2, L.lq_y1, L.lq_y2, y * s);
   L.acc_i += fi;
   L.acc_q += fq;
 }
 
-__device__ inline uint32_t discriminate(Lane<float> &L, const Consts<float> &C, float &amp) {
+__device__ inline uint32_t discriminate(Lane<float> &L, const Consts<float> &C, float &amp, float &post) {
   const float PI = 3.14159265358979323846f;
   // + 0.0f canonicalises -0 to +0: the reference's averages are never -0 (sums start at +0),
   // and atan2(+0, -0) would be pi instead of 0 on an all-zero input
@@ -224,8 +244,9 @@ __device__ inline uint32_t discriminate(Lane<float> &L, const Consts<float> &C, 
   if (dphi > PI) dphi -= 2.0f * PI;
   else if (dphi < -PI) dphi += 2.0f * PI;
   L.last_phase = phase;
-  float f = lp32(C.lp_b0, C.lp_a1, C.lp_a2, L.po_x1, L.po_x2, L.po_y1, L.po_y2, dphi);
+  float f = lp32(C.lp_b0, C.lp_a2, C.lp_delta, L.po_x1, L.po_x2, L.po_y1, L.po_y2, dphi);
   L.acc_i = 0.0f; L.acc_q = 0.0f;
+  post = f;
   return f > 0.0f ? 1u : 0u;
 }
 
@@ -291,20 +312,36 @@ __device__ inline double wave_sum(double v) {
 
 // processDownsampledBit fsk.ts:278-344 for every lane with act set.  Must be called by the
 // whole wave (it contains a wave-cooperative amplitude-ring read at sync time).
-template <typename Real>
+__device__ inline uint32_t popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+__device__ inline uint32_t popc(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
+
+template <typename Real, typename PolyT, bool FRAC>
 __device__ inline void downsampled_bit(Lane<Real> &L, const DemodParams &P, const DemodState &S,
-                                       uint32_t *poly, uint32_t lane, uint32_t row, bool valid,
+                                       PolyT *poly, PolyT *poly_u, uint32_t lane, uint32_t row, bool valid,
                                        bool act, uint32_t bit, Real amp, OutCtx &O) {
+  const PolyT pat_q = (PolyT)P.pat_q, pat_mask = (PolyT)P.pat_mask;
   bool sync_now = false;
   if (act) {
     // syncSamplesBuffer.put(bit): polyphase register of this push slot, newest bit in bit 0
     uint32_t idx = L.poly_phase * 64u + lane;
-    uint32_t r = (poly[idx] << 1) | bit;
+    PolyT r, u = 0;
+    if (FRAC) {
+      const bool undef = L.ring_len >= P.ring_int;  // this store is dropped by the reference's ring
+      u = (PolyT)(poly_u[idx] << 1) | (PolyT)(undef ? 1u : 0u);
+      poly_u[idx] = u;
+      r = (PolyT)(poly[idx] << 1) | (PolyT)(undef ? 0u : bit);
+    } else {
+      r = (PolyT)(poly[idx] << 1) | (PolyT)bit;
+    }
     poly[idx] = r;
     L.poly_phase = (L.poly_phase + 1 == P.d) ? 0u : L.poly_phase + 1;
     // slots j = 1..n_bits-1 gain tap j and lose tap j+1 (see file header)
-    L.matched += __builtin_popcount(~(r ^ P.pat_q) & P.pat_mask);
-    L.matched -= __builtin_popcount(~((r >> 1) ^ P.pat_q) & P.pat_mask);
+    L.matched += popc((PolyT)(~(r ^ pat_q) & ~u & pat_mask));
+    L.matched -= popc((PolyT)(~((r >> 1) ^ pat_q) & ~(u >> 1) & pat_mask));
+    if (FRAC) {  // slot 0 compares against `undefined`: it counts undefined taps
+      L.matched += (uint32_t)(u & 1u);
+      L.matched -= (uint32_t)((u >> 1) & 1u);
+    }
     if (L.ring_len < P.ring_cap) L.ring_len++;
     // syncAmplitudeBuffer.put(amp): Float32Array store
     if (valid) S.amp_ring[(size_t)L.amp_pos * P.n_streams + row] = (float)amp;
@@ -371,15 +408,18 @@ __device__ inline void downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
 // ------------------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------------------
-template <typename Real, bool UNI, bool WRITEBACK>
+template <typename Real, typename PolyT, bool FRAC, bool UNI>
 __global__ __launch_bounds__(64) void demod_kernel(DemodParams P, DemodState S, float *__restrict__ samples,
-                                                   size_t n, size_t pitch, int vec_ok,
+                                                   size_t n, size_t pitch, int vec_ok, int writeback,
                                                    uint8_t *__restrict__ out, size_t out_pitch,
                                                    uint32_t *__restrict__ out_counts,
                                                    uint32_t *__restrict__ eod_counts) {
   extern __shared__ float4 lds[];
   float4 *stage = lds;                                               // [kChunks][kSlotStride]
-  uint32_t *poly = (uint32_t *)(lds + kChunks * kSlotStride);        // [d][64]
+  PolyT *poly = (PolyT *)(lds + kChunks * kSlotStride);              // [d][64]
+  PolyT *gpoly = (PolyT *)S.poly + (size_t)blockIdx.x * P.d * 64u;   // this wave's registers in HBM
+  PolyT *poly_u = poly + (FRAC ? 64u * P.d : 0u);
+  PolyT *gpoly_u = (PolyT *)S.poly_u + (size_t)blockIdx.x * P.d * 64u;
 
   const uint32_t lane = threadIdx.x;
   const uint32_t stream = blockIdx.x * 64u + lane;
@@ -391,7 +431,10 @@ __global__ __launch_bounds__(64) void demod_kernel(DemodParams P, DemodState S, 
   load_lane(L, S, ns, row);
   Consts<Real> C;
   C.init(P, S, row);
-  for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = S.poly[((size_t)blockIdx.x * P.d + p) * 64u + lane];
+  for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
+  if (FRAC)
+    for (uint32_t p = 0; p < P.d; p++) poly_u[p * 64u + lane] = gpoly_u[p * 64u + lane];
+  const bool tracing = (S.trace_stream >> 6) == blockIdx.x;  // wave-uniform
 
   OutCtx O;
   O.out_row = out + (size_t)row * out_pitch;
@@ -447,17 +490,26 @@ __global__ __launch_bounds__(64) void demod_kernel(DemodParams P, DemodState S, 
           bool dec = L.ds_cnt >= 2;
           bool any = UNI ? (bool)__builtin_amdgcn_readfirstlane((int)dec) : (__ballot(dec) != 0);
           if (any) {
-            Real amp = (Real)0;
+            Real amp = (Real)0, post = (Real)0;
             uint32_t bit = 0;
             if (UNI || dec) {
-              bit = discriminate(L, C, amp);
+              bit = discriminate(L, C, amp, post);
               L.ds_cnt = 0;
             }
-            downsampled_bit(L, P, S, poly, lane, row, valid, UNI || dec, bit, amp, O);
+            if (tracing && stream == S.trace_stream && (UNI || dec)) {
+              uint32_t k = *S.trace_n;
+              if (k < S.trace_cap) {
+                S.trace_amp[k] = (double)amp;
+                S.trace_post[k] = (double)post;
+                S.trace_bit[k] = (uint8_t)bit;
+              }
+              *S.trace_n = k + 1;
+            }
+            downsampled_bit<Real, PolyT, FRAC>(L, P, S, poly, poly_u, lane, row, valid, UNI || dec, bit, amp, O);
           }
         }
       }
-      if (WRITEBACK && valid) {
+      if (writeback && valid) {
         float *dst = samples + (size_t)row * pitch + t0 + 4u * c;
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -466,13 +518,29 @@ __global__ __launch_bounds__(64) void demod_kernel(DemodParams P, DemodState S, 
     }
   }
 
-  for (uint32_t p = 0; p < P.d; p++) S.poly[((size_t)blockIdx.x * P.d + p) * 64u + lane] = poly[p * 64u + lane];
+  for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
+  if (FRAC)
+    for (uint32_t p = 0; p < P.d; p++) gpoly_u[p * 64u + lane] = poly_u[p * 64u + lane];
   if (valid) {
     store_lane(L, S, ns, row);
     out_counts[stream] = O.out_cnt;
     if (eod_counts) eod_counts[stream] = O.eod_cnt;
   }
 }
+
+size_t demod_lds_bytes(const DemodParams &P) {
+  const size_t reg = (P.wide ? sizeof(uint64_t) : sizeof(uint32_t)) * 64u * P.d;
+  return sizeof(float4) * kChunks * kSlotStride + reg * (P.frac ? 2u : 1u);
+}
+
+// kernel variants: Real x {u32, u64, u64+frac} x {uniform, per-lane decimator phase}
+#define FSK_FOR_ALL_VARIANTS(X)                                                                    \
+  X(float, uint32_t, false, true) X(float, uint32_t, false, false)                                 \
+  X(float, uint64_t, false, true) X(float, uint64_t, false, false)                                 \
+  X(float, uint64_t, true, true) X(float, uint64_t, true, false)                                   \
+  X(double, uint32_t, false, true) X(double, uint32_t, false, false)                               \
+  X(double, uint64_t, false, true) X(double, uint64_t, false, false)                               \
+  X(double, uint64_t, true, true) X(double, uint64_t, true, false)
 
 // Host-side launcher (called from fsk_api.hip).  uniform_ds: every stream's downsample.counter is
 // equal (true unless single streams were reset at odd sample positions).
@@ -481,31 +549,27 @@ hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, const De
                         size_t out_pitch, uint32_t *out_counts, uint32_t *eod_counts,
                         hipStream_t stream) {
   const uint32_t blocks = (P.n_streams + 63u) / 64u;
-  const size_t lds_bytes = sizeof(float4) * kChunks * kSlotStride + sizeof(uint32_t) * 64u * P.d;
+  const size_t lds_bytes = demod_lds_bytes(P);
   const int vec_ok = (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(samples) & 15u) == 0);
+  const int wb = writeback ? 1 : 0;
+  const bool f64 = precision != 0, wide = P.wide != 0, frac = P.frac != 0;
   dim3 g(blocks), b(64);
-#define FSK_LAUNCH(R, U, W)                                                                        \
-  hipLaunchKernelGGL((demod_kernel<R, U, W>), g, b, lds_bytes, stream, P, S, samples, n, pitch,    \
-                     vec_ok, out, out_pitch, out_counts, eod_counts)
-  if (precision == 0) {
-    if (uniform_ds) { if (writeback) FSK_LAUNCH(float, true, true); else FSK_LAUNCH(float, true, false); }
-    else { if (writeback) FSK_LAUNCH(float, false, true); else FSK_LAUNCH(float, false, false); }
-  } else {
-    if (uniform_ds) { if (writeback) FSK_LAUNCH(double, true, true); else FSK_LAUNCH(double, true, false); }
-    else { if (writeback) FSK_LAUNCH(double, false, true); else FSK_LAUNCH(double, false, false); }
-  }
+#define FSK_LAUNCH(R, T, F, U)                                                                     \
+  if (f64 == (sizeof(R) == 8) && wide == (sizeof(T) == 8) && frac == F && uniform_ds == U)         \
+    hipLaunchKernelGGL((demod_kernel<R, T, F, U>), g, b, lds_bytes, stream, P, S, samples, n,      \
+                       pitch, vec_ok, wb, out, out_pitch, out_counts, eod_counts);
+  FSK_FOR_ALL_VARIANTS(FSK_LAUNCH)
 #undef FSK_LAUNCH
   return hipGetLastError();
 }
 
 hipError_t set_demod_lds_limit(size_t lds_bytes) {
   hipError_t e = hipSuccess;
-#define FSK_ATTR(R, U, W)                                                                          \
+#define FSK_ATTR(R, T, F, U)                                                                       \
   if (e == hipSuccess)                                                                             \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_kernel<R, U, W>),                \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_kernel<R, T, F, U>),             \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  FSK_ATTR(float, true, true) FSK_ATTR(float, true, false) FSK_ATTR(float, false, true) FSK_ATTR(float, false, false)
-  FSK_ATTR(double, true, true) FSK_ATTR(double, true, false) FSK_ATTR(double, false, true) FSK_ATTR(double, false, false)
+  FSK_FOR_ALL_VARIANTS(FSK_ATTR)
 #undef FSK_ATTR
   return e;
 }

@@ -72,8 +72,11 @@ struct DemodParams {
   uint32_t amp_cap;       // syncAmplitudeBuffer capacity = 8*d (fsk.ts:150)
   uint32_t matched_min;   // smallest integer `matched` with matched/total > syncThreshold in f64
   uint32_t eod_min;       // ceil(silence.samplesForEOD) (fsk.ts:148, 288)
-  uint32_t pat_q;         // bit j (1..n_bits-1) = preambleSfdBits[n_bits - j] (fsk.ts:307)
-  uint32_t pat_mask;      // bits 1..n_bits-1
+  uint64_t pat_q;         // bit j (1..n_bits-1) = preambleSfdBits[n_bits - j] (fsk.ts:307)
+  uint64_t pat_mask;      // bits 1..n_bits-1
+  uint32_t wide;          // 1: polyphase registers are 64-bit (n_bits > 31, or frac)
+  uint32_t frac;          // 1: the reference's ring capacity is fractional (see fsk_demod.hip)
+  uint32_t ring_int;      // frac: typed-array length A = floor(capacity); pushes >= A store `undefined`
   uint32_t stop_pos;      // 9 or 10 (fsk.ts:348)
   uint32_t parity_on;
   uint32_t agc_on;
@@ -84,10 +87,18 @@ struct DemodParams {
 struct DemodState {
   void *rs;           // Real   [RF_COUNT][n_streams]
   uint32_t *is;       // u32    [IF_COUNT][n_streams]
-  uint32_t *poly;     // u32    [n_blocks][d][64]   polyphase sync-bit registers
+  void *poly;         // u32|u64 [n_blocks][d][64]  polyphase sync-bit registers
+  void *poly_u;       // u64     [n_blocks][d][64]  frac only: 1 = that tap holds `undefined`
   float *amp_ring;    // f32    [amp_cap][n_streams] syncAmplitudeBuffer storage
   const double *coef; // double [CF_COUNT][n_streams]
   const uint64_t *nco_inc; // u64 [n_streams]: round(centerFreq/sampleRate * 2^64)
+  // optional intermediate capture of ONE stream (parity tests: fsk.ts:252 amplitude, :264 bit)
+  double *trace_amp;
+  double *trace_post;     // post-filter output (fsk.ts:261)
+  uint8_t *trace_bit;
+  uint32_t *trace_n;      // running count of decimated samples captured
+  uint32_t trace_cap;
+  uint32_t trace_stream;  // 0xFFFFFFFF = off
 };
 
 struct ModParams {

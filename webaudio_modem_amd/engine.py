@@ -172,6 +172,24 @@ class FSKEngine:
         _lib.check(self._L.fskhip_get_status(self._h, stream, C.byref(st)))
         return _status_dict(st)
 
+    def demod_supported(self):
+        return bool(self._L.fskhip_demod_supported(self._h))
+
+    # ---- intermediate capture (parity tests) -----------------------------------------------------
+    def trace_enable(self, stream, capacity):
+        _lib.check(self._L.fskhip_trace_enable(self._h, stream, capacity))
+        self._trace_cap = capacity
+
+    def trace_read(self):
+        cap = self._trace_cap
+        amp = np.zeros(cap, np.float64)
+        post = np.zeros(cap, np.float64)
+        bit = np.zeros(cap, np.uint8)
+        n = C.c_size_t(0)
+        _lib.check(self._L.fskhip_trace_read(self._h, amp.ctypes.data, post.ctypes.data, bit.ctypes.data, cap,
+                                             C.byref(n)))
+        return {"amp": amp[:n.value], "post_out": post[:n.value], "bit": bit[:n.value]}
+
     # ---- measurement tooling -------------------------------------------------------------------
     def synth_device(self, d_out, n_per_stream, pitch, payload_len, seed, lead_max, amp_lo, amp_hi, stream=None):
         _lib.check(self._L.fskhip_synth_device(self._h, d_out, n_per_stream, pitch, payload_len, seed, lead_max,
