@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=1.0, help="audio seconds per stream per step")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--pitch-pad", type=int, default=0, help="extra floats of row pitch (experiments)")
     ap.add_argument("--snr-db", type=float, default=None, help="add AWGN at this SNR (BASELINE config #5 shape)")
     args = ap.parse_args()
 
@@ -78,7 +79,7 @@ def main():
     sr = 48000
     N = int(round(args.seconds * sr))
     N = (N + 31) // 32 * 32
-    pitch = (N + 63) // 64 * 64  # 256-B row pitch
+    pitch = (N + 63) // 64 * 64 + args.pitch_pad  # 256-B row pitch
     prec = wm.PRECISION_F32 if args.precision == "f32" else wm.PRECISION_F64
     spb = sr // int(cfg.get("baudRate", 1200))
     seed = 0xF5C0DE + 0x1000 * rank

@@ -83,6 +83,7 @@ __global__ void init_kernel(DemodState S, uint32_t n, uint32_t matched_zero) {
   rs[(size_t)RF_agc_gain * n + s] = (Real)1.0;
   rs[(size_t)RF_sil_thr * n + s] = (Real)0.01;
   S.is[(size_t)IF_matched * n + s] = matched_zero;
+  S.is[(size_t)IF_bit_wait * n + s] = kBigWait;
 }
 
 // reset() fsk.ts:464-469 = resetState() + syncSamplesBuffer.clear() (+ host-side counters).
@@ -97,8 +98,9 @@ __global__ void reset_kernel(DemodState S, uint32_t n, int64_t stream) {
                     RF_po_x1, RF_po_x2, RF_po_y1, RF_po_y2, RF_acc_i,  RF_acc_q,  RF_last_phase, RF_nco_phase};
   for (int f : rz) rs[(size_t)f * n + s] = (Real)0;
   const int iz[] = {IF_nco_lo, IF_nco_hi, IF_ds_cnt, IF_gsc, IF_cad_ctr, IF_sil_cnt, IF_started, IF_bit_acc,
-                    IF_bit_cnt, IF_bit_sample_ctr, IF_next_bit_idx, IF_byte_cur, IF_bit_pos, IF_ring_len, IF_sync_det};
+                    IF_bit_reload, IF_byte_cur, IF_bit_pos, IF_ring_len, IF_sync_det};
   for (int f : iz) S.is[(size_t)f * n + s] = 0u;
+  S.is[(size_t)IF_bit_wait * n + s] = kBigWait;
 }
 
 }  // namespace
@@ -329,8 +331,9 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   }
   {
     const double for_eod = e->bpb * dsSPB * 0.7;  // fsk.ts:148
+    // sampleCount is >= 1 when the compare runs, so a threshold <= 1 behaves like 1
     double m = std::ceil(for_eod);
-    P.eod_min = m <= 0 ? 0u : (uint32_t)m;
+    P.eod_min = m <= 1 ? 1u : (uint32_t)m;
   }
   P.pat_q = 0; P.pat_mask = 0;
   for (uint32_t j = 1; j < n_bits && j < 64; j++) {

@@ -9,18 +9,25 @@
 //   (330-341) -> UART byte framing (346-375)
 // with no intermediate ever leaving the CU.  HBM traffic is the 4 B/sample input stream, the
 // f32 amplitude ring (the reference's syncAmplitudeBuffer, needed verbatim for the silence
-// threshold at sync time) and the per-stream state once per launch.
+// threshold at sync time: 2 B/sample of stores) and the per-stream state once per launch.
 //
 // Input rows are [stream][sample]; a wave loads a 64-row x 32-sample tile with coalesced
 // 16-B/lane loads (8 lanes cover one 128-B row segment), parks it in LDS chunk-major with a
 // one-slot pad so both the ds_write_b128 (8 lanes x 4 banks) and the per-lane ds_read_b128
 // are bank-conflict free, and prefetches the next tile into registers while it computes.
 //
-// The sync correlator is NOT the reference's O(nBits*dsSPB) brute force: the decision-bit
-// history is kept as dsSPB polyphase shift registers in LDS (register p holds the bits pushed
-// at times == p mod dsSPB, newest in bit 0), so the 30 window slots' entering/leaving bits at
-// each step are two masked popcounts of ONE register; `matched` is carried incrementally and is
-// at every step exactly the count the reference's double loop would produce.
+// The kernel is VALU-bound, not HBM-bound, so the per-decimated-sample state
+// machine is written as straight-line code plus three wave-uniform rare paths:
+//  * sync correlator: NOT the reference's O(nBits*dsSPB) brute force.  The decision-bit history
+//    is kept as dsSPB polyphase shift registers in LDS (register p holds the bits pushed at
+//    times == p mod dsSPB, newest in bit 0), so the window slots' entering/leaving bits at each
+//    step are two masked popcounts of ONE register; `matched` is carried incrementally and is at
+//    every step exactly the count the reference's double loop would produce;
+//  * bit clock: nextBitSampleIndex - bitSampleCounter is one down-counter (parked at kBigWait
+//    while no frame is started) and the vote accumulator runs ungated -- every path that
+//    (re)starts a frame zeroes it, like the reference does;
+//  * ring positions that are equal for all streams of a launch (push slot, amplitude-ring slot,
+//    pushes so far) live in SGPRs in the UNI kernels.
 //
 // Fractional ring capacities (FRAC kernels).  The reference sizes its sync ring
 // maxSyncBits*dsSPB*1.1 (fsk.ts:149), which is often NOT an integer in f64 (44.1 kHz; 48 kHz with
@@ -35,19 +42,19 @@
 // pushes; otherwise the configuration is refused.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fsk_params.h"
+
+#ifndef FSK_F32_WAVES_PER_SIMD
+#define FSK_F32_WAVES_PER_SIMD 2
+#endif
 
 namespace fsk {
 
 // ------------------------------------------------------------------------------------------------
 // per-precision arithmetic
 // ------------------------------------------------------------------------------------------------
-template <typename Real>
-struct Biquad {
-  Real x1, x2, y1, y2;
-};
-
 template <typename Real>
 struct Consts;
 
@@ -56,11 +63,16 @@ struct Consts<float> {
   float lp_b0, lp_a2, lp_delta, agc_att, agc_rel;
   float bp_b0, bp_a1, bp_a2;
   uint32_t inc_lo, inc_hi;
+  // converts once and pins the value in an SGPR (otherwise hipcc re-converts the f64 kernel
+  // argument with a quarter-rate v_cvt_f32_f64 at every use)
+  static __device__ float pin(double v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)v)));
+  }
   __device__ void init(const DemodParams &P, const DemodState &S, uint32_t row) {
     // delta = 1 + a1 + a2 (= b0+b1+b2 for the unity-DC-gain Butterworth) is formed in f64 and only
     // then rounded: rounding a1 ~ -1.94 itself to f32 would move the DC gain by ~1e-4 at 300 baud
-    lp_b0 = (float)P.lp_b0; lp_a2 = (float)P.lp_a2; lp_delta = (float)(1.0 + P.lp_a1 + P.lp_a2);
-    agc_att = (float)P.agc_attack; agc_rel = (float)P.agc_release;
+    lp_b0 = pin(P.lp_b0); lp_a2 = pin(P.lp_a2); lp_delta = pin(1.0 + P.lp_a1 + P.lp_a2);
+    agc_att = pin(P.agc_attack); agc_rel = pin(P.agc_release);
     size_t n = P.n_streams;
     bp_b0 = (float)S.coef[(size_t)CF_bp_b0 * n + row];
     bp_a1 = (float)S.coef[(size_t)CF_bp_a1 * n + row];
@@ -93,6 +105,7 @@ struct Lane {
 #define X(n) uint32_t n;
   FSK_INT_FIELDS(X)
 #undef X
+  uint32_t thr_eff;  // matched_min while searching, 0xFFFFFFFF while a frame is started (not stored)
 };
 
 template <typename Real>
@@ -133,8 +146,9 @@ __device__ inline double biquad64(double b0, double b1, double b2, double a1, do
   return out;
 }
 
-// AGC + pre-filter + mixer + I/Q low-pass for one input sample (fsk.ts:52-76, 202, 228-243).
-__device__ inline void front(Lane<double> &L, const Consts<double> &C, bool agc_on, float xin, float &agc_out) {
+// AGC + pre-filter for one input sample (fsk.ts:52-76, 202): returns the pre-filter's Float32Array
+// output.  Neither stage is touched by resetState().
+__device__ inline float pre_stage(Lane<double> &L, const Consts<double> &C, bool agc_on, float xin, float &agc_out) {
   float xs = xin;
   if (agc_on) {
     xs = (float)((double)xin * L.agc_gain);  // samples[i] *= gain : Float32Array store
@@ -151,22 +165,25 @@ __device__ inline void front(Lane<double> &L, const Consts<double> &C, bool agc_
   }
   agc_out = xs;
   // preFilter.processBuffer: f64 state, f32 result (filters.ts:81-87)
-  float pre = (float)biquad64(C.bp_b0, 0.0, -C.bp_b0, C.bp_a1, C.bp_a2, L.bp_x1, L.bp_x2, L.bp_y1, L.bp_y2, (double)xs);
+  return (float)biquad64(C.bp_b0, 0.0, -C.bp_b0, C.bp_a1, C.bp_a2, L.bp_x1, L.bp_x2, L.bp_y1, L.bp_y2, (double)xs);
+}
+
+// NCO mix + I/Q low-pass for one pre-filtered sample (fsk.ts:228-238): the part resetState() zeroes.
+__device__ inline void mix_lp(Lane<double> &L, const Consts<double> &C, float pre, double &fi, double &fq) {
   double s = (double)pre;
   double ci = s * cos(L.nco_phase);
   double cq = s * sin(L.nco_phase);
   L.nco_phase = fmod(L.nco_phase + C.omega, 2.0 * 3.14159265358979323846);
-  double fi = biquad64(C.lp_b0, C.lp_b1, C.lp_b2, C.lp_a1, C.lp_a2, L.li_x1, L.li_x2, L.li_y1, L.li_y2, ci);
-  double fq = biquad64(C.lp_b0, C.lp_b1, C.lp_b2, C.lp_a1, C.lp_a2, L.lq_x1, L.lq_x2, L.lq_y1, L.lq_y2, cq);
-  L.acc_i += fi;
-  L.acc_q += fq;
+  fi = biquad64(C.lp_b0, C.lp_b1, C.lp_b2, C.lp_a1, C.lp_a2, L.li_x1, L.li_x2, L.li_y1, L.li_y2, ci);
+  fq = biquad64(C.lp_b0, C.lp_b1, C.lp_b2, C.lp_a1, C.lp_a2, L.lq_x1, L.lq_x2, L.lq_y1, L.lq_y2, cq);
 }
 
-// decimated-rate discriminator (fsk.ts:245-264): returns the slicer bit, amplitude by reference
-__device__ inline uint32_t discriminate(Lane<double> &L, const Consts<double> &C, double &amp, double &post) {
+// decimated-rate discriminator (fsk.ts:245-264): returns the slicer bit
+__device__ inline bool discriminate(Lane<double> &L, const Consts<double> &C, double sum_i, double sum_q,
+                                    double &amp, double &post) {
   const double PI = 3.14159265358979323846;
-  double avg_i = L.acc_i / 2.0;
-  double avg_q = L.acc_q / 2.0;
+  double avg_i = sum_i / 2.0;
+  double avg_q = sum_q / 2.0;
   double phase = atan2(avg_q, avg_i);
   amp = sqrt(avg_i * avg_i + avg_q * avg_q);
   double dphi = phase - L.last_phase;
@@ -174,17 +191,17 @@ __device__ inline uint32_t discriminate(Lane<double> &L, const Consts<double> &C
   else if (dphi < -PI) dphi += 2.0 * PI;
   L.last_phase = phase;
   double f = biquad64(C.lp_b0, C.lp_b1, C.lp_b2, C.lp_a1, C.lp_a2, L.po_x1, L.po_x2, L.po_y1, L.po_y2, dphi);
-  L.acc_i = 0.0; L.acc_q = 0.0;
   post = f;
-  return f > 0.0 ? 1u : 0u;
+  return f > 0.0;
 }
 
 __device__ inline void nco_reset(Lane<double> &L) { L.nco_phase = 0.0; }
 
 // ---- fp32: throughput path ---------------------------------------------------------------------
 // Same chain, leaner forms: b1 = 0 / b2 = -b0 (band-pass) and b1 = 2*b0, b2 = b0 (low-pass) are
-// folded, FMAs are explicit, 1/x is v_rcp_f32, the NCO is a 64-bit turn accumulator feeding
-// v_sin_f32 / v_cos_f32 (which take revolutions).
+// folded, FMAs are explicit, 1/x is v_rcp_f32, sqrt is v_sqrt_f32, atan2 is a degree-15 odd
+// polynomial, the NCO is a 64-bit turn accumulator feeding v_sin_f32 / v_cos_f32 (which take
+// revolutions).
 
 // Low-pass biquad in "velocity" form.  With v = y[n-1] - y[n-2] kept as state,
 //   y[n] = y[n-1] + a2*v + (b0*(x + 2*x1 + x2) - delta*y[n-1]),   delta = 1 + a1 + a2
@@ -201,7 +218,28 @@ __device__ inline float lp32(float b0, float a2, float delta, float &x1, float &
   return y;
 }
 
-__device__ inline void front(Lane<float> &L, const Consts<float> &C, bool agc_on, float xin, float &agc_out) {
+// atan2 for the discriminator: |error| <= 1.5e-7 rad.  min/max ratio through v_rcp_f32, odd
+// minimax polynomial on [0,1] (coefficients fitted for this file), quadrant by compares.  -0 counts
+// as +0 for x (the reference's averages are never -0: its sums start at +0), atan2(0, 0) = 0.
+__device__ inline float atan2_fast(float y, float x) {
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+  const float a = mn * __builtin_amdgcn_rcpf(__builtin_fmaxf(mx, 1.0e-37f));
+  const float s = a * a;
+  float p = -4.355408570e-03f;
+  p = __builtin_fmaf(p, s, 2.304014596e-02f);
+  p = __builtin_fmaf(p, s, -5.777360382e-02f);
+  p = __builtin_fmaf(p, s, 9.794235514e-02f);
+  p = __builtin_fmaf(p, s, -1.397658244e-01f);
+  p = __builtin_fmaf(p, s, 1.996270403e-01f);
+  p = __builtin_fmaf(p, s, -3.333165903e-01f);
+  float r = __builtin_fmaf(a * s, p, a);
+  r = ay > ax ? 1.57079632679489662f - r : r;
+  r = x < 0.0f ? 3.14159265358979323846f - r : r;
+  return __builtin_copysignf(r, y);
+}
+
+__device__ inline float pre_stage(Lane<float> &L, const Consts<float> &C, bool agc_on, float xin, float &agc_out) {
   float xs = xin;
   if (agc_on) {
     xs = xin * L.agc_gain;
@@ -213,12 +251,16 @@ __device__ inline void front(Lane<float> &L, const Consts<float> &C, bool agc_on
     L.agc_gain = __builtin_fminf(__builtin_fmaxf(g, 0.1f), 10.0f);
   }
   agc_out = xs;
-  // band-pass: y = b0*(x - x2) - a1*y1 - a2*y2
+  // band-pass: y = b0*(x - x2) - a2*y2 - a1*y1 (the y1 term last: shortest recurrence)
   float y = C.bp_b0 * (xs - L.bp_x2);
-  y = __builtin_fmaf(-C.bp_a1, L.bp_y1, y);
   y = __builtin_fmaf(-C.bp_a2, L.bp_y2, y);
+  y = __builtin_fmaf(-C.bp_a1, L.bp_y1, y);
   L.bp_x2 = L.bp_x1; L.bp_x1 = xs;
   L.bp_y2 = L.bp_y1; L.bp_y1 = y;
+  return y;
+}
+
+__device__ inline void mix_lp(Lane<float> &L, const Consts<float> &C, float y, float &fi, float &fq) {
   // NCO: phase in turns = top 32 bits of the accumulator
   float turns = (float)L.nco_hi * 2.3283064365386963e-10f;  // 2^-32
   float c = __builtin_amdgcn_cosf(turns);
@@ -226,28 +268,25 @@ __device__ inline void front(Lane<float> &L, const Consts<float> &C, bool agc_on
   uint32_t lo = L.nco_lo + C.inc_lo;
   L.nco_hi = L.nco_hi + C.inc_hi + (lo < L.nco_lo ? 1u : 0u);
   L.nco_lo = lo;
-  float fi = lp32(C.lp_b0, C.lp_a2, C.lp_delta, L.li_x1, L.li_x2, L.li_y1, L.li_y2, y * c);
-  float fq = lp32(C.lp_b0, C.lp_a2, C.lp_delta, L.lq_x1, L.lq_x2, L.lq_y1, L.lq_y2, y * s);
-  L.acc_i += fi;
-  L.acc_q += fq;
+  fi = lp32(C.lp_b0, C.lp_a2, C.lp_delta, L.li_x1, L.li_x2, L.li_y1, L.li_y2, y * c);
+  fq = lp32(C.lp_b0, C.lp_a2, C.lp_delta, L.lq_x1, L.lq_x2, L.lq_y1, L.lq_y2, y * s);
 }
 
-__device__ inline uint32_t discriminate(Lane<float> &L, const Consts<float> &C, float &amp, float &post) {
+__device__ inline bool discriminate(Lane<float> &L, const Consts<float> &C, float sum_i, float sum_q, float &amp,
+                                    float &post) {
   const float PI = 3.14159265358979323846f;
-  // + 0.0f canonicalises -0 to +0: the reference's averages are never -0 (sums start at +0),
-  // and atan2(+0, -0) would be pi instead of 0 on an all-zero input
-  float avg_i = L.acc_i * 0.5f + 0.0f;
-  float avg_q = L.acc_q * 0.5f + 0.0f;
-  float phase = atan2f(avg_q, avg_i);
-  amp = __builtin_sqrtf(__builtin_fmaf(avg_i, avg_i, avg_q * avg_q));
+  float avg_i = sum_i * 0.5f;
+  float avg_q = sum_q * 0.5f;
+  float phase = atan2_fast(avg_q, avg_i);
+  amp = __builtin_amdgcn_sqrtf(__builtin_fmaf(avg_i, avg_i, avg_q * avg_q));
   float dphi = phase - L.last_phase;
-  if (dphi > PI) dphi -= 2.0f * PI;
-  else if (dphi < -PI) dphi += 2.0f * PI;
+  float wrap = dphi > PI ? -2.0f * PI : 0.0f;
+  wrap = dphi < -PI ? 2.0f * PI : wrap;
+  dphi += wrap;
   L.last_phase = phase;
   float f = lp32(C.lp_b0, C.lp_a2, C.lp_delta, L.po_x1, L.po_x2, L.po_y1, L.po_y2, dphi);
-  L.acc_i = 0.0f; L.acc_q = 0.0f;
   post = f;
-  return f > 0.0f ? 1u : 0u;
+  return f > 0.0f;
 }
 
 __device__ inline void nco_reset(Lane<float> &L) { L.nco_lo = 0; L.nco_hi = 0; }
@@ -257,14 +296,15 @@ __device__ inline void nco_reset(Lane<float> &L) { L.nco_lo = 0; L.nco_hi = 0; }
 // ------------------------------------------------------------------------------------------------
 
 // resetState() fsk.ts:175-188.  Not touched: AGC gain, pre-filter, both rings (and therefore
-// `matched`, the polyphase registers, ring_len, amp_pos/len), silence threshold.
+// `matched`, the polyphase registers, ring positions), silence threshold.
 template <typename Real>
-__device__ inline void reset_state(Lane<Real> &L) {
+__device__ inline void reset_state(Lane<Real> &L, uint32_t matched_min) {
   nco_reset(L);
   L.last_phase = (Real)0;
-  L.gsc = 0; L.cad_ctr = 0; L.bit_sample_ctr = 0; L.bit_acc = 0; L.bit_cnt = 0; L.next_bit_idx = 0;
+  L.gsc = 0; L.cad_ctr = 0;
+  L.bit_acc = 0; L.bit_wait = kBigWait; L.bit_reload = 0;
   L.byte_cur = 0; L.bit_pos = 0;
-  L.started = 0;
+  L.started = 0; L.thr_eff = matched_min;
   L.sil_cnt = 0;
   L.li_x1 = L.li_x2 = L.li_y1 = L.li_y2 = (Real)0;
   L.lq_x1 = L.lq_x2 = L.lq_y1 = L.lq_y2 = (Real)0;
@@ -280,29 +320,8 @@ struct OutCtx {
   uint32_t eod_cnt;    // eod events this call
 };
 
-// processByte fsk.ts:346-375
-template <typename Real>
-__device__ inline void process_byte(Lane<Real> &L, const DemodParams &P, uint32_t bit, OutCtx &O, bool valid) {
-  uint32_t pos = L.bit_pos;
-  if (pos == 0) {
-    if (bit != 0) { reset_state(L); return; }
-  } else if (pos <= 8) {
-    L.byte_cur |= bit << (8 - pos);
-  } else if (P.parity_on && pos == 9) {
-    // parity bit: not validated by the reference
-  } else if (pos == P.stop_pos) {
-    if (bit != 1) { L.started = 0; return; }
-    if (valid && O.out_cnt < O.out_pitch) O.out_row[O.out_cnt] = (uint8_t)L.byte_cur;
-    O.out_cnt++;
-    L.byte_cur = 0;
-    L.bit_pos = 0;
-    return;
-  } else {
-    L.started = 0;
-    return;
-  }
-  L.bit_pos = pos + 1;
-}
+__device__ inline uint32_t popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+__device__ inline uint32_t popc(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
 
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -310,23 +329,32 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
-// processDownsampledBit fsk.ts:278-344 for every lane with act set.  Must be called by the
-// whole wave (it contains a wave-cooperative amplitude-ring read at sync time).
-__device__ inline uint32_t popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
-__device__ inline uint32_t popc(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
+// Ring bookkeeping that is identical for all lanes of a UNI launch (kept in SGPRs there) and
+// per-lane otherwise.
+struct RingPos {
+  uint32_t phase;    // push slot = pushes mod dsSPB
+  uint32_t amp_pos;  // syncAmplitudeBuffer write index
+  uint32_t k;        // pushes made so far in this launch
+};
 
+// processDownsampledBit (fsk.ts:278-344) for every lane with act set.  Must be called by the
+// whole wave (rare paths are wave-uniform branches; the sync path reads the amplitude ring
+// cooperatively).
 template <typename Real, typename PolyT, bool FRAC>
-__device__ inline void downsampled_bit(Lane<Real> &L, const DemodParams &P, const DemodState &S,
-                                       PolyT *poly, PolyT *poly_u, uint32_t lane, uint32_t row, bool valid,
-                                       bool act, uint32_t bit, Real amp, OutCtx &O) {
-  const PolyT pat_q = (PolyT)P.pat_q, pat_mask = (PolyT)P.pat_mask;
-  bool sync_now = false;
+__device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, const DemodState &S, PolyT *poly,
+                                       PolyT *poly_u, RingPos &R, uint32_t need, uint32_t ring_base,
+                                       uint32_t amp_base, uint32_t lane, uint32_t row, bool valid, bool act, bool bitb,
+                                       Real amp, OutCtx &O) {
+  const PolyT qn = (PolyT)~P.pat_q, mask = (PolyT)P.pat_mask;
+  const PolyT qn2 = (PolyT)(qn << 1), mask2 = (PolyT)(mask << 1);
+  const uint32_t bit = bitb ? 1u : 0u;
+  bool eod = false, cand = false, decide = false, did_reset = false;
   if (act) {
-    // syncSamplesBuffer.put(bit): polyphase register of this push slot, newest bit in bit 0
-    uint32_t idx = L.poly_phase * 64u + lane;
+    // ---- syncSamplesBuffer.put(bit): polyphase register of this push slot, newest bit in bit 0
+    const uint32_t idx = R.phase * 64u + lane;
     PolyT r, u = 0;
     if (FRAC) {
-      const bool undef = L.ring_len >= P.ring_int;  // this store is dropped by the reference's ring
+      const bool undef = ring_base + R.k >= P.ring_int;  // this store is dropped by the reference's ring
       u = (PolyT)(poly_u[idx] << 1) | (PolyT)(undef ? 1u : 0u);
       poly_u[idx] = u;
       r = (PolyT)(poly[idx] << 1) | (PolyT)(undef ? 0u : bit);
@@ -334,82 +362,118 @@ __device__ inline void downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
       r = (PolyT)(poly[idx] << 1) | (PolyT)bit;
     }
     poly[idx] = r;
-    L.poly_phase = (L.poly_phase + 1 == P.d) ? 0u : L.poly_phase + 1;
-    // slots j = 1..n_bits-1 gain tap j and lose tap j+1 (see file header)
-    L.matched += popc((PolyT)(~(r ^ pat_q) & ~u & pat_mask));
-    L.matched -= popc((PolyT)(~((r >> 1) ^ pat_q) & ~(u >> 1) & pat_mask));
+    // slots j = 1..n_bits-1 gain tap j and lose tap j+1: [tap_j == q_j] - [tap_{j+1} == q_j]
+    L.matched += popc((PolyT)((r ^ qn) & ~u & mask));
+    L.matched -= popc((PolyT)((r ^ qn2) & ~u & mask2));
     if (FRAC) {  // slot 0 compares against `undefined`: it counts undefined taps
       L.matched += (uint32_t)(u & 1u);
       L.matched -= (uint32_t)((u >> 1) & 1u);
     }
-    if (L.ring_len < P.ring_cap) L.ring_len++;
-    // syncAmplitudeBuffer.put(amp): Float32Array store
-    if (valid) S.amp_ring[(size_t)L.amp_pos * P.n_streams + row] = (float)amp;
-    L.amp_pos = (L.amp_pos + 1 == P.amp_cap) ? 0u : L.amp_pos + 1;
-    if (L.amp_len < P.amp_cap) L.amp_len++;
+    // ---- syncAmplitudeBuffer.put(amp): Float32Array store
+    if (valid) S.amp_ring[(size_t)R.amp_pos * P.n_streams + row] = (float)amp;
+    R.phase = (R.phase + 1 == P.d) ? 0u : R.phase + 1;
+    R.amp_pos = (R.amp_pos + 1 == P.amp_cap) ? 0u : R.amp_pos + 1;
+    R.k++;
 
     L.gsc++;
     L.cad_ctr = (L.cad_ctr + 1 == P.cadence) ? 0u : L.cad_ctr + 1;
-    bool eod = false;
-    if (amp < L.sil_thr) {
-      L.sil_cnt++;
-      if (L.sil_cnt >= P.eod_min) {
-        O.eod_cnt++;
-        L.eod_total++;
-        reset_state(L);
-        eod = true;
-      }
-    } else {
-      L.sil_cnt = 0;
-    }
-    if (!eod) {
-      if (!L.started) {
-        if (L.ring_len >= P.sample_count && P.cadence != 0 && L.cad_ctr == 0 && L.matched >= P.matched_min) {
-          L.started = 1;
-          L.byte_cur = 0; L.bit_pos = 0;
-          L.bit_acc = 0; L.bit_cnt = 0; L.bit_sample_ctr = 0; L.next_bit_idx = 0;
-          L.sync_det++;
-          sync_now = true;
-        }
-      } else {
-        L.bit_acc += bit;
-        L.bit_cnt++;
-        L.bit_sample_ctr++;
-        if (L.bit_sample_ctr >= L.next_bit_idx) {
-          uint32_t b = (2 * L.bit_acc > L.bit_cnt) ? 1u : 0u;
-          L.bit_acc = 0; L.bit_cnt = 0;
-          L.next_bit_idx += P.d;
-          process_byte(L, P, b, O, valid);
-        }
-      }
+    // ---- silence detection (fsk.ts:285-295)
+    L.sil_cnt = (amp < L.sil_thr) ? L.sil_cnt + 1 : 0u;
+    eod = L.sil_cnt >= P.eod_min;
+    // ---- bit clock, ungated (fsk.ts:331-335): every (re)start of a frame zeroes these
+    L.bit_acc += bit;
+    L.bit_wait -= 1u;
+    decide = (int32_t)L.bit_wait <= 0;
+    // ---- frame sync candidate (fsk.ts:297-315); thr_eff is 0xFFFFFFFF while started
+    cand = (L.matched >= L.thr_eff) & (L.cad_ctr == 0) & (R.k >= need);
+  }
+
+  // ---- rare path 1: end of data (fsk.ts:288-291) ------------------------------------------------
+  if (__ballot(eod)) {
+    if (eod) {
+      O.eod_cnt++;
+      L.eod_total++;
+      reset_state(L, P.matched_min);
+      did_reset = true;
     }
   }
-  // silence.threshold = mean(syncAmplitudeBuffer) * 0.1 (fsk.ts:321-326), wave-cooperative:
-  // the 64 lanes read the syncing stream's ring column together and tree-reduce in f64.
+  // ---- rare path 2: frame sync found (fsk.ts:315-327) -------------------------------------------
+  const bool sync_now = cand & !eod;
   uint64_t m = __ballot(sync_now);
   if (m) {
+    if (sync_now) {
+      L.started = 1; L.thr_eff = 0xFFFFFFFFu;
+      L.byte_cur = 0; L.bit_pos = 0;
+      L.bit_acc = 0; L.bit_wait = 0; L.bit_reload = 0;
+      L.sync_det++;
+    }
+    // silence.threshold = mean(syncAmplitudeBuffer) * 0.1: the 64 lanes read the syncing stream's
+    // ring column together and tree-reduce in f64
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's ring stores have reached L2
+    const uint32_t pushes = amp_base + R.k;
+    const uint32_t my_len = pushes < P.amp_cap ? pushes : P.amp_cap;
     while (m) {
-      int src = __ffsll((unsigned long long)m) - 1;
+      const int src = __ffsll((unsigned long long)m) - 1;
       m &= m - 1;
-      uint32_t srow = __shfl(row, src, 64);
-      uint32_t slen = __shfl(L.amp_len, src, 64);
+      const uint32_t srow = __shfl(row, src, 64);
+      const uint32_t slen = __shfl(my_len, src, 64);
       double part = 0.0;
       for (uint32_t i = lane; i < slen; i += 64) {
         const float *p = S.amp_ring + (size_t)i * P.n_streams + srow;
         part += (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L1 bypass
       }
-      double sum = wave_sum(part);
+      const double sum = wave_sum(part);
       if ((int)lane == src) L.sil_thr = (Real)((sum / (double)slen) * 0.1);
     }
   }
+  // ---- rare path 3 (some lane nearly every step): bit decision + processByte (fsk.ts:335-375) ---
+  const bool dec_now = decide & !eod & (L.started != 0);
+  if (__ballot(dec_now)) {
+    bool emit = false, bad_start = false;
+    if (dec_now) {
+      const uint32_t cnt = L.bit_reload - L.bit_wait;           // bitAccumCount
+      const uint32_t b = (2u * L.bit_acc > cnt) ? 1u : 0u;      // fsk.ts:336
+      L.bit_acc = 0;
+      L.bit_wait += P.d;                                        // nextBitSampleIndex += dsSPB
+      L.bit_reload = L.bit_wait;
+      const uint32_t pos = L.bit_pos;
+      // data bits MSB first: positions 1..8 land in bits 7..0; position 0 (start bit, must be 0 to
+      // get here) and positions >= 9 land above bit 7 and are masked off when the byte is emitted
+      L.byte_cur |= b << ((8u - pos) & 31u);
+      const bool is_stop = pos == P.stop_pos;
+      bad_start = (pos == 0) & (b != 0);
+      emit = is_stop & (b != 0);
+      L.bit_pos = is_stop ? 0u : pos + 1;
+      if (is_stop & (b == 0)) {                                 // bad stop bit: fsk.ts:363-366
+        L.started = 0; L.thr_eff = P.matched_min; L.bit_wait = kBigWait;
+        L.bit_pos = pos;
+      }
+    }
+    if (__ballot(bad_start)) {
+      if (bad_start) { reset_state(L, P.matched_min); did_reset = true; }  // fsk.ts:352-355
+    }
+    if (__ballot(emit)) {
+      if (emit) {
+        if (valid && O.out_cnt < O.out_pitch) O.out_row[O.out_cnt] = (uint8_t)L.byte_cur;
+        O.out_cnt++;
+        L.byte_cur = 0;
+      }
+    }
+  }
+  // bit_wait ran down without a frame (12 h of decimated samples): park it again
+  if (__ballot(decide & (L.started == 0))) {
+    if (decide & (L.started == 0)) L.bit_wait = kBigWait;
+  }
+  return did_reset;
 }
 
 // ------------------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------------------
-template <typename Real, typename PolyT, bool FRAC, bool UNI>
-__global__ __launch_bounds__(64) void demod_kernel(DemodParams P, DemodState S, float *__restrict__ samples,
+// fp32 kernels are capped at 128 VGPRs (4 waves/SIMD): the chain is VALU-bound and one wave per
+// SIMD issues a VALU op only every 4 cycles (MI355X_MICROARCH.md), so occupancy is throughput.
+template <typename Real, typename PolyT, bool FRAC, bool UNI, bool TRACE>
+__global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1)) void demod_kernel(DemodParams P, DemodState S, float *__restrict__ samples,
                                                    size_t n, size_t pitch, int vec_ok, int writeback,
                                                    uint8_t *__restrict__ out, size_t out_pitch,
                                                    uint32_t *__restrict__ out_counts,
@@ -429,12 +493,21 @@ __global__ __launch_bounds__(64) void demod_kernel(DemodParams P, DemodState S, 
 
   Lane<Real> L;
   load_lane(L, S, ns, row);
+  L.thr_eff = L.started ? 0xFFFFFFFFu : P.matched_min;
   Consts<Real> C;
   C.init(P, S, row);
   for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
   if (FRAC)
     for (uint32_t p = 0; p < P.d; p++) poly_u[p * 64u + lane] = gpoly_u[p * 64u + lane];
-  const bool tracing = (S.trace_stream >> 6) == blockIdx.x;  // wave-uniform
+
+  // ring positions: wave-uniform (SGPR) in UNI launches
+  RingPos R;
+  R.phase = UNI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)L.poly_phase) : L.poly_phase;
+  R.amp_pos = UNI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)L.amp_pos) : L.amp_pos;
+  R.k = 0;
+  const uint32_t ring_base = L.ring_len, amp_base = L.amp_len;
+  // the sync search needs ring length >= sample_count: true once k >= need
+  const uint32_t need = ring_base >= P.sample_count ? 0u : P.sample_count - ring_base;
 
   OutCtx O;
   O.out_row = out + (size_t)row * out_pitch;
@@ -442,38 +515,157 @@ __global__ __launch_bounds__(64) void demod_kernel(DemodParams P, DemodState S, 
   O.out_cnt = 0;
   O.eod_cnt = 0;
 
-  // tile prefetch: instruction i covers rows 8i..8i+7, lane -> (row 8i + lane/8, chunk lane%8)
-  const uint32_t sub_row = lane >> 3, chunk = lane & 7;
-  float4 pre[8];
-  auto load_tile = [&](size_t t0) {
-    const bool full = vec_ok && (t0 + kTile <= n);
+  // tile prefetch: load i covers kRowsPerLoad rows; lane -> (row i*kRowsPerLoad + lane/kChunks,
+  // chunk lane%kChunks), i.e. kChunks lanes sweep one row's contiguous tile segment.
+  // Two separate code paths on purpose: when both lived in one loop hipcc split every 16-B load
+  // into dwordx3 + dword with a vmcnt(0) in between, serialising 8 HBM round trips per tile.
+  const uint32_t sub_row = lane / kChunks, chunk = lane % kChunks;
+  const bool rows_full = (blockIdx.x + 1u) * 64u <= P.n_streams;
+  const float *lane_src = samples + (size_t)(blockIdx.x * 64u + sub_row) * pitch + 4u * chunk;
+  float4 pre[kChunks];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      uint32_t r = blockIdx.x * 64u + 8u * i + sub_row;
+  for (int i = 0; i < kChunks; i++) pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // defined on every path (keeps it in VGPRs)
+  auto load_tile_fast = [&](size_t t0) {
+#pragma unroll
+    for (int i = 0; i < kChunks; i++)
+      pre[i] = *reinterpret_cast<const float4 *>(lane_src + (size_t)(kRowsPerLoad * i) * pitch + t0);
+  };
+  // ragged tiles (row tail of the batch, sample tail of the call, unaligned buffers) are staged
+  // synchronously element by element, straight into LDS, so that the fast path above stays free of
+  // shared code
+  auto stage_tile_slow = [&](size_t t0) {
+    for (int i = 0; i < kChunks; i++) {
+      uint32_t r = blockIdx.x * 64u + (uint32_t)kRowsPerLoad * i + sub_row;
       r = r < P.n_streams ? r : P.n_streams - 1;
-      const float *src = samples + (size_t)r * pitch + t0 + 4u * chunk;
-      if (full) {
-        pre[i] = *reinterpret_cast<const float4 *>(src);
-      } else {
-        size_t c0 = t0 + 4u * chunk;
-        float4 v;
-        v.x = c0 + 0 < n ? src[0] : 0.0f;
-        v.y = c0 + 1 < n ? src[1] : 0.0f;
-        v.z = c0 + 2 < n ? src[2] : 0.0f;
-        v.w = c0 + 3 < n ? src[3] : 0.0f;
-        pre[i] = v;
+      const size_t c0 = t0 + 4u * chunk;
+      const float *src = samples + (size_t)r * pitch + c0;
+      float *dst = reinterpret_cast<float *>(&stage[chunk * kSlotStride + (uint32_t)kRowsPerLoad * i + sub_row]);
+      for (int q = 0; q < 4; q++) dst[q] = (c0 + q < n) ? src[q] : 0.0f;
+    }
+  };
+  auto tile_is_fast = [&](size_t t0) { return vec_ok && rows_full && t0 + kTile <= n; };
+
+  const bool agc_on = P.agc_on != 0;
+#ifdef FSK_ABLATE
+  const int ablate = writeback >> 8;
+  writeback &= 0xFF;
+#endif
+
+  auto trace_put = [&](Real amp, Real post, bool bit) {
+    if (TRACE) {
+      if (stream == S.trace_stream) {
+        uint32_t kk = *S.trace_n;
+        if (kk < S.trace_cap) {
+          S.trace_amp[kk] = (double)amp;
+          S.trace_post[kk] = (double)post;
+          S.trace_bit[kk] = bit ? 1 : 0;
+        }
+        *S.trace_n = kk + 1;
       }
     }
   };
 
-  const bool agc_on = P.agc_on != 0;
-  if (n > 0) load_tile(0);
+  // generic path: one sample at a time, per-lane decimator phase (fsk.ts:224-276 as written)
+  auto step_generic = [&](float x, float &wbv) {
+    float pre_y = pre_stage(L, C, agc_on, x, wbv);
+    Real fi, fq;
+    mix_lp(L, C, pre_y, fi, fq);
+    L.acc_i += fi;
+    L.acc_q += fq;
+    L.ds_cnt++;
+    const bool dec = L.ds_cnt >= 2;
+    const bool any = UNI ? (bool)__builtin_amdgcn_readfirstlane((int)dec) : (__ballot(dec) != 0);
+    if (any) {
+      Real amp = (Real)0, post = (Real)0;
+      bool bit = false;
+      if (UNI || dec) {
+        bit = discriminate(L, C, L.acc_i, L.acc_q, amp, post);
+        L.acc_i = (Real)0; L.acc_q = (Real)0;
+        L.ds_cnt = 0;
+        trace_put(amp, post, bit);
+      }
+      downsampled_bit<Real, PolyT, FRAC>(L, P, S, poly, poly_u, R, need, ring_base, amp_base, lane, row, valid,
+                                         UNI || dec, bit, amp, O);
+    }
+  };
+
+  // Fast path (UNI launches whose decimator is at a pair boundary): four samples at a time.  The
+  // four front ends and both discriminators form ONE branch-free block, so the independent
+  // recurrences (AGC gain, band-pass, NCO, I/Q low-pass, post filter) of neighbouring samples can
+  // overlap in the in-order pipeline.  Samples 2,3 are therefore computed BEFORE the frame state
+  // machine has seen pair 0; if that step resets a stream (EOD or bad start bit, fsk.ts:288-291,
+  // 352-355) the reset-sensitive part of samples 2,3 is recomputed for those lanes from the
+  // zeroed state, which is exactly what the reference's sample-serial order produces.
+  auto block4 = [&](const float (&x)[4], float (&wbv)[4]) {
+    float pre_y[4];
+    Real fi[4], fq[4];
+#ifdef FSK_ABLATE
+    if (ablate) {  // timing experiments only (tools/): skips stages, results are wrong
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (ablate & 8) { pre_y[k] = x[k]; wbv[k] = x[k]; } else pre_y[k] = pre_stage(L, C, agc_on, x[k], wbv[k]);
+        if (ablate & 4) { fi[k] = (Real)pre_y[k]; fq[k] = (Real)pre_y[k] * (Real)0.5; } else mix_lp(L, C, pre_y[k], fi[k], fq[k]);
+      }
+      Real a0, p0, a1, p1;
+      bool b0, b1;
+      if (ablate & 2) {
+        a0 = fi[0] + fi[1]; p0 = fq[0] + fq[1]; b0 = p0 > (Real)0;
+        a1 = fi[2] + fi[3]; p1 = fq[2] + fq[3]; b1 = p1 > (Real)0;
+      } else {
+        b0 = discriminate(L, C, fi[0] + fi[1], fq[0] + fq[1], a0, p0);
+        b1 = discriminate(L, C, fi[2] + fi[3], fq[2] + fq[3], a1, p1);
+      }
+      if (ablate & 1) {
+        L.sil_thr += a0 + a1 + (Real)((b0 ? 1 : 0) + (b1 ? 2 : 0)) + p0 + p1;  // keep everything live
+      } else {
+        downsampled_bit<Real, PolyT, FRAC>(L, P, S, poly, poly_u, R, need, ring_base, amp_base, lane, row, valid, true, b0, a0, O);
+        downsampled_bit<Real, PolyT, FRAC>(L, P, S, poly, poly_u, R, need, ring_base, amp_base, lane, row, valid, true, b1, a1, O);
+      }
+      return;
+    }
+#endif
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      pre_y[k] = pre_stage(L, C, agc_on, x[k], wbv[k]);
+      mix_lp(L, C, pre_y[k], fi[k], fq[k]);
+    }
+    Real amp0, post0, amp1, post1;
+    const bool bit0 = discriminate(L, C, fi[0] + fi[1], fq[0] + fq[1], amp0, post0);
+    bool bit1 = discriminate(L, C, fi[2] + fi[3], fq[2] + fq[3], amp1, post1);
+    // one copy of the state machine, run twice (keeps the kernel and its live ranges small)
+#pragma unroll 1
+    for (int p = 0; p < 2; p++) {
+      const Real amp = p ? amp1 : amp0;
+      const Real post = p ? post1 : post0;
+      const bool bit = p ? bit1 : bit0;
+      trace_put(amp, post, bit);
+      const bool rst = downsampled_bit<Real, PolyT, FRAC>(L, P, S, poly, poly_u, R, need, ring_base, amp_base, lane,
+                                                          row, valid, true, bit, amp, O);
+      if (p == 0 && __ballot(rst)) {
+        if (rst) {  // resetState() ran after pair 0: redo the reset-sensitive half of samples 2,3
+          Real gi2, gq2, gi3, gq3;
+          mix_lp(L, C, pre_y[2], gi2, gq2);
+          mix_lp(L, C, pre_y[3], gi3, gq3);
+          bit1 = discriminate(L, C, gi2 + gi3, gq2 + gq3, amp1, post1);
+        }
+      }
+    }
+  };
+
+  const bool fast = UNI && (__builtin_amdgcn_readfirstlane((int)L.ds_cnt) == 0);
+  bool cur_fast = n > 0 && tile_is_fast(0);
+  if (cur_fast) load_tile_fast(0);
   for (size_t t0 = 0; t0 < n; t0 += kTile) {
     __syncthreads();  // single-wave workgroup: orders last tile's LDS reads before the overwrite
+    if (cur_fast) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) stage[chunk * kSlotStride + 8u * i + sub_row] = pre[i];
+      for (int i = 0; i < kChunks; i++) stage[chunk * kSlotStride + (uint32_t)kRowsPerLoad * i + sub_row] = pre[i];
+    } else {
+      stage_tile_slow(t0);
+    }
     __syncthreads();
-    if (t0 + kTile < n) load_tile(t0 + kTile);
+    cur_fast = (t0 + kTile < n) && tile_is_fast(t0 + kTile);
+    if (cur_fast) load_tile_fast(t0 + kTile);
 
     const uint32_t tile_len = (uint32_t)((n - t0) < (size_t)kTile ? (n - t0) : (size_t)kTile);
     const uint32_t n_chunks = (tile_len + 3u) >> 2;
@@ -482,32 +674,17 @@ __global__ __launch_bounds__(64) void demod_kernel(DemodParams P, DemodState S, 
       float xv[4] = {v4.x, v4.y, v4.z, v4.w};
       float wb[4];
       const uint32_t lim = tile_len - 4u * c < 4u ? tile_len - 4u * c : 4u;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if ((uint32_t)k < lim) {
-          front(L, C, agc_on, xv[k], wb[k]);
-          L.ds_cnt++;
-          bool dec = L.ds_cnt >= 2;
-          bool any = UNI ? (bool)__builtin_amdgcn_readfirstlane((int)dec) : (__ballot(dec) != 0);
-          if (any) {
-            Real amp = (Real)0, post = (Real)0;
-            uint32_t bit = 0;
-            if (UNI || dec) {
-              bit = discriminate(L, C, amp, post);
-              L.ds_cnt = 0;
-            }
-            if (tracing && stream == S.trace_stream && (UNI || dec)) {
-              uint32_t k = *S.trace_n;
-              if (k < S.trace_cap) {
-                S.trace_amp[k] = (double)amp;
-                S.trace_post[k] = (double)post;
-                S.trace_bit[k] = (uint8_t)bit;
-              }
-              *S.trace_n = k + 1;
-            }
-            downsampled_bit<Real, PolyT, FRAC>(L, P, S, poly, poly_u, lane, row, valid, UNI || dec, bit, amp, O);
-          }
+      if (fast && lim == 4u) {
+        block4(xv, wb);
+      } else {
+        const float *xs = reinterpret_cast<const float *>(&stage[c * kSlotStride + lane]);
+#pragma unroll 1
+        for (uint32_t k = 0; k < lim; k++) {
+          float w;
+          step_generic(xs[k], w);
+          if (writeback && valid) samples[(size_t)row * pitch + t0 + 4u * c + k] = w;
         }
+        continue;
       }
       if (writeback && valid) {
         float *dst = samples + (size_t)row * pitch + t0 + 4u * c;
@@ -518,6 +695,15 @@ __global__ __launch_bounds__(64) void demod_kernel(DemodParams P, DemodState S, 
     }
   }
 
+  // ring bookkeeping back to per-stream state
+  {
+    const uint32_t rl = ring_base + R.k;
+    L.ring_len = rl < P.ring_cap ? rl : P.ring_cap;
+    const uint32_t al = amp_base + R.k;
+    L.amp_len = al < P.amp_cap ? al : P.amp_cap;
+    L.poly_phase = R.phase;
+    L.amp_pos = R.amp_pos;
+  }
   for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
   if (FRAC)
     for (uint32_t p = 0; p < P.d; p++) gpoly_u[p * 64u + lane] = poly_u[p * 64u + lane];
@@ -533,17 +719,16 @@ size_t demod_lds_bytes(const DemodParams &P) {
   return sizeof(float4) * kChunks * kSlotStride + reg * (P.frac ? 2u : 1u);
 }
 
-// kernel variants: Real x {u32, u64, u64+frac} x {uniform, per-lane decimator phase}
+// kernel variants: Real x {u32, u64, u64+frac} x {uniform, per-lane decimator phase} x trace
+#define FSK_FOR_RT(X, R, T, F)                                                                     \
+  X(R, T, F, true, false) X(R, T, F, false, false) X(R, T, F, true, true) X(R, T, F, false, true)
 #define FSK_FOR_ALL_VARIANTS(X)                                                                    \
-  X(float, uint32_t, false, true) X(float, uint32_t, false, false)                                 \
-  X(float, uint64_t, false, true) X(float, uint64_t, false, false)                                 \
-  X(float, uint64_t, true, true) X(float, uint64_t, true, false)                                   \
-  X(double, uint32_t, false, true) X(double, uint32_t, false, false)                               \
-  X(double, uint64_t, false, true) X(double, uint64_t, false, false)                               \
-  X(double, uint64_t, true, true) X(double, uint64_t, true, false)
+  FSK_FOR_RT(X, float, uint32_t, false) FSK_FOR_RT(X, float, uint64_t, false)                      \
+  FSK_FOR_RT(X, float, uint64_t, true) FSK_FOR_RT(X, double, uint32_t, false)                      \
+  FSK_FOR_RT(X, double, uint64_t, false) FSK_FOR_RT(X, double, uint64_t, true)
 
-// Host-side launcher (called from fsk_api.hip).  uniform_ds: every stream's downsample.counter is
-// equal (true unless single streams were reset at odd sample positions).
+// Host-side launcher (called from fsk_api.hip).  uniform_ds: every stream's downsample.counter
+// and ring positions are equal (true unless single streams were reset at odd sample positions).
 hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, const DemodParams &P,
                         const DemodState &S, float *samples, size_t n, size_t pitch, uint8_t *out,
                         size_t out_pitch, uint32_t *out_counts, uint32_t *eod_counts,
@@ -551,12 +736,17 @@ hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, const De
   const uint32_t blocks = (P.n_streams + 63u) / 64u;
   const size_t lds_bytes = demod_lds_bytes(P);
   const int vec_ok = (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(samples) & 15u) == 0);
-  const int wb = writeback ? 1 : 0;
+  int wb = writeback ? 1 : 0;
+#ifdef FSK_ABLATE
+  if (const char *a = getenv("FSK_ABLATE")) wb |= atoi(a) << 8;
+#endif
   const bool f64 = precision != 0, wide = P.wide != 0, frac = P.frac != 0;
+  const bool trace = S.trace_stream != 0xFFFFFFFFu;
   dim3 g(blocks), b(64);
-#define FSK_LAUNCH(R, T, F, U)                                                                     \
-  if (f64 == (sizeof(R) == 8) && wide == (sizeof(T) == 8) && frac == F && uniform_ds == U)         \
-    hipLaunchKernelGGL((demod_kernel<R, T, F, U>), g, b, lds_bytes, stream, P, S, samples, n,      \
+#define FSK_LAUNCH(R, T, F, U, TR)                                                                 \
+  if (f64 == (sizeof(R) == 8) && wide == (sizeof(T) == 8) && frac == F && uniform_ds == U &&       \
+      trace == TR)                                                                                 \
+    hipLaunchKernelGGL((demod_kernel<R, T, F, U, TR>), g, b, lds_bytes, stream, P, S, samples, n,  \
                        pitch, vec_ok, wb, out, out_pitch, out_counts, eod_counts);
   FSK_FOR_ALL_VARIANTS(FSK_LAUNCH)
 #undef FSK_LAUNCH
@@ -565,9 +755,9 @@ hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, const De
 
 hipError_t set_demod_lds_limit(size_t lds_bytes) {
   hipError_t e = hipSuccess;
-#define FSK_ATTR(R, T, F, U)                                                                       \
+#define FSK_ATTR(R, T, F, U, TR)                                                                   \
   if (e == hipSuccess)                                                                             \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_kernel<R, T, F, U>),             \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_kernel<R, T, F, U, TR>),         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   FSK_FOR_ALL_VARIANTS(FSK_ATTR)
 #undef FSK_ATTR

@@ -104,10 +104,10 @@ __device__ inline float frame_next(FrameGen &G, const ModParams &M, ByteFn paylo
 // coalesced store of a 64-row x 32-sample LDS tile (rows = this wave's streams)
 __device__ inline void store_tile(const float4 *stage, float *out, size_t pitch, size_t t0, size_t row_len_limit,
                                   uint32_t n_streams, const uint32_t *row_lens_lds, int vec_ok) {
-  const uint32_t lane = threadIdx.x, sub_row = lane >> 3, chunk = lane & 7;
+  const uint32_t lane = threadIdx.x, sub_row = lane / kChunks, chunk = lane % kChunks;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint32_t lr = 8u * i + sub_row;
+  for (int i = 0; i < kChunks; i++) {
+    uint32_t lr = (uint32_t)kRowsPerLoad * i + sub_row;
     uint32_t r = blockIdx.x * 64u + lr;
     if (r >= n_streams) continue;
     size_t lim = row_lens_lds ? (size_t)row_lens_lds[lr] : row_len_limit;

@@ -29,7 +29,11 @@ namespace fsk {
   X(cad_ctr)            /* gsc % round(dsSPB/4), kept incrementally (fsk.ts:302) */         \
   X(sil_cnt)            /* silence.sampleCount */                                           \
   X(started)            /* frame.started */                                                 \
-  X(bit_acc) X(bit_cnt) X(bit_sample_ctr) X(next_bit_idx)   /* bitSync.* fsk.ts:113-114 */  \
+  X(bit_acc)            /* bitSync.bitAccumulator fsk.ts:113 */                             \
+  X(bit_wait)           /* int32: nextBitSampleIndex - bitSampleCounter (fsk.ts:335); */    \
+                        /* kBigWait while no frame is started */                            \
+  X(bit_reload)         /* bit_wait right after the last bit decision: bitAccumCount at */  \
+                        /* the next decision = bit_reload - bit_wait (fsk.ts:336) */        \
   X(byte_cur) X(bit_pos)                /* byteState fsk.ts:125 */                          \
   X(ring_len)           /* syncSamplesBuffer.length (utils.ts:10) */                        \
   X(poly_phase)         /* pushes into the sync ring mod dsSPB (polyphase register index) */\
@@ -110,8 +114,13 @@ struct ModParams {
   uint8_t pre[2 * 16];
 };
 
-static constexpr int kTile = 32;            // samples per stream per LDS tile (128 B per row)
-static constexpr int kChunks = kTile / 4;   // 16-B chunks per row per tile
+static constexpr uint32_t kBigWait = 0x40000000u;  // bit_wait while !started (12 h of decimated samples)
+#ifndef FSK_TILE
+#define FSK_TILE 32
+#endif
+static constexpr int kTile = FSK_TILE;      // samples per stream per LDS tile (FSK_TILE*4 B per row)
+static constexpr int kChunks = kTile / 4;   // 16-B chunks per row per tile (8, 16 or 32)
+static constexpr int kRowsPerLoad = 64 / kChunks;  // rows one wave-wide 16-B/lane load covers
 static constexpr int kSlotStride = 65;      // 16-B slots per chunk column (64 lanes + 1 pad)
 
 }  // namespace fsk
