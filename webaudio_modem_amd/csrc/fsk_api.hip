@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <limits>
 #include <new>
 #include <string>
@@ -15,9 +16,14 @@
 #include "fsk_params.h"
 
 namespace fsk {
-hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, const DemodParams &P, const DemodState &S,
-                        float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch,
+hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, bool append, const DemodParams &P,
+                        const DemodState &S, float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch,
                         uint32_t *out_counts, uint32_t *eod_counts, hipStream_t stream);
+bool demod_fast_applicable(int precision, bool uniform_even, const DemodParams &P, const DemodState &S,
+                           const float *samples, size_t pitch);
+hipError_t launch_demod_fast(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+                             size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
+                             uint32_t *eod_counts, hipStream_t stream);
 hipError_t set_demod_lds_limit(size_t lds_bytes);
 size_t demod_lds_bytes(const DemodParams &P);
 hipError_t launch_modulate(const ModParams &M, const double *coef, const uint8_t *payloads, const uint32_t *lens,
@@ -122,6 +128,8 @@ struct fskhip_engine {
   uint64_t calls = 0, total_samples = 0;
   std::vector<uint64_t> base_calls, base_samples;
   bool ds_uniform = true;
+  uint32_t ds_parity = 0;        // downsample.counter shared by all streams while ds_uniform
+  bool force_generic = false;    // FSKHIP_FORCE_GENERIC=1: never use the fast kernel (tests)
   bool demod_ok = true;          // false: configuration the demodulator kernels do not implement
   std::string demod_why;
   uint32_t trace_cap = 0;
@@ -255,6 +263,7 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   fskhip_engine *e = new (std::nothrow) fskhip_engine();
   if (!e) return fail(FSKHIP_E_NOMEM, "out of host memory");
   e->device = device; e->precision = precision; e->n_streams = n_streams; e->cfg0 = c0;
+  if (const char *fg = getenv("FSKHIP_FORCE_GENERIC")) e->force_generic = fg[0] == '1';
 
   // calculateParameters (fsk.ts:426-444), in doubles like the reference
   const double downsampleRate = c0.sampleRate / 2;
@@ -352,6 +361,11 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   }
   P.agc_attack = 1.0 - std::exp(-1.0 / (c0.sampleRate * 0.001));  // fsk.ts:48-49
   P.agc_release = 1.0 - std::exp(-1.0 / (c0.sampleRate * 0.01));
+  if (!P.agc_on) { P.agc_attack = 0.0; P.agc_release = 0.0; }  // fp32 kernels run the AGC block as a no-op
+  P.f_lp_b0 = (float)P.lp_b0; P.f_lp_b0h = (float)(0.5 * P.lp_b0); P.f_lp_a2 = (float)P.lp_a2;
+  // delta = 1 + a1 + a2 formed in f64, then rounded (see fsk_demod.hip lp32)
+  P.f_lp_delta = (float)(1.0 + P.lp_a1 + P.lp_a2);
+  P.f_agc_att = (float)P.agc_attack; P.f_agc_rel = (float)P.agc_release;
 
   ModParams &M = e->M;
   M.n_streams = n_streams;
@@ -385,6 +399,12 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     coef[(size_t)CF_omega * n_streams + s] = 2 * M_PI * center / c.sampleRate;
     coef[(size_t)CF_mark_w * n_streams + s] = 2 * M_PI * c.markFrequency / c.sampleRate;
     coef[(size_t)CF_space_w * n_streams + s] = 2 * M_PI * c.spaceFrequency / c.sampleRate;
+    for (int k = 1; k <= 3; k++) {
+      const long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)k * (long double)center /
+                              (long double)c.sampleRate;
+      coef[(size_t)(CF_w1_re + 2 * (k - 1)) * n_streams + s] = (double)cosl(ang);
+      coef[(size_t)(CF_w1_im + 2 * (k - 1)) * n_streams + s] = (double)sinl(ang);
+    }
     // NCO increment as a 64-bit fraction of a turn: frac(center/sr) * 2^64
     long double turns = (long double)center / (long double)c.sampleRate;
     turns -= std::floor(turns);
@@ -463,14 +483,27 @@ int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_
     e->timing_stream = st;
     HIP_TRY(hipEventRecord(e->ev[e->ev_used], st));
   }
-  HIP_TRY(launch_demod(e->precision, e->ds_uniform, (flags & FSKHIP_DEMOD_WRITEBACK_AGC) != 0, e->P, e->S, d_samples,
-                       n, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+  {
+    const bool wb = (flags & FSKHIP_DEMOD_WRITEBACK_AGC) != 0;
+    // whole 16-sample tiles of lock-step fp32 streams go through the fast kernel, the rest (and every
+    // other configuration) through the generic one
+    size_t n_fast = 0;
+    if (!e->force_generic && demod_fast_applicable(e->precision, e->ds_uniform && e->ds_parity == 0, e->P,
+                                                   e->S, d_samples, pitch))
+      n_fast = n & ~(size_t)15;
+    if (n_fast) HIP_TRY(launch_demod_fast(wb, e->P, e->S, d_samples, n_fast, pitch, d_out, out_pitch, d_out_counts,
+                                          d_eod_counts, st));
+    if (n_fast < n || n == 0)
+      HIP_TRY(launch_demod(e->precision, e->ds_uniform, wb, n_fast != 0, e->P, e->S, d_samples + n_fast, n - n_fast,
+                           pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+  }
   if (timed) {
     HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], st));
     e->ev_used += 2;
   }
   e->calls += 1;
   e->total_samples += n;
+  e->ds_parity = (e->ds_parity + (uint32_t)(n & 1)) & 1u;
   return FSKHIP_OK;
 }
 
@@ -561,12 +594,13 @@ int fskhip_reset(fskhip_engine *e, int64_t stream) {
   if (stream < 0) {
     for (auto &v : e->base_calls) v = e->calls;
     for (auto &v : e->base_samples) v = e->total_samples;
-    e->ds_uniform = true;
+    e->ds_parity = 0;  // every decimator restarts; ring positions stay as they were (see below)
   } else {
     e->base_calls[stream] = e->calls;
     e->base_samples[stream] = e->total_samples;
-    // the other streams may sit mid-pair of the /2 decimator: per-lane decimation from now on
-    if (e->n_streams > 1 && (e->total_samples & 1)) e->ds_uniform = false;
+    // the other streams may sit mid-pair of the /2 decimator: from now on this stream pushes into its
+    // rings at other instants than its neighbours, for good (ring positions are never re-aligned)
+    if (e->n_streams > 1 && e->ds_parity) e->ds_uniform = false;
   }
   return FSKHIP_OK;
 }

@@ -46,6 +46,9 @@
 
 #include "fsk_params.h"
 
+#ifndef FSK_FAST_WAVES
+#define FSK_FAST_WAVES 2
+#endif
 #ifndef FSK_F32_WAVES_PER_SIMD
 #define FSK_F32_WAVES_PER_SIMD 2
 #endif
@@ -60,19 +63,17 @@ struct Consts;
 
 template <>
 struct Consts<float> {
-  float lp_b0, lp_a2, lp_delta, agc_att, agc_rel;
+  float lp_b0, lp_b0h, lp_a2, lp_delta, agc_att, agc_rel;
   float bp_b0, bp_a1, bp_a2;
   uint32_t inc_lo, inc_hi;
-  // converts once and pins the value in an SGPR (otherwise hipcc re-converts the f64 kernel
-  // argument with a quarter-rate v_cvt_f32_f64 at every use)
-  static __device__ float pin(double v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)v)));
-  }
   __device__ void init(const DemodParams &P, const DemodState &S, uint32_t row) {
-    // delta = 1 + a1 + a2 (= b0+b1+b2 for the unity-DC-gain Butterworth) is formed in f64 and only
-    // then rounded: rounding a1 ~ -1.94 itself to f32 would move the DC gain by ~1e-4 at 300 baud
-    lp_b0 = pin(P.lp_b0); lp_a2 = pin(P.lp_a2); lp_delta = pin(1.0 + P.lp_a1 + P.lp_a2);
-    agc_att = pin(P.agc_attack); agc_rel = pin(P.agc_release);
+    // host-rounded constants (DemodParams::f_*).  delta = 1 + a1 + a2 (= b0+b1+b2 for the unity-DC-
+    // gain Butterworth) is formed in f64 and only then rounded: rounding a1 ~ -1.94 itself to f32
+    // would move the DC gain by ~1e-4 at 300 baud.  The I/Q low-passes run with b0/2: a power-of-two
+    // scaling is exact in binary floating point, so their outputs are bit for bit half the
+    // reference's and the /2 boxcar sum IS the average.
+    lp_b0 = P.f_lp_b0; lp_b0h = P.f_lp_b0h; lp_a2 = P.f_lp_a2; lp_delta = P.f_lp_delta;
+    agc_att = P.f_agc_att; agc_rel = P.f_agc_rel;
     size_t n = P.n_streams;
     bp_b0 = (float)S.coef[(size_t)CF_bp_b0 * n + row];
     bp_a1 = (float)S.coef[(size_t)CF_bp_a1 * n + row];
@@ -240,15 +241,17 @@ __device__ inline float atan2_fast(float y, float x) {
 }
 
 __device__ inline float pre_stage(Lane<float> &L, const Consts<float> &C, bool agc_on, float xin, float &agc_out) {
-  float xs = xin;
-  if (agc_on) {
-    xs = xin * L.agc_gain;
-    float level = __builtin_fabsf(xs);
-    float target = 0.5f * __builtin_amdgcn_rcpf(level);
-    float rate = level > 0.5f ? C.agc_att : C.agc_rel;
-    float g = __builtin_fmaf(target - L.agc_gain, rate, L.agc_gain);
+  // AGC (fsk.ts:52-76), always executed: with AGC disabled the host sets both rates to 0 and the
+  // gain to 1, which makes this block an exact no-op (x*1, g + t*0 = g)
+  (void)agc_on;
+  const float xs = xin * L.agc_gain;
+  {
+    const float level = __builtin_fabsf(xs);
+    const float t = __builtin_fmaf(0.5f, __builtin_amdgcn_rcpf(level), -L.agc_gain);  // target - gain
+    const float rate = level > 0.5f ? C.agc_att : C.agc_rel;
+    float g = __builtin_fmaf(t, rate, L.agc_gain);
     g = level > 0.0f ? g : L.agc_gain;  // exact zero holds the gain (fsk.ts:67)
-    L.agc_gain = __builtin_fminf(__builtin_fmaxf(g, 0.1f), 10.0f);
+    L.agc_gain = __builtin_amdgcn_fmed3f(g, 0.1f, 10.0f);
   }
   agc_out = xs;
   // band-pass: y = b0*(x - x2) - a2*y2 - a1*y1 (the y1 term last: shortest recurrence)
@@ -268,15 +271,15 @@ __device__ inline void mix_lp(Lane<float> &L, const Consts<float> &C, float y, f
   uint32_t lo = L.nco_lo + C.inc_lo;
   L.nco_hi = L.nco_hi + C.inc_hi + (lo < L.nco_lo ? 1u : 0u);
   L.nco_lo = lo;
-  fi = lp32(C.lp_b0, C.lp_a2, C.lp_delta, L.li_x1, L.li_x2, L.li_y1, L.li_y2, y * c);
-  fq = lp32(C.lp_b0, C.lp_a2, C.lp_delta, L.lq_x1, L.lq_x2, L.lq_y1, L.lq_y2, y * s);
+  fi = lp32(C.lp_b0h, C.lp_a2, C.lp_delta, L.li_x1, L.li_x2, L.li_y1, L.li_y2, y * c);
+  fq = lp32(C.lp_b0h, C.lp_a2, C.lp_delta, L.lq_x1, L.lq_x2, L.lq_y1, L.lq_y2, y * s);
 }
 
 __device__ inline bool discriminate(Lane<float> &L, const Consts<float> &C, float sum_i, float sum_q, float &amp,
                                     float &post) {
   const float PI = 3.14159265358979323846f;
-  float avg_i = sum_i * 0.5f;
-  float avg_q = sum_q * 0.5f;
+  float avg_i = sum_i;  // sums of the half-scale low-pass outputs = the averages (see lp_b0h)
+  float avg_q = sum_q;
   float phase = atan2_fast(avg_q, avg_i);
   amp = __builtin_amdgcn_sqrtf(__builtin_fmaf(avg_i, avg_i, avg_q * avg_q));
   float dphi = phase - L.last_phase;
@@ -474,7 +477,7 @@ __device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
 // SIMD issues a VALU op only every 4 cycles (MI355X_MICROARCH.md), so occupancy is throughput.
 template <typename Real, typename PolyT, bool FRAC, bool UNI, bool TRACE>
 __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1)) void demod_kernel(DemodParams P, DemodState S, float *__restrict__ samples,
-                                                   size_t n, size_t pitch, int vec_ok, int writeback,
+                                                   size_t n, size_t pitch, int vec_ok, int writeback, int append,
                                                    uint8_t *__restrict__ out, size_t out_pitch,
                                                    uint32_t *__restrict__ out_counts,
                                                    uint32_t *__restrict__ eod_counts) {
@@ -512,8 +515,8 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
   OutCtx O;
   O.out_row = out + (size_t)row * out_pitch;
   O.out_pitch = (uint32_t)out_pitch;
-  O.out_cnt = 0;
-  O.eod_cnt = 0;
+  O.out_cnt = (append && valid) ? out_counts[stream] : 0;       // continue a preceding launch of the same call
+  O.eod_cnt = (append && valid && eod_counts) ? eod_counts[stream] : 0;
 
   // tile prefetch: load i covers kRowsPerLoad rows; lane -> (row i*kRowsPerLoad + lane/kChunks,
   // chunk lane%kChunks), i.e. kChunks lanes sweep one row's contiguous tile segment.
@@ -714,6 +717,439 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
   }
 }
 
+
+// ================================================================================================
+// Fast kernel: fp32, <= 31 pattern bits, integer ring capacity, every stream of the launch in lock
+// step at a decimator pair boundary, whole 16-sample tiles.  Same arithmetic and the same state
+// arrays as the generic fp32 kernel above (a call may run this kernel for its first n - n%16
+// samples and the generic one for the rest); what differs is instruction economy:
+//  * the four front ends of a block and both discriminators are one branch-free region;
+//  * the NCO phasor of sample 0 comes from the exact 64-bit turn accumulator through v_cos/v_sin,
+//    samples 1..3 by one complex multiply with per-stream constants e^{j k omega};
+//  * ring positions / push counts live in SGPRs, the amplitude ring is written with a buffer store
+//    whose row offset is an SGPR, globalSampleCounter is derived from the push count;
+//  * polyphase registers of both decimated steps are fetched from LDS at block start.
+// ================================================================================================
+typedef float f2 __attribute__((ext_vector_type(2)));
+static constexpr int kFastTile = 16;
+
+__device__ inline f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ inline f2 bc2(float v) { return (f2){v, v}; }
+
+struct FastLane {
+  float g, bx1, bx2, by1, by2;       // AGC gain, pre-filter history
+  f2 lx1, lx2, ly, lv;               // I/Q low-pass (x = I, y = Q), velocity form, half scale
+  float px1, px2, py, pv;            // post filter
+  float last_phase, thr;
+  uint32_t nco_lo, nco_hi, cad, sil, acc, wait, reload, byte_cur, bit_pos, started, thr_eff, matched;
+  uint32_t koff;                     // globalSampleCounter = k + koff (mod 2^32)
+  uint32_t out_cnt, eod_cnt, sync_det, eod_total;
+};
+struct FastConst {                   // per-stream constants (VGPRs)
+  float bp_b0, bp_a1, bp_a2;
+  f2 w1, w2, w3;
+  uint32_t inc_lo, inc_hi, inc4_lo, inc4_hi;
+};
+struct FastUni {                     // wave-uniform constants
+  float lp_b0, lp_a2, lp_delta, agc_att, agc_rel;   // scalar uses (SGPR operands)
+  f2 a2v, ndv, b0hv;                 // (a2,a2), (-delta,-delta), (b0/2,b0/2): packed-math operands, pinned in VGPRs
+};
+
+__device__ inline void fast_reset(FastLane &F, uint32_t k, uint32_t matched_min) {  // resetState()
+  F.nco_lo = 0; F.nco_hi = 0;
+  F.last_phase = 0.0f;
+  F.koff = 0u - k;  // globalSampleCounter = 0
+  F.cad = 0;
+  F.acc = 0; F.wait = kBigWait; F.reload = 0;
+  F.byte_cur = 0; F.bit_pos = 0;
+  F.started = 0; F.thr_eff = matched_min;
+  F.sil = 0;
+  F.lx1 = bc2(0.f); F.lx2 = bc2(0.f); F.ly = bc2(0.f); F.lv = bc2(0.f);
+  F.px1 = 0.f; F.px2 = 0.f; F.py = 0.f; F.pv = 0.f;
+}
+
+// I/Q low-pass step on the mixed sample m = (y*cos, y*sin); returns the (half-scale) outputs
+__device__ inline f2 fast_lp2(FastLane &F, const FastUni &U, f2 m) {
+  f2 t = fma2(bc2(2.0f), F.lx1, m) + F.lx2;
+  f2 u = fma2(U.ndv, F.ly, U.b0hv * t);
+  F.lv = fma2(U.a2v, F.lv, u);
+  F.ly = F.ly + F.lv;
+  F.lx2 = F.lx1; F.lx1 = m;
+  return F.ly;
+}
+__device__ inline f2 cmul(f2 z, f2 w) {  // z * w
+  return fma2(bc2(z.y), (f2){-w.y, w.x}, bc2(z.x) * w);
+}
+
+// phase / amplitude / slicer of one decimated sample from the pair sums (fsk.ts:247-264)
+__device__ inline bool fast_disc(FastLane &F, const FastUni &U, f2 sum, float &amp) {
+  const float PI = 3.14159265358979323846f;
+  const float phase = atan2_fast(sum.y, sum.x);
+  amp = __builtin_amdgcn_sqrtf(__builtin_fmaf(sum.x, sum.x, sum.y * sum.y));
+  float dphi = phase - F.last_phase;
+  float wrap = dphi > PI ? -2.0f * PI : 0.0f;
+  wrap = dphi < -PI ? 2.0f * PI : wrap;
+  dphi += wrap;
+  F.last_phase = phase;
+  const float f = lp32(U.lp_b0, U.lp_a2, U.lp_delta, F.px1, F.px2, F.py, F.pv, dphi);
+  return f > 0.0f;
+}
+
+struct FastCtx {
+  uint32_t *poly;            // LDS polyphase registers [d][64]
+  uint32_t lane, row, need, amp_base;
+  bool valid;
+  uint8_t *out_row;
+  uint32_t out_pitch;
+  uint32_t amp_voff;         // row*4, or out of range for lanes beyond the batch
+};
+
+// processDownsampledBit (fsk.ts:278-344); k = pushes of this launch including this one (SGPR),
+// phase = push slot (SGPR), amp_soff = byte offset of the amplitude-ring row (SGPR).
+// Returns true for lanes on which resetState() ran.
+__device__ inline bool fast_fsm(FastLane &F, const DemodParams &P, const DemodState &S, const FastCtx &X,
+                                __amdgpu_buffer_rsrc_t amp_rsrc, bool bitb, float amp, uint32_t r_old,
+                                uint32_t phase, uint32_t k, uint32_t amp_soff) {
+  const uint32_t qn = ~(uint32_t)P.pat_q, mask = (uint32_t)P.pat_mask;
+  const uint32_t bit = bitb ? 1u : 0u;
+  // syncSamplesBuffer.put(bit)
+  const uint32_t r = (r_old << 1) | bit;
+  X.poly[phase * 64u + X.lane] = r;
+  F.matched += (uint32_t)__builtin_popcount((r ^ qn) & mask);
+  F.matched -= (uint32_t)__builtin_popcount((r ^ (qn << 1)) & (mask << 1));
+  // syncAmplitudeBuffer.put(amp)
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, X.amp_voff, amp_soff, 0);
+  // globalSampleCounter % round(dsSPB/4)
+  const uint32_t c1 = F.cad + 1;
+  const bool hit = c1 == P.cadence;
+  F.cad = hit ? 0u : c1;
+  // silence run (fsk.ts:285-295)
+  F.sil = (amp < F.thr) ? F.sil + 1 : 0u;
+  const bool eod = F.sil >= P.eod_min;
+  // bit clock, ungated
+  F.acc += bit;
+  F.wait -= 1u;
+  const bool decide = (int32_t)F.wait <= 0;
+  const bool cand = hit & (F.matched >= F.thr_eff);
+  bool did_reset = false;
+
+  if (__builtin_amdgcn_ballot_w64(eod | cand)) {
+    if (eod) {                                                   // fsk.ts:288-291
+      F.eod_cnt++; F.eod_total++;
+      fast_reset(F, k, P.matched_min);
+      did_reset = true;
+    }
+    const bool sync_now = cand & !eod & (k >= X.need);           // fsk.ts:302, 315
+    uint64_t m = __builtin_amdgcn_ballot_w64(sync_now);
+    if (m) {
+      if (sync_now) {
+        F.started = 1; F.thr_eff = 0xFFFFFFFFu;
+        F.byte_cur = 0; F.bit_pos = 0;
+        F.acc = 0; F.wait = 0; F.reload = 0;
+        F.sync_det++;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // ring stores have reached L2
+      const uint32_t pushes = X.amp_base + k;
+      const uint32_t slen = pushes < P.amp_cap ? pushes : P.amp_cap;
+      while (m) {
+        const int src = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t srow = (uint32_t)__builtin_amdgcn_readlane((int)X.row, src);
+        double part = 0.0;
+        for (uint32_t i = X.lane; i < slen; i += 64) {
+          const float *p = S.amp_ring + (size_t)i * P.n_streams + srow;
+          part += (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const double sum = wave_sum(part);
+        if ((int)X.lane == src) F.thr = (float)((sum / (double)slen) * 0.1);   // fsk.ts:321-326
+      }
+    }
+  }
+
+  const bool dec_now = decide & !eod;
+  if (__builtin_amdgcn_ballot_w64(dec_now)) {
+    bool bad_start = false, emit = false, bad_stop = false, stale = false;
+    if (dec_now) {
+      if (F.started) {
+        const uint32_t cnt = F.reload - F.wait;                  // bitAccumCount
+        const uint32_t b = (2u * F.acc > cnt) ? 1u : 0u;         // fsk.ts:336
+        F.acc = 0;
+        F.wait += P.d;
+        F.reload = F.wait;
+        const uint32_t pos = F.bit_pos;
+        F.byte_cur |= b << ((8u - pos) & 31u);                   // data bits MSB first (fsk.ts:358)
+        const bool is_stop = pos == P.stop_pos;
+        bad_start = (pos == 0) & (b != 0);
+        emit = is_stop & (b != 0);
+        bad_stop = is_stop & (b == 0);
+        F.bit_pos = is_stop ? 0u : pos + 1;
+      } else {
+        stale = true;                                            // bit_wait ran down without a frame
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(bad_start | bad_stop | stale)) {
+      if (bad_start) { fast_reset(F, k, P.matched_min); did_reset = true; }       // fsk.ts:352-355
+      if (bad_stop) { F.started = 0; F.thr_eff = P.matched_min; F.wait = kBigWait; F.bit_pos = P.stop_pos; }
+      if (stale) F.wait = kBigWait;
+    }
+    if (__builtin_amdgcn_ballot_w64(emit)) {
+      if (emit) {                                                // fsk.ts:367-368
+        if (X.valid && F.out_cnt < X.out_pitch) X.out_row[F.out_cnt] = (uint8_t)F.byte_cur;
+        F.out_cnt++;
+        F.byte_cur = 0;
+      }
+    }
+  }
+  return did_reset;
+}
+
+__global__ __launch_bounds__(64, FSK_FAST_WAVES) void demod_fast_kernel(
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch, int writeback,
+    uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
+    uint32_t *__restrict__ eod_counts) {
+  extern __shared__ float4 lds[];
+  float4 *stage = lds;                                       // [4 chunks][kSlotStride]
+  uint32_t *poly = (uint32_t *)(lds + 4 * kSlotStride);      // [d][64]
+  uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
+
+  const uint32_t lane = threadIdx.x;
+  const uint32_t stream = blockIdx.x * 64u + lane;
+  const bool valid = stream < P.n_streams;
+  const uint32_t row = valid ? stream : P.n_streams - 1;
+  // Per-stream state goes through buffer instructions: descriptor in SGPRs, field offset as the
+  // SGPR soffset, ONE VGPR offset (row*4).  With plain pointers hipcc keeps a 64-bit address pair
+  // per field alive across the whole sample loop for the stores at the end (~90 VGPRs).
+  const uint32_t fld = P.n_streams * 4u;  // bytes per state field
+  const __amdgpu_buffer_rsrc_t rs_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.rs, 0, (int)(fld * RF_COUNT), 0x00020000);
+  const __amdgpu_buffer_rsrc_t is_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.is, 0, (int)(fld * IF_COUNT), 0x00020000);
+  const __amdgpu_buffer_rsrc_t cf_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)S.coef, 0, (int)(2u * fld * CF_COUNT), 0x00020000);
+  const uint32_t row4 = row * 4u;
+  const uint32_t st_voff = valid ? row4 : 0xFFFFFFF0u;  // stores of lanes beyond the batch are dropped
+#define RLOAD(f) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rsrc, row4, (uint32_t)RF_##f * fld, 0))
+#define ILOAD(f) __builtin_amdgcn_raw_buffer_load_b32(is_rsrc, row4, (uint32_t)IF_##f * fld, 0)
+#define CLOAD(f) ((float)__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cf_rsrc, row4 * 2u, (uint32_t)(f) * fld * 2u, 0)))
+
+  FastLane F;
+  F.g = RLOAD(agc_gain);
+  F.bx1 = RLOAD(bp_x1); F.bx2 = RLOAD(bp_x2); F.by1 = RLOAD(bp_y1); F.by2 = RLOAD(bp_y2);
+  F.lx1 = (f2){RLOAD(li_x1), RLOAD(lq_x1)}; F.lx2 = (f2){RLOAD(li_x2), RLOAD(lq_x2)};
+  F.ly = (f2){RLOAD(li_y1), RLOAD(lq_y1)}; F.lv = (f2){RLOAD(li_y2), RLOAD(lq_y2)};
+  F.px1 = RLOAD(po_x1); F.px2 = RLOAD(po_x2); F.py = RLOAD(po_y1); F.pv = RLOAD(po_y2);
+  F.last_phase = RLOAD(last_phase); F.thr = RLOAD(sil_thr);
+  F.nco_lo = ILOAD(nco_lo); F.nco_hi = ILOAD(nco_hi);
+  F.cad = ILOAD(cad_ctr); F.sil = ILOAD(sil_cnt); F.acc = ILOAD(bit_acc); F.wait = ILOAD(bit_wait);
+  F.reload = ILOAD(bit_reload); F.byte_cur = ILOAD(byte_cur); F.bit_pos = ILOAD(bit_pos);
+  F.started = ILOAD(started); F.matched = ILOAD(matched);
+  F.thr_eff = F.started ? 0xFFFFFFFFu : P.matched_min;
+  F.koff = ILOAD(gsc);
+  F.sync_det = ILOAD(sync_det); F.eod_total = ILOAD(eod_total);
+  F.out_cnt = 0; F.eod_cnt = 0;
+
+  FastConst K;
+  K.bp_b0 = CLOAD(CF_bp_b0); K.bp_a1 = CLOAD(CF_bp_a1); K.bp_a2 = CLOAD(CF_bp_a2);
+  K.w1 = (f2){CLOAD(CF_w1_re), CLOAD(CF_w1_im)};
+  K.w2 = (f2){CLOAD(CF_w2_re), CLOAD(CF_w2_im)};
+  K.w3 = (f2){CLOAD(CF_w3_re), CLOAD(CF_w3_im)};
+  {
+    const uint64_t inc = S.nco_inc[row];
+    K.inc_lo = (uint32_t)inc; K.inc_hi = (uint32_t)(inc >> 32);
+    K.inc4_lo = (uint32_t)(inc << 2); K.inc4_hi = (uint32_t)((inc << 2) >> 32);
+  }
+  FastUni U;
+  U.lp_b0 = P.f_lp_b0; U.lp_a2 = P.f_lp_a2; U.lp_delta = P.f_lp_delta;
+  U.agc_att = P.f_agc_att; U.agc_rel = P.f_agc_rel;
+  U.a2v = bc2(P.f_lp_a2); U.ndv = bc2(-P.f_lp_delta); U.b0hv = bc2(P.f_lp_b0h);
+  // opaque VGPR pairs: otherwise hipcc parks these uniform values in scratch and reloads them (a
+  // VMEM op, hence a vmcnt wait behind the tile prefetch) at the top of every tile
+  asm volatile("" : "+v"(U.a2v), "+v"(U.ndv), "+v"(U.b0hv));
+
+  for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
+
+  // wave-uniform ring bookkeeping (SGPRs)
+  uint32_t phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)ILOAD(poly_phase));
+  uint32_t amp_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)ILOAD(amp_pos));
+  const uint32_t ring_base = ILOAD(ring_len), amp_base = ILOAD(amp_len);
+  uint32_t k = 0;
+  const uint32_t amp_row_bytes = P.n_streams * 4u;
+  uint32_t amp_soff = amp_pos * amp_row_bytes;
+  const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
+
+  FastCtx X;
+  X.poly = poly; X.lane = lane; X.row = row; X.valid = valid;
+  X.need = ring_base >= P.sample_count ? 0u : P.sample_count - ring_base;
+  X.amp_base = amp_base;
+  X.out_row = out + (size_t)row * out_pitch;
+  X.out_pitch = (uint32_t)out_pitch;
+  const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
+  X.amp_voff = valid ? row * 4u : 0xFFFFFFF0u;  // out of range: the store is dropped by the bounds check
+
+  // tile prefetch: 4 loads of 16 rows x 64 B; lane -> (row 16*i + lane/4, chunk lane%4).  Named
+  // scalars and an unconditional (clamped) prefetch: arrays / conditional definitions end up in scratch.
+  const uint32_t sub_row = lane >> 2, chunk = lane & 3;
+  auto row_ptr = [&](uint32_t i) {
+    uint32_t r = blockIdx.x * 64u + 16u * i + sub_row;
+    r = r < P.n_streams ? r : P.n_streams - 1;
+    return samples + (size_t)r * pitch + 4u * chunk;
+  };
+  const float *src0 = row_ptr(0), *src1 = row_ptr(1), *src2 = row_ptr(2), *src3 = row_ptr(3);
+  // The prefetch loads are inline asm on purpose.  vmcnt counts loads AND stores in issue order, and
+  // hipcc cannot count the stores this loop issues conditionally, so with compiler-visible loads it
+  // waits vmcnt(0) at the top of every tile -- i.e. for the amplitude-ring stores issued a few hundred
+  // cycles earlier (~1-2 us each).  With asm loads the wait is ours: each tile issues at least
+  // kStoresPerTile VMEM ops after its prefetch (the 8 unconditional ring stores), so vmcnt(8) retires
+  // exactly the loads; extra conditional stores only make the wait more conservative, never unsafe.
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f pre0, pre1, pre2, pre3;
+#define FSK_GLOAD4(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+  FSK_GLOAD4(pre0, src0); FSK_GLOAD4(pre1, src1); FSK_GLOAD4(pre2, src2); FSK_GLOAD4(pre3, src3);
+  // everything loaded so far (state, constants, first tile) is complete before the loop; the builtin form
+  // also tells hipcc's own scoreboard, so it needs no vmcnt wait inside the loop
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre0), "+v"(pre1), "+v"(pre2), "+v"(pre3) : : "memory");
+  const uint32_t st_slot = chunk * kSlotStride + sub_row;
+  v4f *stage_v = reinterpret_cast<v4f *>(stage);
+
+  for (size_t t0 = 0; t0 < n; t0 += kFastTile) {
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(8)" : "+v"(pre0), "+v"(pre1), "+v"(pre2), "+v"(pre3) : : "memory");
+    stage_v[st_slot] = pre0;
+    stage_v[st_slot + 16] = pre1;
+    stage_v[st_slot + 32] = pre2;
+    stage_v[st_slot + 48] = pre3;
+    __syncthreads();
+    {
+      // next tile (the last iteration re-reads its own tile: always in bounds, never used)
+      const size_t tn = t0 + kFastTile < n ? t0 + kFastTile : t0;
+      FSK_GLOAD4(pre0, src0 + tn); FSK_GLOAD4(pre1, src1 + tn); FSK_GLOAD4(pre2, src2 + tn); FSK_GLOAD4(pre3, src3 + tn);
+    }
+
+    float4 xq = stage[lane];
+#pragma unroll 1
+    for (uint32_t c = 0; c < 4; c++) {
+      const float4 x4 = xq;
+      if (c < 3) xq = stage[(c + 1) * kSlotStride + lane];
+      // polyphase registers of this block's two decimated steps (d >= 2: distinct slots)
+      const uint32_t ph0 = phase, ph1 = (phase + 1 == P.d) ? 0u : phase + 1;
+      const uint32_t r0 = poly[ph0 * 64u + lane];
+      const uint32_t r1 = poly[ph1 * 64u + lane];
+
+      // ---- AGC + pre-filter, four samples (fsk.ts:52-76, filters.ts:47-87)
+      const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
+      float xs[4], y[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        xs[j] = xin[j] * F.g;
+        const float level = __builtin_fabsf(xs[j]);
+        const float t = __builtin_fmaf(0.5f, __builtin_amdgcn_rcpf(level), -F.g);
+        const float rate = level > 0.5f ? U.agc_att : U.agc_rel;
+        float g = __builtin_fmaf(t, rate, F.g);
+        g = level > 0.0f ? g : F.g;
+        F.g = __builtin_amdgcn_fmed3f(g, 0.1f, 10.0f);
+        float v = K.bp_b0 * (xs[j] - F.bx2);
+        v = __builtin_fmaf(-K.bp_a2, F.by2, v);
+        v = __builtin_fmaf(-K.bp_a1, F.by1, v);
+        F.bx2 = F.bx1; F.bx1 = xs[j];
+        F.by2 = F.by1; F.by1 = v;
+        y[j] = v;
+      }
+      // ---- NCO phasors of the block (fsk.ts:228-232)
+      const float turns = (float)F.nco_hi * 2.3283064365386963e-10f;
+      const f2 z0 = (f2){__builtin_amdgcn_cosf(turns), __builtin_amdgcn_sinf(turns)};
+      const f2 z1 = cmul(z0, K.w1), z2 = cmul(z0, K.w2), z3 = cmul(z0, K.w3);
+      {
+        const uint32_t lo = F.nco_lo + K.inc4_lo;
+        F.nco_hi = F.nco_hi + K.inc4_hi + (lo < F.nco_lo ? 1u : 0u);
+        F.nco_lo = lo;
+      }
+      // ---- mix + I/Q low-pass + /2 boxcar (fsk.ts:229-248)
+      const f2 o0 = fast_lp2(F, U, bc2(y[0]) * z0);
+      const f2 o1 = fast_lp2(F, U, bc2(y[1]) * z1);
+      const f2 o2 = fast_lp2(F, U, bc2(y[2]) * z2);
+      const f2 o3 = fast_lp2(F, U, bc2(y[3]) * z3);
+      float amp0, amp1;
+      const bool bit0 = fast_disc(F, U, o0 + o1, amp0);
+      bool bit1 = fast_disc(F, U, o2 + o3, amp1);
+
+      // ---- frame state machine, decimated sample 0 of the block
+      k++;
+      const bool rst = fast_fsm(F, P, S, X, amp_rsrc, bit0, amp0, r0, ph0, k, amp_soff);
+      amp_soff += amp_row_bytes; if (amp_soff == amp_wrap) amp_soff = 0;
+      if (__builtin_amdgcn_ballot_w64(rst)) {
+        if (rst) {
+          // resetState() ran after sample 1: samples 2,3 restart from the zeroed NCO / filters
+          // (phasors of NCO steps 0 and 1 are (1,0) and w1)
+          const f2 q2 = fast_lp2(F, U, (f2){y[2], 0.0f});
+          const f2 q3 = fast_lp2(F, U, bc2(y[3]) * K.w1);
+          F.nco_lo = K.inc_lo << 1; F.nco_hi = (K.inc_hi << 1) | (K.inc_lo >> 31);
+          bit1 = fast_disc(F, U, q2 + q3, amp1);
+        }
+      }
+      // ---- decimated sample 1
+      k++;
+      fast_fsm(F, P, S, X, amp_rsrc, bit1, amp1, r1, ph1, k, amp_soff);
+      amp_soff += amp_row_bytes; if (amp_soff == amp_wrap) amp_soff = 0;
+      phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
+
+      if (writeback && valid) {
+        float4 w4 = {xs[0], xs[1], xs[2], xs[3]};
+        *reinterpret_cast<float4 *>(samples + (size_t)row * pitch + t0 + 4u * c) = w4;
+      }
+    }
+  }
+
+  for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
+  {
+#define RSTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)(v)), rs_rsrc, st_voff, (uint32_t)RF_##f * fld, 0)
+#define ISTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(v), is_rsrc, st_voff, (uint32_t)IF_##f * fld, 0)
+    RSTORE(agc_gain, F.g);
+    RSTORE(bp_x1, F.bx1); RSTORE(bp_x2, F.bx2); RSTORE(bp_y1, F.by1); RSTORE(bp_y2, F.by2);
+    RSTORE(li_x1, F.lx1.x); RSTORE(lq_x1, F.lx1.y); RSTORE(li_x2, F.lx2.x); RSTORE(lq_x2, F.lx2.y);
+    RSTORE(li_y1, F.ly.x); RSTORE(lq_y1, F.ly.y); RSTORE(li_y2, F.lv.x); RSTORE(lq_y2, F.lv.y);
+    RSTORE(po_x1, F.px1); RSTORE(po_x2, F.px2); RSTORE(po_y1, F.py); RSTORE(po_y2, F.pv);
+    RSTORE(last_phase, F.last_phase); RSTORE(sil_thr, F.thr);
+    ISTORE(nco_lo, F.nco_lo); ISTORE(nco_hi, F.nco_hi);
+    ISTORE(cad_ctr, F.cad); ISTORE(sil_cnt, F.sil); ISTORE(bit_acc, F.acc); ISTORE(bit_wait, F.wait);
+    ISTORE(bit_reload, F.reload); ISTORE(byte_cur, F.byte_cur); ISTORE(bit_pos, F.bit_pos);
+    ISTORE(started, F.started); ISTORE(matched, F.matched);
+    ISTORE(gsc, k + F.koff);
+    ISTORE(sync_det, F.sync_det); ISTORE(eod_total, F.eod_total);
+    const uint32_t rl = ring_base + k, al = amp_base + k;
+    ISTORE(ring_len, rl < P.ring_cap ? rl : P.ring_cap);
+    ISTORE(amp_len, al < P.amp_cap ? al : P.amp_cap);
+    ISTORE(poly_phase, phase);
+    ISTORE(amp_pos, amp_soff / amp_row_bytes);
+    if (valid) {
+      out_counts[stream] = F.out_cnt;
+      if (eod_counts) eod_counts[stream] = F.eod_cnt;
+    }
+#undef RSTORE
+#undef ISTORE
+  }
+#undef RLOAD
+#undef ILOAD
+#undef CLOAD
+}
+
+size_t demod_fast_lds_bytes(const DemodParams &P) { return sizeof(float4) * 4 * kSlotStride + sizeof(uint32_t) * 64u * P.d; }
+
+// The fast kernel applies to fp32 engines with narrow integer-capacity rings whose streams are in lock
+// step at a pair boundary; n must be a multiple of 16, the buffer 16-B aligned with pitch % 4 == 0.
+bool demod_fast_applicable(int precision, bool uniform_even, const DemodParams &P, const DemodState &S,
+                           const float *samples, size_t pitch) {
+  return precision == 0 && uniform_even && !P.wide && !P.frac && P.d >= 2 && S.trace_stream == 0xFFFFFFFFu &&
+         (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(samples) & 15u) == 0) &&
+         demod_fast_lds_bytes(P) <= 64 * 1024 && (uint64_t)P.amp_cap * P.n_streams * 4u < 0xFFFFFFF0ull;
+}
+hipError_t launch_demod_fast(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+                             size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
+                             uint32_t *eod_counts, hipStream_t stream) {
+  const uint32_t blocks = (P.n_streams + 63u) / 64u;
+  hipLaunchKernelGGL(demod_fast_kernel, dim3(blocks), dim3(64), demod_fast_lds_bytes(P), stream, P, S, samples, n,
+                     pitch, writeback ? 1 : 0, out, out_pitch, out_counts, eod_counts);
+  return hipGetLastError();
+}
+
 size_t demod_lds_bytes(const DemodParams &P) {
   const size_t reg = (P.wide ? sizeof(uint64_t) : sizeof(uint32_t)) * 64u * P.d;
   return sizeof(float4) * kChunks * kSlotStride + reg * (P.frac ? 2u : 1u);
@@ -729,7 +1165,7 @@ size_t demod_lds_bytes(const DemodParams &P) {
 
 // Host-side launcher (called from fsk_api.hip).  uniform_ds: every stream's downsample.counter
 // and ring positions are equal (true unless single streams were reset at odd sample positions).
-hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, const DemodParams &P,
+hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, bool append, const DemodParams &P,
                         const DemodState &S, float *samples, size_t n, size_t pitch, uint8_t *out,
                         size_t out_pitch, uint32_t *out_counts, uint32_t *eod_counts,
                         hipStream_t stream) {
@@ -747,7 +1183,7 @@ hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, const De
   if (f64 == (sizeof(R) == 8) && wide == (sizeof(T) == 8) && frac == F && uniform_ds == U &&       \
       trace == TR)                                                                                 \
     hipLaunchKernelGGL((demod_kernel<R, T, F, U, TR>), g, b, lds_bytes, stream, P, S, samples, n,  \
-                       pitch, vec_ok, wb, out, out_pitch, out_counts, eod_counts);
+                       pitch, vec_ok, wb, append ? 1 : 0, out, out_pitch, out_counts, eod_counts);
   FSK_FOR_ALL_VARIANTS(FSK_LAUNCH)
 #undef FSK_LAUNCH
   return hipGetLastError();

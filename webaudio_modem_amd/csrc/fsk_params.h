@@ -63,6 +63,9 @@ enum CoefField {
   CF_omega,   // 2*pi*centerFreq/sampleRate (fsk.ts:228)
   CF_mark_w,  // 2*pi*markFrequency/sampleRate  (modulator, fsk.ts:404)
   CF_space_w, // 2*pi*spaceFrequency/sampleRate
+  CF_w1_re, CF_w1_im,  // e^{j*k*omega}, k = 1..3: NCO phasors of samples 1..3 of a 4-sample block
+  CF_w2_re, CF_w2_im,  // relative to sample 0 (fast fp32 kernel)
+  CF_w3_re, CF_w3_im,
   CF_COUNT
 };
 
@@ -86,6 +89,9 @@ struct DemodParams {
   uint32_t agc_on;
   double lp_b0, lp_b1, lp_b2, lp_a1, lp_a2;  // butterworthLowpass(baud, sr) (fsk.ts:458-461)
   double agc_attack, agc_release;            // fsk.ts:48-49
+  // the same constants rounded once on the host for the fp32 kernels (a device-side (float) of the
+  // f64 fields gets re-materialised by hipcc with a quarter-rate v_cvt_f32_f64 at every use)
+  float f_lp_b0, f_lp_b0h, f_lp_a2, f_lp_delta, f_agc_att, f_agc_rel;
 };
 
 struct DemodState {
