@@ -44,8 +44,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
-    ap.add_argument("--seconds", type=float, default=1.0, help="audio seconds per stream per step")
+    ap.add_argument("--streams", type=int, default=196608,
+                    help="streams per GPU (>= 64 k; 196 608 = three waves per SIMD, the occupancy the kernel is built for)")
+    ap.add_argument("--seconds", type=float, default=0.5, help="audio seconds per stream per step")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--pitch-pad", type=int, default=0, help="extra floats of row pitch (experiments)")
@@ -146,10 +147,8 @@ def main():
     elapsed = time.perf_counter() - t0
     n_launch, kernel_ms = eng.timing_end()
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from webaudio_modem_amd.sharding import max_over_ranks
+    elapsed = max_over_ranks(elapsed, dist, "cuda")
 
     total_samples = float(S) * N * args.steps * world
     value = total_samples / elapsed / 1e6

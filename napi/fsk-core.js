@@ -1,0 +1,148 @@
+'use strict';
+// FSKCore / FSKBatch: the host side of the MI355X engine in the reference's own language.
+//
+// FSKCore keeps the public surface of the reference class (src/modems/fsk.ts:82-494 on top of
+// src/core.ts:210-289): name, type, configure, getConfig, modulateData, demodulateData, reset,
+// isReady, getSignalQuality, getStatus, on/off/emit with the 'configured' | 'eod' | 'error' events.
+// Every DSP call goes through the N-API addon into libfskhip.so; there is no JavaScript DSP here.
+const path = require('path');
+const addon = require(path.join(__dirname, 'fsk_addon.node'));
+
+const PRECISION_F32 = 0, PRECISION_F64 = 1;
+const DEMOD_WRITEBACK_AGC = 1;
+
+// DEFAULT_FSK_CONFIG (fsk.ts:19-33)
+const DEFAULT_FSK_CONFIG = {
+  sampleRate: 48000, baudRate: 1200, markFrequency: 1650, spaceFrequency: 1850,
+  preamblePattern: [0x55, 0x55], sfdPattern: [0x7E], startBits: 1, stopBits: 1, parity: 'none',
+  syncThreshold: 0.85, agcEnabled: true, preFilterBandwidth: 800, adaptiveThreshold: true
+};
+
+class Event {                       // core.ts:205-207
+  constructor(data = null) { this.data = data; }
+}
+
+class EventEmitter {                // core.ts:210-244
+  constructor() { this.listeners = new Map(); }
+  on(eventName, callback) {
+    if (!this.listeners.has(eventName)) this.listeners.set(eventName, []);
+    this.listeners.get(eventName).push(callback);
+  }
+  off(eventName, callback) {
+    const l = this.listeners.get(eventName);
+    if (l) { const i = l.indexOf(callback); if (i !== -1) l.splice(i, 1); }
+  }
+  emit(eventName, event = new Event()) {
+    const l = this.listeners.get(eventName);
+    if (l) l.slice().forEach((cb) => cb(event));
+  }
+  removeAllListeners(eventName) {
+    if (eventName) this.listeners.delete(eventName); else this.listeners.clear();
+  }
+}
+
+class FSKCore extends EventEmitter {
+  // precision defaults to the fp64 parity path: one stream cannot fill the GPU anyway and fp64 is
+  // op-for-op with the reference's arithmetic.  FSKBatch is the throughput interface.
+  constructor(options = {}) {
+    super();
+    this.name = 'FSK';
+    this.type = 'FSK';
+    this.device = options.device || 0;
+    this.precision = options.precision === undefined ? PRECISION_F64 : options.precision;
+    this.handle = null;
+    this.config = undefined;
+    this.ready = false;
+  }
+
+  configure(config) {               // fsk.ts:133-157
+    if (this.handle) { addon.destroy(this.handle); this.handle = null; }
+    this.config = Object.assign({}, DEFAULT_FSK_CONFIG, config);
+    this.handle = addon.create(this.config, 1, this.device, this.precision);
+    this.ready = true;
+    this.emit('configured');
+  }
+
+  getConfig() { return Object.assign({}, this.config); }
+  isReady() { return this.ready; }
+
+  async demodulateData(samples) {   // fsk.ts:190-222; mutates `samples` when AGC is on (fsk.ts:55)
+    if (!this.ready || !this.config) throw new Error('FSK demodulator not configured');
+    try {
+      const r = addon.demodulate(this.handle, samples, samples.length, samples.length,
+                                 this.config.agcEnabled ? DEMOD_WRITEBACK_AGC : 0);
+      for (let i = 0; i < r.eod[0]; i++) this.emit('eod');
+      return r.out.slice(0, r.counts[0]);
+    } catch (error) {               // fsk.ts:218-221
+      this.emit('error', new Event({ data: error }));
+      return new Uint8Array(0);
+    }
+  }
+
+  async modulateData(data) {        // fsk.ts:377-383
+    if (!this.ready || !this.config) throw new Error('FSK modulator not configured');
+    const bytes = data instanceof Uint8Array ? data : Uint8Array.from(data);
+    const r = addon.modulate(this.handle, bytes.length ? bytes : new Uint8Array(1), Uint32Array.of(bytes.length),
+                             Math.max(1, bytes.length));
+    return r.out.slice(0, r.lens[0]);
+  }
+
+  reset() {                         // fsk.ts:464-469: `ready` stays true
+    if (this.handle) addon.reset(this.handle, 0);
+  }
+
+  getSignalQuality() {              // fsk.ts:471-479: all-zero stub in the reference
+    return { snr: 0, ber: 0, eyeOpening: 0, phaseJitter: 0, frequencyOffset: 0 };
+  }
+
+  getStatus() {                     // fsk.ts:481-493
+    if (!this.handle) {
+      return { ready: this.ready, frameStarted: false, globalSampleCounter: 0, receivedBitsLength: 0,
+               byteBufferLength: 0, demodulationCalls: 0, syncDetections: 0, silenceThreshold: 0.01,
+               totalSamplesProcessed: 0 };
+    }
+    const st = addon.getStatus(this.handle, 0);
+    st.ready = this.ready;
+    return st;
+  }
+
+  close() {
+    if (this.handle) { addon.destroy(this.handle); this.handle = null; }
+    this.ready = false;
+  }
+}
+
+// S independent FSKCore instances in one engine: samples are [S][N] stream-major Float32Array.
+class FSKBatch {
+  constructor(nStreams, configs, options = {}) {
+    this.nStreams = nStreams;
+    this.configs = Array.isArray(configs) ? configs.map((c) => Object.assign({}, DEFAULT_FSK_CONFIG, c))
+                                          : Object.assign({}, DEFAULT_FSK_CONFIG, configs);
+    this.handle = addon.create(this.configs, nStreams, options.device || 0,
+                               options.precision === undefined ? PRECISION_F32 : options.precision);
+  }
+  // returns {bytes: Uint8Array[S], eod: Uint32Array(S)}
+  demodulateData(samples, nPerStream, pitch, writebackAgc) {
+    const r = addon.demodulate(this.handle, samples, nPerStream, pitch || nPerStream, writebackAgc ? DEMOD_WRITEBACK_AGC : 0);
+    const bytes = [];
+    for (let s = 0; s < this.nStreams; s++) bytes.push(r.out.slice(s * r.outPitch, s * r.outPitch + r.counts[s]));
+    return { bytes, eod: r.eod };
+  }
+  // payloads: Uint8Array[S] -> Float32Array[S]
+  modulateData(payloads) {
+    let pitch = 1;
+    payloads.forEach((p) => { pitch = Math.max(pitch, p.length); });
+    const flat = new Uint8Array(pitch * this.nStreams);
+    const lens = new Uint32Array(this.nStreams);
+    payloads.forEach((p, s) => { flat.set(p, s * pitch); lens[s] = p.length; });
+    const r = addon.modulate(this.handle, flat, lens, pitch);
+    const out = [];
+    for (let s = 0; s < this.nStreams; s++) out.push(r.out.slice(s * r.outPitch, s * r.outPitch + r.lens[s]));
+    return out;
+  }
+  reset(stream) { addon.reset(this.handle, stream === undefined ? -1 : stream); }
+  getStatus(stream) { return addon.getStatus(this.handle, stream || 0); }
+  close() { if (this.handle) { addon.destroy(this.handle); this.handle = null; } }
+}
+
+module.exports = { FSKCore, FSKBatch, DEFAULT_FSK_CONFIG, Event, EventEmitter, PRECISION_F32, PRECISION_F64, addon };

@@ -1,0 +1,38 @@
+"""The reference's host language is TypeScript/Node: napi/fsk-core.js keeps FSKCore's public surface and
+calls the HIP engine through the N-API addon.  These tests run the JS suites under `node` (skipped when
+node is absent on the box)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+NODE = shutil.which("node")
+JS = os.path.join(ROOT, "tests", "js", "fsk_core_test.js")
+
+
+def _build():
+    import __graft_entry__ as ge
+    ge.build()
+    addon = os.path.join(ROOT, "napi", "fsk_addon.node")
+    if not os.path.exists(addon):
+        pytest.skip("N-API addon not built (no node headers)")
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_node_host_cpu_side():
+    _build()
+    out = subprocess.run([NODE, JS, "cpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "js cpu tests ok" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_node_host_gpu_roundtrips():
+    _build()
+    out = subprocess.run([NODE, JS, "gpu"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "js gpu tests ok" in out.stdout

@@ -7,6 +7,7 @@ from ._lib import FskHipError, PRECISION_F32, PRECISION_F64, LIB_PATH  # noqa: F
 from .engine import FSKEngine, DEFAULT_FSK_CONFIG, make_config  # noqa: F401
 from .fsk_core import FSKCore, Event, EventEmitter  # noqa: F401
 from .filters import FilterDesign  # noqa: F401
+from . import sharding  # noqa: F401
 
 __all__ = ["FSKEngine", "FSKCore", "FilterDesign", "DEFAULT_FSK_CONFIG", "FskHipError",
            "PRECISION_F32", "PRECISION_F64"]
