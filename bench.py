@@ -44,8 +44,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=196608,
-                    help="streams per GPU (>= 64 k; 196 608 = three waves per SIMD, the occupancy the kernel is built for)")
+    ap.add_argument("--streams", type=int, default=262144,
+                    help="streams per GPU (>= 64 k; 262 144 = four waves per SIMD, the occupancy the kernel is built for)")
     ap.add_argument("--seconds", type=float, default=0.5, help="audio seconds per stream per step")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline leg (0 = skip)")

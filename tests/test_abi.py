@@ -103,3 +103,21 @@ def test_product_never_imports_oracle():
                 with open(os.path.join(dirpath, f), encoding="utf-8") as fh:
                     src = fh.read()
                 assert "oracle" not in src.lower(), os.path.join(dirpath, f)
+
+
+def test_fast_kernel_never_spills():
+    """tools/check_isa.py: the fast demod kernel's asm-issued prefetch is only safe without spills,
+    and its plain variant is built for 4 waves per SIMD (<= 128 VGPRs)."""
+    import shutil
+    import sys
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("hipcc not installed")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    res = check_isa.kernel_resources()
+    fast = {k: v for k, v in res.items() if "demod_fast_kernel" in k}
+    assert len(fast) == 2
+    for name, v in fast.items():
+        assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
+    plain = [v for k, v in fast.items() if "ILb0E" in k][0]
+    assert plain["VGPRs"] <= 128, plain

@@ -333,7 +333,7 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   P.amp_cap = 8 * P.d;
   {
     const double total = (double)P.sample_count;
-    P.matched_min = 0xFFFFFFFFu;
+    P.matched_min = 0xFFFFFFFEu;  // never (0xFFFFFFFF is the kernels' "frame started" marker)
     if (P.sample_count > 0)
       for (uint32_t m = 0; m <= P.sample_count; m++)
         if ((double)m / total > c0.syncThreshold) { P.matched_min = m; break; }

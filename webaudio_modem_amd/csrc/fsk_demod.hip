@@ -47,7 +47,7 @@
 #include "fsk_params.h"
 
 #ifndef FSK_FAST_WAVES
-#define FSK_FAST_WAVES 2
+#define FSK_FAST_WAVES 4
 #endif
 #ifndef FSK_F32_WAVES_PER_SIMD
 #define FSK_F32_WAVES_PER_SIMD 2
@@ -74,8 +74,11 @@ struct Consts<float> {
     // reference's and the /2 boxcar sum IS the average.
     lp_b0 = P.f_lp_b0; lp_b0h = P.f_lp_b0h; lp_a2 = P.f_lp_a2; lp_delta = P.f_lp_delta;
     agc_att = P.f_agc_att; agc_rel = P.f_agc_rel;
+    // ... and that b0/2 is folded into the band-pass gain below (the pre-filter is linear, so its whole
+    // output -- and its y history -- simply carries the factor), which removes one multiply per
+    // sample from the I/Q low-passes
     size_t n = P.n_streams;
-    bp_b0 = (float)S.coef[(size_t)CF_bp_b0 * n + row];
+    bp_b0 = (float)(S.coef[(size_t)CF_bp_b0 * n + row] * (0.5 * P.lp_b0));
     bp_a1 = (float)S.coef[(size_t)CF_bp_a1 * n + row];
     bp_a2 = (float)S.coef[(size_t)CF_bp_a2 * n + row];
     uint64_t inc = S.nco_inc[row];
@@ -210,9 +213,11 @@ __device__ inline void nco_reset(Lane<double> &L) { L.nco_phase = 0.0; }
 // z = 1 (cutoff = baud << fs), where DF-I in f32 amplifies both coefficient and state rounding by
 // 1/|A(1)| ~ 700 (300 baud); here the rounding of y is fed back only through delta ~ 1.5e-3.
 // State: y1 holds y[n-1], y2 holds v.
+// GAIN = false is the variant whose input already carries the b0 gain (the I/Q filters).
+template <bool GAIN = true>
 __device__ inline float lp32(float b0, float a2, float delta, float &x1, float &x2, float &y, float &v, float x) {
   float t = __builtin_fmaf(2.0f, x1, x) + x2;
-  float u = __builtin_fmaf(-delta, y, b0 * t);
+  float u = GAIN ? __builtin_fmaf(-delta, y, b0 * t) : __builtin_fmaf(-delta, y, t);
   v = __builtin_fmaf(a2, v, u);
   y = y + v;
   x2 = x1; x1 = x;
@@ -271,8 +276,8 @@ __device__ inline void mix_lp(Lane<float> &L, const Consts<float> &C, float y, f
   uint32_t lo = L.nco_lo + C.inc_lo;
   L.nco_hi = L.nco_hi + C.inc_hi + (lo < L.nco_lo ? 1u : 0u);
   L.nco_lo = lo;
-  fi = lp32(C.lp_b0h, C.lp_a2, C.lp_delta, L.li_x1, L.li_x2, L.li_y1, L.li_y2, y * c);
-  fq = lp32(C.lp_b0h, C.lp_a2, C.lp_delta, L.lq_x1, L.lq_x2, L.lq_y1, L.lq_y2, y * s);
+  fi = lp32<false>(0.0f, C.lp_a2, C.lp_delta, L.li_x1, L.li_x2, L.li_y1, L.li_y2, y * c);
+  fq = lp32<false>(0.0f, C.lp_a2, C.lp_delta, L.lq_x1, L.lq_x2, L.lq_y1, L.lq_y2, y * s);
 }
 
 __device__ inline bool discriminate(Lane<float> &L, const Consts<float> &C, float sum_i, float sum_q, float &amp,
@@ -731,38 +736,57 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
 //  * polyphase registers of both decimated steps are fetched from LDS at block start.
 // ================================================================================================
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 static constexpr int kFastTile = 16;
+static constexpr uint32_t kStarted = 0xFFFFFFFFu;  // thr_eff while a frame is started (matched_min is <= 0xFFFFFFFE)
 
 __device__ inline f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ inline f2 bc2(float v) { return (f2){v, v}; }
 
+// Registers of one stream.  Everything that only rare paths touch (eod / sync counters,
+// globalSampleCounter, ring lengths) stays in the state arrays in HBM and is read-modify-written
+// there: the kernel is capped at 128 VGPRs (4 waves per SIMD).
 struct FastLane {
   float g, bx1, bx2, by1, by2;       // AGC gain, pre-filter history
   f2 lx1, lx2, ly, lv;               // I/Q low-pass (x = I, y = Q), velocity form, half scale
   float px1, px2, py, pv;            // post filter
   float last_phase, thr;
-  uint32_t nco_lo, nco_hi, cad, sil, acc, wait, reload, byte_cur, bit_pos, started, thr_eff, matched;
-  uint32_t koff;                     // globalSampleCounter = k + koff (mod 2^32)
-  uint32_t out_cnt, eod_cnt, sync_det, eod_total;
+  uint32_t nco_lo, nco_hi, cad, sil, acc, wait, reload, byte_cur, bit_pos;
+  uint32_t thr_eff;                  // matched_min while searching, kStarted while a frame is started
+  uint32_t matched, out_cnt;
 };
 struct FastConst {                   // per-stream constants (VGPRs)
   float bp_b0, bp_a1, bp_a2;
-  f2 w1, w2, w3;
-  uint32_t inc_lo, inc_hi, inc4_lo, inc4_hi;
+  f2 w1;                             // e^{j omega}: NCO phasor of the second sample of a pair
+  uint32_t inc2_lo, inc2_hi;         // two NCO steps
 };
 struct FastUni {                     // wave-uniform constants
   float lp_b0, lp_a2, lp_delta, agc_att, agc_rel;   // scalar uses (SGPR operands)
-  f2 a2v, ndv, b0hv;                 // (a2,a2), (-delta,-delta), (b0/2,b0/2): packed-math operands, pinned in VGPRs
+  f2 a2v, ndv;                       // (a2,a2), (-delta,-delta): packed-math operands, pinned in VGPRs
+};
+struct FastMem {                     // how rare paths reach the per-stream state in HBM
+  __amdgpu_buffer_rsrc_t is_rsrc;    // integer state [IF_COUNT][n_streams]
+  uint32_t fld;                      // bytes per field
+  uint32_t voff;                     // row*4, or out of range for lanes beyond the batch
 };
 
-__device__ inline void fast_reset(FastLane &F, uint32_t k, uint32_t matched_min) {  // resetState()
+__device__ inline uint32_t ist_load(const FastMem &M, uint32_t field) {
+  return __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, M.voff, field * M.fld, 0);
+}
+__device__ inline void ist_store(const FastMem &M, uint32_t field, uint32_t v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, M.is_rsrc, M.voff, field * M.fld, 0);
+}
+
+// resetState() fsk.ts:175-188.  globalSampleCounter = k + koff with koff kept in the gsc state word.
+__device__ inline void fast_reset(FastLane &F, const FastMem &M, uint32_t k, uint32_t matched_min) {
   F.nco_lo = 0; F.nco_hi = 0;
   F.last_phase = 0.0f;
-  F.koff = 0u - k;  // globalSampleCounter = 0
+  ist_store(M, IF_gsc, 0u - k);
   F.cad = 0;
   F.acc = 0; F.wait = kBigWait; F.reload = 0;
   F.byte_cur = 0; F.bit_pos = 0;
-  F.started = 0; F.thr_eff = matched_min;
+  F.thr_eff = matched_min;
   F.sil = 0;
   F.lx1 = bc2(0.f); F.lx2 = bc2(0.f); F.ly = bc2(0.f); F.lv = bc2(0.f);
   F.px1 = 0.f; F.px2 = 0.f; F.py = 0.f; F.pv = 0.f;
@@ -771,7 +795,7 @@ __device__ inline void fast_reset(FastLane &F, uint32_t k, uint32_t matched_min)
 // I/Q low-pass step on the mixed sample m = (y*cos, y*sin); returns the (half-scale) outputs
 __device__ inline f2 fast_lp2(FastLane &F, const FastUni &U, f2 m) {
   f2 t = fma2(bc2(2.0f), F.lx1, m) + F.lx2;
-  f2 u = fma2(U.ndv, F.ly, U.b0hv * t);
+  f2 u = fma2(U.ndv, F.ly, t);       // the b0/2 gain rides on the pre-filter output
   F.lv = fma2(U.a2v, F.lv, u);
   F.ly = F.ly + F.lv;
   F.lx2 = F.lx1; F.lx1 = m;
@@ -795,30 +819,21 @@ __device__ inline bool fast_disc(FastLane &F, const FastUni &U, f2 sum, float &a
   return f > 0.0f;
 }
 
-struct FastCtx {
-  uint32_t *poly;            // LDS polyphase registers [d][64]
-  uint32_t lane, row, need, amp_base;
-  bool valid;
-  uint8_t *out_row;
-  uint32_t out_pitch;
-  uint32_t amp_voff;         // row*4, or out of range for lanes beyond the batch
-};
-
 // processDownsampledBit (fsk.ts:278-344); k = pushes of this launch including this one (SGPR),
 // phase = push slot (SGPR), amp_soff = byte offset of the amplitude-ring row (SGPR).
-// Returns true for lanes on which resetState() ran.
-__device__ inline bool fast_fsm(FastLane &F, const DemodParams &P, const DemodState &S, const FastCtx &X,
-                                __amdgpu_buffer_rsrc_t amp_rsrc, bool bitb, float amp, uint32_t r_old,
+__device__ inline void fast_fsm(FastLane &F, const DemodParams &P, const DemodState &S, const FastMem &M,
+                                uint32_t *poly, uint32_t lane, __amdgpu_buffer_rsrc_t amp_rsrc, uint8_t *out,
+                                uint32_t out_pitch, uint32_t *eod_counts, bool bitb, float amp, uint32_t r_old,
                                 uint32_t phase, uint32_t k, uint32_t amp_soff) {
   const uint32_t qn = ~(uint32_t)P.pat_q, mask = (uint32_t)P.pat_mask;
   const uint32_t bit = bitb ? 1u : 0u;
   // syncSamplesBuffer.put(bit)
   const uint32_t r = (r_old << 1) | bit;
-  X.poly[phase * 64u + X.lane] = r;
+  poly[phase * 64u + lane] = r;
   F.matched += (uint32_t)__builtin_popcount((r ^ qn) & mask);
   F.matched -= (uint32_t)__builtin_popcount((r ^ (qn << 1)) & (mask << 1));
   // syncAmplitudeBuffer.put(amp)
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, X.amp_voff, amp_soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, M.voff, amp_soff, 0);
   // globalSampleCounter % round(dsSPB/4)
   const uint32_t c1 = F.cad + 1;
   const bool hit = c1 == P.cadence;
@@ -831,37 +846,43 @@ __device__ inline bool fast_fsm(FastLane &F, const DemodParams &P, const DemodSt
   F.wait -= 1u;
   const bool decide = (int32_t)F.wait <= 0;
   const bool cand = hit & (F.matched >= F.thr_eff);
-  bool did_reset = false;
 
   if (__builtin_amdgcn_ballot_w64(eod | cand)) {
     if (eod) {                                                   // fsk.ts:288-291
-      F.eod_cnt++; F.eod_total++;
-      fast_reset(F, k, P.matched_min);
-      did_reset = true;
+      ist_store(M, IF_eod_total, ist_load(M, IF_eod_total) + 1u);
+      if (eod_counts && M.voff < 0xFFFFFFF0u) eod_counts[M.voff >> 2] += 1u;
+      fast_reset(F, M, k, P.matched_min);
     }
-    const bool sync_now = cand & !eod & (k >= X.need);           // fsk.ts:302, 315
+    // ring length >= preamble window? (fsk.ts:302); ring_len / amp_len in HBM hold the launch-start values
+    bool sync_now = false;
+    uint32_t slen = 0;
+    if (cand & !eod) {
+      const uint32_t ring_base = ist_load(M, IF_ring_len);
+      sync_now = ring_base + k >= P.sample_count;
+      const uint32_t pushes = ist_load(M, IF_amp_len) + k;
+      slen = pushes < P.amp_cap ? pushes : P.amp_cap;
+    }
     uint64_t m = __builtin_amdgcn_ballot_w64(sync_now);
     if (m) {
-      if (sync_now) {
-        F.started = 1; F.thr_eff = 0xFFFFFFFFu;
+      if (sync_now) {                                            // fsk.ts:315-319
+        F.thr_eff = kStarted;
         F.byte_cur = 0; F.bit_pos = 0;
         F.acc = 0; F.wait = 0; F.reload = 0;
-        F.sync_det++;
+        ist_store(M, IF_sync_det, ist_load(M, IF_sync_det) + 1u);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // ring stores have reached L2
-      const uint32_t pushes = X.amp_base + k;
-      const uint32_t slen = pushes < P.amp_cap ? pushes : P.amp_cap;
       while (m) {
         const int src = __builtin_ctzll(m);
         m &= m - 1;
-        const uint32_t srow = (uint32_t)__builtin_amdgcn_readlane((int)X.row, src);
+        const uint32_t srow = (uint32_t)__builtin_amdgcn_readlane((int)M.voff, src) >> 2;
+        const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slen, src);
         double part = 0.0;
-        for (uint32_t i = X.lane; i < slen; i += 64) {
+        for (uint32_t i = lane; i < sl; i += 64) {
           const float *p = S.amp_ring + (size_t)i * P.n_streams + srow;
           part += (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const double sum = wave_sum(part);
-        if ((int)X.lane == src) F.thr = (float)((sum / (double)slen) * 0.1);   // fsk.ts:321-326
+        if ((int)lane == src) F.thr = (float)((sum / (double)sl) * 0.1);   // fsk.ts:321-326
       }
     }
   }
@@ -870,7 +891,7 @@ __device__ inline bool fast_fsm(FastLane &F, const DemodParams &P, const DemodSt
   if (__builtin_amdgcn_ballot_w64(dec_now)) {
     bool bad_start = false, emit = false, bad_stop = false, stale = false;
     if (dec_now) {
-      if (F.started) {
+      if (F.thr_eff == kStarted) {
         const uint32_t cnt = F.reload - F.wait;                  // bitAccumCount
         const uint32_t b = (2u * F.acc > cnt) ? 1u : 0u;         // fsk.ts:336
         F.acc = 0;
@@ -888,27 +909,30 @@ __device__ inline bool fast_fsm(FastLane &F, const DemodParams &P, const DemodSt
       }
     }
     if (__builtin_amdgcn_ballot_w64(bad_start | bad_stop | stale)) {
-      if (bad_start) { fast_reset(F, k, P.matched_min); did_reset = true; }       // fsk.ts:352-355
-      if (bad_stop) { F.started = 0; F.thr_eff = P.matched_min; F.wait = kBigWait; F.bit_pos = P.stop_pos; }
+      if (bad_start) fast_reset(F, M, k, P.matched_min);                          // fsk.ts:352-355
+      if (bad_stop) { F.thr_eff = P.matched_min; F.wait = kBigWait; F.bit_pos = P.stop_pos; }  // fsk.ts:363-366
       if (stale) F.wait = kBigWait;
     }
     if (__builtin_amdgcn_ballot_w64(emit)) {
       if (emit) {                                                // fsk.ts:367-368
-        if (X.valid && F.out_cnt < X.out_pitch) X.out_row[F.out_cnt] = (uint8_t)F.byte_cur;
+        if (M.voff < 0xFFFFFFF0u && F.out_cnt < out_pitch)
+          out[(size_t)(M.voff >> 2) * out_pitch + F.out_cnt] = (uint8_t)F.byte_cur;
         F.out_cnt++;
         F.byte_cur = 0;
       }
     }
   }
-  return did_reset;
 }
 
-__global__ __launch_bounds__(64, FSK_FAST_WAVES) void demod_fast_kernel(
-    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch, int writeback,
+// WB: also write the AGC-scaled samples back (fsk.ts:55); that variant keeps four more values live per
+// chunk and is built for 3 waves/SIMD, the plain one for FSK_FAST_WAVES (4: 128 VGPRs).
+template <bool WB>
+__global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kernel(
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
     uint32_t *__restrict__ eod_counts) {
   extern __shared__ float4 lds[];
-  float4 *stage = lds;                                       // [4 chunks][kSlotStride]
+  v4f *stage = reinterpret_cast<v4f *>(lds);                 // [4 chunks][kSlotStride]
   uint32_t *poly = (uint32_t *)(lds + 4 * kSlotStride);      // [d][64]
   uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
 
@@ -921,13 +945,15 @@ __global__ __launch_bounds__(64, FSK_FAST_WAVES) void demod_fast_kernel(
   // per field alive across the whole sample loop for the stores at the end (~90 VGPRs).
   const uint32_t fld = P.n_streams * 4u;  // bytes per state field
   const __amdgpu_buffer_rsrc_t rs_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.rs, 0, (int)(fld * RF_COUNT), 0x00020000);
-  const __amdgpu_buffer_rsrc_t is_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.is, 0, (int)(fld * IF_COUNT), 0x00020000);
   const __amdgpu_buffer_rsrc_t cf_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)S.coef, 0, (int)(2u * fld * CF_COUNT), 0x00020000);
+  FastMem M;
+  M.is_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.is, 0, (int)(fld * IF_COUNT), 0x00020000);
+  M.fld = fld;
+  M.voff = valid ? row * 4u : 0xFFFFFFF0u;  // stores of lanes beyond the batch are dropped by the bounds check
   const uint32_t row4 = row * 4u;
-  const uint32_t st_voff = valid ? row4 : 0xFFFFFFF0u;  // stores of lanes beyond the batch are dropped
 #define RLOAD(f) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rsrc, row4, (uint32_t)RF_##f * fld, 0))
-#define ILOAD(f) __builtin_amdgcn_raw_buffer_load_b32(is_rsrc, row4, (uint32_t)IF_##f * fld, 0)
+#define ILOAD(f) __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, row4, (uint32_t)IF_##f * fld, 0)
 #define CLOAD(f) ((float)__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cf_rsrc, row4 * 2u, (uint32_t)(f) * fld * 2u, 0)))
 
   FastLane F;
@@ -940,168 +966,154 @@ __global__ __launch_bounds__(64, FSK_FAST_WAVES) void demod_fast_kernel(
   F.nco_lo = ILOAD(nco_lo); F.nco_hi = ILOAD(nco_hi);
   F.cad = ILOAD(cad_ctr); F.sil = ILOAD(sil_cnt); F.acc = ILOAD(bit_acc); F.wait = ILOAD(bit_wait);
   F.reload = ILOAD(bit_reload); F.byte_cur = ILOAD(byte_cur); F.bit_pos = ILOAD(bit_pos);
-  F.started = ILOAD(started); F.matched = ILOAD(matched);
-  F.thr_eff = F.started ? 0xFFFFFFFFu : P.matched_min;
-  F.koff = ILOAD(gsc);
-  F.sync_det = ILOAD(sync_det); F.eod_total = ILOAD(eod_total);
-  F.out_cnt = 0; F.eod_cnt = 0;
+  F.matched = ILOAD(matched);
+  F.thr_eff = ILOAD(started) ? kStarted : P.matched_min;
+  F.out_cnt = 0;
+  if (valid && eod_counts) eod_counts[stream] = 0;  // incremented in memory by the (rare) EOD path
 
   FastConst K;
-  K.bp_b0 = CLOAD(CF_bp_b0); K.bp_a1 = CLOAD(CF_bp_a1); K.bp_a2 = CLOAD(CF_bp_a2);
+  K.bp_b0 = (float)(__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cf_rsrc, row4 * 2u, (uint32_t)CF_bp_b0 * fld * 2u, 0)) * (0.5 * P.lp_b0));
+  K.bp_a1 = CLOAD(CF_bp_a1); K.bp_a2 = CLOAD(CF_bp_a2);
   K.w1 = (f2){CLOAD(CF_w1_re), CLOAD(CF_w1_im)};
-  K.w2 = (f2){CLOAD(CF_w2_re), CLOAD(CF_w2_im)};
-  K.w3 = (f2){CLOAD(CF_w3_re), CLOAD(CF_w3_im)};
   {
     const uint64_t inc = S.nco_inc[row];
-    K.inc_lo = (uint32_t)inc; K.inc_hi = (uint32_t)(inc >> 32);
-    K.inc4_lo = (uint32_t)(inc << 2); K.inc4_hi = (uint32_t)((inc << 2) >> 32);
+    K.inc2_lo = (uint32_t)(inc << 1); K.inc2_hi = (uint32_t)((inc << 1) >> 32);
   }
   FastUni U;
   U.lp_b0 = P.f_lp_b0; U.lp_a2 = P.f_lp_a2; U.lp_delta = P.f_lp_delta;
   U.agc_att = P.f_agc_att; U.agc_rel = P.f_agc_rel;
-  U.a2v = bc2(P.f_lp_a2); U.ndv = bc2(-P.f_lp_delta); U.b0hv = bc2(P.f_lp_b0h);
+  U.a2v = bc2(P.f_lp_a2); U.ndv = bc2(-P.f_lp_delta);
   // opaque VGPR pairs: otherwise hipcc parks these uniform values in scratch and reloads them (a
   // VMEM op, hence a vmcnt wait behind the tile prefetch) at the top of every tile
-  asm volatile("" : "+v"(U.a2v), "+v"(U.ndv), "+v"(U.b0hv));
+  asm volatile("" : "+v"(U.a2v), "+v"(U.ndv));
 
   for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
 
   // wave-uniform ring bookkeeping (SGPRs)
   uint32_t phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)ILOAD(poly_phase));
-  uint32_t amp_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)ILOAD(amp_pos));
-  const uint32_t ring_base = ILOAD(ring_len), amp_base = ILOAD(amp_len);
+  const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ILOAD(amp_pos));
   uint32_t k = 0;
   const uint32_t amp_row_bytes = P.n_streams * 4u;
-  uint32_t amp_soff = amp_pos * amp_row_bytes;
+  uint32_t amp_soff = amp_pos0 * amp_row_bytes;
   const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
-
-  FastCtx X;
-  X.poly = poly; X.lane = lane; X.row = row; X.valid = valid;
-  X.need = ring_base >= P.sample_count ? 0u : P.sample_count - ring_base;
-  X.amp_base = amp_base;
-  X.out_row = out + (size_t)row * out_pitch;
-  X.out_pitch = (uint32_t)out_pitch;
   const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
-  X.amp_voff = valid ? row * 4u : 0xFFFFFFF0u;  // out of range: the store is dropped by the bounds check
 
-  // tile prefetch: 4 loads of 16 rows x 64 B; lane -> (row 16*i + lane/4, chunk lane%4).  Named
-  // scalars and an unconditional (clamped) prefetch: arrays / conditional definitions end up in scratch.
+  // Tile prefetch: 4 loads of 16 rows x 64 B; lane -> (row 16*i + lane/4, chunk lane%4), through a per-wave
+  // buffer descriptor over this wave's 64 rows (rows beyond the batch read as 0 via the bounds check, so
+  // one VGPR offset serves all four loads).  Inline asm on purpose: vmcnt counts loads AND stores in issue
+  // order and hipcc cannot count the stores this loop issues conditionally, so with compiler-visible loads
+  // it waits vmcnt(0) at the top of every tile -- i.e. for the amplitude-ring stores issued a few hundred
+  // cycles earlier (~1-2 us each).  With asm loads the wait is ours: each tile issues at least 8 VMEM ops
+  // after its prefetch (the unconditional ring stores), so vmcnt(8) retires exactly the loads; extra
+  // conditional stores only make the wait more conservative, never unsafe.
   const uint32_t sub_row = lane >> 2, chunk = lane & 3;
-  auto row_ptr = [&](uint32_t i) {
-    uint32_t r = blockIdx.x * 64u + 16u * i + sub_row;
-    r = r < P.n_streams ? r : P.n_streams - 1;
-    return samples + (size_t)r * pitch + 4u * chunk;
-  };
-  const float *src0 = row_ptr(0), *src1 = row_ptr(1), *src2 = row_ptr(2), *src3 = row_ptr(3);
-  // The prefetch loads are inline asm on purpose.  vmcnt counts loads AND stores in issue order, and
-  // hipcc cannot count the stores this loop issues conditionally, so with compiler-visible loads it
-  // waits vmcnt(0) at the top of every tile -- i.e. for the amplitude-ring stores issued a few hundred
-  // cycles earlier (~1-2 us each).  With asm loads the wait is ours: each tile issues at least
-  // kStoresPerTile VMEM ops after its prefetch (the 8 unconditional ring stores), so vmcnt(8) retires
-  // exactly the loads; extra conditional stores only make the wait more conservative, never unsafe.
-  typedef float v4f __attribute__((ext_vector_type(4)));
+  const uint32_t rows_here = P.n_streams - blockIdx.x * 64u < 64u ? P.n_streams - blockIdx.x * 64u : 64u;
+  v4i in_rsrc;
+  {
+    const uint64_t base = reinterpret_cast<uint64_t>(samples + (size_t)blockIdx.x * 64u * pitch);
+    in_rsrc.x = (int)(uint32_t)base;
+    in_rsrc.y = (int)(uint32_t)(base >> 32);          // stride 0
+    in_rsrc.z = (int)(uint32_t)(rows_here * pitch * 4u);
+    in_rsrc.w = 0x00020000;
+  }
+  const uint32_t in_voff = (uint32_t)((sub_row * pitch + 4u * chunk) * 4u);
+  const uint32_t in_row16 = (uint32_t)(16u * pitch * 4u);   // byte step between the four loads
   v4f pre0, pre1, pre2, pre3;
-#define FSK_GLOAD4(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
-  FSK_GLOAD4(pre0, src0); FSK_GLOAD4(pre1, src1); FSK_GLOAD4(pre2, src2); FSK_GLOAD4(pre3, src3);
+#define FSK_BLOAD4(dst, soff) \
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(in_voff), "s"(in_rsrc), "s"(soff) : "memory")
+  {
+    const uint32_t s0 = 0u, s1 = in_row16, s2 = 2u * in_row16, s3 = 3u * in_row16;
+    FSK_BLOAD4(pre0, s0); FSK_BLOAD4(pre1, s1); FSK_BLOAD4(pre2, s2); FSK_BLOAD4(pre3, s3);
+  }
   // everything loaded so far (state, constants, first tile) is complete before the loop; the builtin form
   // also tells hipcc's own scoreboard, so it needs no vmcnt wait inside the loop
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre0), "+v"(pre1), "+v"(pre2), "+v"(pre3) : : "memory");
   const uint32_t st_slot = chunk * kSlotStride + sub_row;
-  v4f *stage_v = reinterpret_cast<v4f *>(stage);
 
   for (size_t t0 = 0; t0 < n; t0 += kFastTile) {
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(8)" : "+v"(pre0), "+v"(pre1), "+v"(pre2), "+v"(pre3) : : "memory");
-    stage_v[st_slot] = pre0;
-    stage_v[st_slot + 16] = pre1;
-    stage_v[st_slot + 32] = pre2;
-    stage_v[st_slot + 48] = pre3;
+    stage[st_slot] = pre0;
+    stage[st_slot + 16] = pre1;
+    stage[st_slot + 32] = pre2;
+    stage[st_slot + 48] = pre3;
     __syncthreads();
     {
       // next tile (the last iteration re-reads its own tile: always in bounds, never used)
-      const size_t tn = t0 + kFastTile < n ? t0 + kFastTile : t0;
-      FSK_GLOAD4(pre0, src0 + tn); FSK_GLOAD4(pre1, src1 + tn); FSK_GLOAD4(pre2, src2 + tn); FSK_GLOAD4(pre3, src3 + tn);
+      const uint32_t tn = (uint32_t)((t0 + kFastTile < n ? t0 + kFastTile : t0) * 4u);
+      const uint32_t s0 = tn, s1 = tn + in_row16, s2 = tn + 2u * in_row16, s3 = tn + 3u * in_row16;
+      FSK_BLOAD4(pre0, s0); FSK_BLOAD4(pre1, s1); FSK_BLOAD4(pre2, s2); FSK_BLOAD4(pre3, s3);
     }
 
-    float4 xq = stage[lane];
 #pragma unroll 1
     for (uint32_t c = 0; c < 4; c++) {
-      const float4 x4 = xq;
-      if (c < 3) xq = stage[(c + 1) * kSlotStride + lane];
-      // polyphase registers of this block's two decimated steps (d >= 2: distinct slots)
+      const v4f x4 = stage[c * kSlotStride + lane];
+      // polyphase registers of this chunk's two decimated steps (d >= 2: distinct slots)
       const uint32_t ph0 = phase, ph1 = (phase + 1 == P.d) ? 0u : phase + 1;
       const uint32_t r0 = poly[ph0 * 64u + lane];
       const uint32_t r1 = poly[ph1 * 64u + lane];
-
-      // ---- AGC + pre-filter, four samples (fsk.ts:52-76, filters.ts:47-87)
+      // two samples at a time: front ends of a decimator pair, discriminator, state machine.  (A 4-sample
+      // region would save ~1.5 instructions/sample on the NCO but costs ~40 VGPRs and a speculative
+      // recompute path; at 4 waves/SIMD the pair form is faster.)
       const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
-      float xs[4], y[4];
+      float xs[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        xs[j] = xin[j] * F.g;
-        const float level = __builtin_fabsf(xs[j]);
-        const float t = __builtin_fmaf(0.5f, __builtin_amdgcn_rcpf(level), -F.g);
-        const float rate = level > 0.5f ? U.agc_att : U.agc_rel;
-        float g = __builtin_fmaf(t, rate, F.g);
-        g = level > 0.0f ? g : F.g;
-        F.g = __builtin_amdgcn_fmed3f(g, 0.1f, 10.0f);
-        float v = K.bp_b0 * (xs[j] - F.bx2);
-        v = __builtin_fmaf(-K.bp_a2, F.by2, v);
-        v = __builtin_fmaf(-K.bp_a1, F.by1, v);
-        F.bx2 = F.bx1; F.bx1 = xs[j];
-        F.by2 = F.by1; F.by1 = v;
-        y[j] = v;
-      }
-      // ---- NCO phasors of the block (fsk.ts:228-232)
-      const float turns = (float)F.nco_hi * 2.3283064365386963e-10f;
-      const f2 z0 = (f2){__builtin_amdgcn_cosf(turns), __builtin_amdgcn_sinf(turns)};
-      const f2 z1 = cmul(z0, K.w1), z2 = cmul(z0, K.w2), z3 = cmul(z0, K.w3);
-      {
-        const uint32_t lo = F.nco_lo + K.inc4_lo;
-        F.nco_hi = F.nco_hi + K.inc4_hi + (lo < F.nco_lo ? 1u : 0u);
-        F.nco_lo = lo;
-      }
-      // ---- mix + I/Q low-pass + /2 boxcar (fsk.ts:229-248)
-      const f2 o0 = fast_lp2(F, U, bc2(y[0]) * z0);
-      const f2 o1 = fast_lp2(F, U, bc2(y[1]) * z1);
-      const f2 o2 = fast_lp2(F, U, bc2(y[2]) * z2);
-      const f2 o3 = fast_lp2(F, U, bc2(y[3]) * z3);
-      float amp0, amp1;
-      const bool bit0 = fast_disc(F, U, o0 + o1, amp0);
-      bool bit1 = fast_disc(F, U, o2 + o3, amp1);
-
-      // ---- frame state machine, decimated sample 0 of the block
-      k++;
-      const bool rst = fast_fsm(F, P, S, X, amp_rsrc, bit0, amp0, r0, ph0, k, amp_soff);
-      amp_soff += amp_row_bytes; if (amp_soff == amp_wrap) amp_soff = 0;
-      if (__builtin_amdgcn_ballot_w64(rst)) {
-        if (rst) {
-          // resetState() ran after sample 1: samples 2,3 restart from the zeroed NCO / filters
-          // (phasors of NCO steps 0 and 1 are (1,0) and w1)
-          const f2 q2 = fast_lp2(F, U, (f2){y[2], 0.0f});
-          const f2 q3 = fast_lp2(F, U, bc2(y[3]) * K.w1);
-          F.nco_lo = K.inc_lo << 1; F.nco_hi = (K.inc_hi << 1) | (K.inc_lo >> 31);
-          bit1 = fast_disc(F, U, q2 + q3, amp1);
+      for (int h = 0; h < 2; h++) {
+        float y[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          // AGC (fsk.ts:52-76), branch-free; exact zero holds the gain
+          const float xv = xin[2 * h + j] * F.g;
+          xs[2 * h + j] = xv;
+          const float level = __builtin_fabsf(xv);
+          const float t = __builtin_fmaf(0.5f, __builtin_amdgcn_rcpf(level), -F.g);
+          const float rate = level > 0.5f ? U.agc_att : U.agc_rel;
+          float g = __builtin_fmaf(t, rate, F.g);
+          g = level > 0.0f ? g : F.g;
+          F.g = __builtin_amdgcn_fmed3f(g, 0.1f, 10.0f);
+          // pre-filter (filters.ts:47-87): y = b0*(x - x2) - a2*y2 - a1*y1
+          float v = K.bp_b0 * (xv - F.bx2);
+          v = __builtin_fmaf(-K.bp_a2, F.by2, v);
+          v = __builtin_fmaf(-K.bp_a1, F.by1, v);
+          F.bx2 = F.bx1; F.bx1 = xv;
+          F.by2 = F.by1; F.by1 = v;
+          y[j] = v;
         }
+        // NCO (fsk.ts:228-232): first sample from the exact 64-bit turn accumulator, second = first * e^{j omega}
+        const float turns = (float)F.nco_hi * 2.3283064365386963e-10f;
+        const f2 z0 = (f2){__builtin_amdgcn_cosf(turns), __builtin_amdgcn_sinf(turns)};
+        const f2 z1 = cmul(z0, K.w1);
+        {
+          const uint32_t lo = F.nco_lo + K.inc2_lo;
+          F.nco_hi = F.nco_hi + K.inc2_hi + (lo < F.nco_lo ? 1u : 0u);
+          F.nco_lo = lo;
+        }
+        // mix + I/Q low-pass + /2 boxcar (fsk.ts:229-248), discriminator (fsk.ts:251-264)
+        const f2 o0 = fast_lp2(F, U, bc2(y[0]) * z0);
+        const f2 o1 = fast_lp2(F, U, bc2(y[1]) * z1);
+        float amp;
+        const bool bit = fast_disc(F, U, o0 + o1, amp);
+        k++;
+        fast_fsm(F, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, bit, amp, h ? r1 : r0,
+                 h ? ph1 : ph0, k, amp_soff);
+        amp_soff += amp_row_bytes; if (amp_soff == amp_wrap) amp_soff = 0;
       }
-      // ---- decimated sample 1
-      k++;
-      fast_fsm(F, P, S, X, amp_rsrc, bit1, amp1, r1, ph1, k, amp_soff);
-      amp_soff += amp_row_bytes; if (amp_soff == amp_wrap) amp_soff = 0;
       phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
 
-      if (writeback && valid) {
-        float4 w4 = {xs[0], xs[1], xs[2], xs[3]};
-        *reinterpret_cast<float4 *>(samples + (size_t)row * pitch + t0 + 4u * c) = w4;
+      if (WB) {
+        if (valid) {
+          const v4f w4 = {xs[0], xs[1], xs[2], xs[3]};
+          *reinterpret_cast<v4f *>(samples + (size_t)row * pitch + t0 + 4u * c) = w4;
+        }
       }
     }
   }
 
   for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
   {
-#define RSTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)(v)), rs_rsrc, st_voff, (uint32_t)RF_##f * fld, 0)
-#define ISTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(v), is_rsrc, st_voff, (uint32_t)IF_##f * fld, 0)
+#define RSTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)(v)), rs_rsrc, M.voff, (uint32_t)RF_##f * fld, 0)
+#define ISTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(v), M.is_rsrc, M.voff, (uint32_t)IF_##f * fld, 0)
     RSTORE(agc_gain, F.g);
     RSTORE(bp_x1, F.bx1); RSTORE(bp_x2, F.bx2); RSTORE(bp_y1, F.by1); RSTORE(bp_y2, F.by2);
     RSTORE(li_x1, F.lx1.x); RSTORE(lq_x1, F.lx1.y); RSTORE(li_x2, F.lx2.x); RSTORE(lq_x2, F.lx2.y);
@@ -1111,24 +1123,21 @@ __global__ __launch_bounds__(64, FSK_FAST_WAVES) void demod_fast_kernel(
     ISTORE(nco_lo, F.nco_lo); ISTORE(nco_hi, F.nco_hi);
     ISTORE(cad_ctr, F.cad); ISTORE(sil_cnt, F.sil); ISTORE(bit_acc, F.acc); ISTORE(bit_wait, F.wait);
     ISTORE(bit_reload, F.reload); ISTORE(byte_cur, F.byte_cur); ISTORE(bit_pos, F.bit_pos);
-    ISTORE(started, F.started); ISTORE(matched, F.matched);
-    ISTORE(gsc, k + F.koff);
-    ISTORE(sync_det, F.sync_det); ISTORE(eod_total, F.eod_total);
-    const uint32_t rl = ring_base + k, al = amp_base + k;
+    ISTORE(started, F.thr_eff == kStarted ? 1u : 0u); ISTORE(matched, F.matched);
+    ISTORE(gsc, k + ILOAD(gsc));              // the gsc word held koff during the launch
+    const uint32_t rl = ILOAD(ring_len) + k, al = ILOAD(amp_len) + k;
     ISTORE(ring_len, rl < P.ring_cap ? rl : P.ring_cap);
     ISTORE(amp_len, al < P.amp_cap ? al : P.amp_cap);
     ISTORE(poly_phase, phase);
     ISTORE(amp_pos, amp_soff / amp_row_bytes);
-    if (valid) {
-      out_counts[stream] = F.out_cnt;
-      if (eod_counts) eod_counts[stream] = F.eod_cnt;
-    }
+    if (valid) out_counts[stream] = F.out_cnt;
 #undef RSTORE
 #undef ISTORE
   }
 #undef RLOAD
 #undef ILOAD
 #undef CLOAD
+#undef FSK_BLOAD4
 }
 
 size_t demod_fast_lds_bytes(const DemodParams &P) { return sizeof(float4) * 4 * kSlotStride + sizeof(uint32_t) * 64u * P.d; }
@@ -1139,14 +1148,19 @@ bool demod_fast_applicable(int precision, bool uniform_even, const DemodParams &
                            const float *samples, size_t pitch) {
   return precision == 0 && uniform_even && !P.wide && !P.frac && P.d >= 2 && S.trace_stream == 0xFFFFFFFFu &&
          (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(samples) & 15u) == 0) &&
-         demod_fast_lds_bytes(P) <= 64 * 1024 && (uint64_t)P.amp_cap * P.n_streams * 4u < 0xFFFFFFF0ull;
+         demod_fast_lds_bytes(P) <= 64 * 1024 && (uint64_t)P.amp_cap * P.n_streams * 4u < 0xFFFFFFF0ull &&
+         (uint64_t)pitch * 4u * 64u < 0x7FFFFFF0ull;  // per-wave input descriptor and offsets fit 31 bits
 }
 hipError_t launch_demod_fast(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream) {
   const uint32_t blocks = (P.n_streams + 63u) / 64u;
-  hipLaunchKernelGGL(demod_fast_kernel, dim3(blocks), dim3(64), demod_fast_lds_bytes(P), stream, P, S, samples, n,
-                     pitch, writeback ? 1 : 0, out, out_pitch, out_counts, eod_counts);
+  if (writeback)
+    hipLaunchKernelGGL(demod_fast_kernel<true>, dim3(blocks), dim3(64), demod_fast_lds_bytes(P), stream, P, S,
+                       samples, n, pitch, out, out_pitch, out_counts, eod_counts);
+  else
+    hipLaunchKernelGGL(demod_fast_kernel<false>, dim3(blocks), dim3(64), demod_fast_lds_bytes(P), stream, P, S,
+                       samples, n, pitch, out, out_pitch, out_counts, eod_counts);
   return hipGetLastError();
 }
 
