@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=0.5, help="audio seconds per stream per step")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--probe-reads", type=int, default=0,
+                    help="also launch the read-pattern probe kernel this many times (FETCH_SIZE calibration)")
     ap.add_argument("--pitch-pad", type=int, default=0, help="extra floats of row pitch (experiments)")
     ap.add_argument("--snr-db", type=float, default=None, help="add AWGN at this SNR (BASELINE config #5 shape)")
     args = ap.parse_args()
@@ -130,6 +132,12 @@ def main():
             "host_cpus": os.cpu_count(),
         }
 
+    if args.probe_reads:
+        # counter calibration aid: the same buffer streamed with the kernel's read pattern and nothing else
+        for _ in range(args.probe_reads):
+            eng.probe_read_device(x.data_ptr(), N, pitch, stream)
+        torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -156,6 +164,13 @@ def main():
     avg_kernel_s = kernel_ms / 1e3 / max(1, n_launch)
     achieved = alg_bytes_per_launch / avg_kernel_s / 1e9
     decoded = int(first_counts.sum())
+    # HBM traffic per launch from the committed PMC passes (profiles/r01_traffic.json): bytes per input sample
+    # measured for this kernel on the default workload; only reported for that workload and precision
+    traffic = None
+    tr_path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if args.workload == "c3" and args.precision == "f32" and args.snr_db is None and os.path.exists(tr_path):
+        with open(tr_path) as fh:
+            traffic = round(json.load(fh)["hbm_bytes_per_input_sample"] * S * N / avg_kernel_s / 1e9, 1)
 
     if rank == 0:
         line = {
@@ -175,8 +190,10 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "fsk::demod_kernel", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_note": "GB/s of HBM traffic = 7.07 B/input sample (rocprofv3 FETCH_SIZE x1.794 calibrated on probe_read_kernel "
+                                "+ WRITE_SIZE, profiles/r01_traffic.json) vs 4 B algorithmic: the extra is the reference's amplitude ring",
+                "kernel": "fsk::demod_fast_kernel<false>", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
             },
             "cpu_baseline": cpu_obj,

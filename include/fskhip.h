@@ -170,6 +170,11 @@ int fskhip_demod_supported(const fskhip_engine *e);
 int fskhip_trace_enable(fskhip_engine *e, int64_t stream, size_t capacity);
 int fskhip_trace_read(fskhip_engine *e, double *amp, double *post, uint8_t *bit, size_t cap, size_t *n);
 
+/* Measurement tooling: streams d_buf with the demodulator's fast-path read pattern and nothing else, so
+ * a FETCH_SIZE counter pass over it can be calibrated against the known n_streams*n*4 bytes. */
+int fskhip_probe_read_device(fskhip_engine *e, const float *d_buf, size_t n_per_stream, size_t pitch,
+                             void *hip_stream);
+
 /* FilterDesign.butterworth* (filters.ts:180-234): the configure-time designs the engine uses. */
 void fskhip_butterworth_lowpass(double cutoff, double sampleRate, double b[3], double a[3]);
 void fskhip_butterworth_highpass(double cutoff, double sampleRate, double b[3], double a[3]);

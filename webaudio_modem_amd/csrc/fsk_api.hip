@@ -33,6 +33,7 @@ hipError_t launch_synth(const ModParams &M, const double *coef, float *out, size
                         hipStream_t st);
 hipError_t launch_awgn(float *buf, size_t n, size_t pitch, uint32_t n_streams, double snr_db, uint64_t seed,
                        double *sigma, hipStream_t st);
+hipError_t launch_probe_read(const float *buf, size_t n, size_t pitch, uint32_t n_streams, float *sink, hipStream_t st);
 uint8_t host_synth_payload_byte(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t i);
 void host_synth_stream_params(uint64_t seed, uint32_t stream, uint32_t lead_max, double amp_lo, double amp_hi,
                               uint32_t *lead, double *amp);
@@ -653,6 +654,14 @@ int fskhip_add_awgn_device(fskhip_engine *e, float *d_buf, size_t n, size_t pitc
   if (!d_buf || pitch < n) return fail(FSKHIP_E_INVALID, "bad buffer");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(launch_awgn(d_buf, n, pitch, e->n_streams, snr_db, seed, e->d_sigma, (hipStream_t)hip_stream));
+  return FSKHIP_OK;
+}
+
+int fskhip_probe_read_device(fskhip_engine *e, const float *d_buf, size_t n, size_t pitch, void *hip_stream) {
+  if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "not configured");
+  if (!d_buf || pitch < n || (pitch % 4) != 0) return fail(FSKHIP_E_INVALID, "bad buffer");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(launch_probe_read(d_buf, n, pitch, e->n_streams, (float *)e->d_sigma, (hipStream_t)hip_stream));
   return FSKHIP_OK;
 }
 

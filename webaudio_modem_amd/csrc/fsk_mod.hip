@@ -250,6 +250,31 @@ __global__ __launch_bounds__(256) void awgn_kernel(float *__restrict__ buf, size
   *p = (float)((double)*p + sigma[s] * g);
 }
 
+// ---- read-pattern probe (measurement tooling) --------------------------------------------------
+// Streams a [n_streams][pitch] float buffer with exactly the demodulator's fast-path access pattern
+// (one wave per 64 rows, 16-sample tiles, four 16-B/lane loads of 16 rows x 64 B) and does nothing
+// else, so a rocprofv3 FETCH_SIZE pass over it calibrates that counter against a known byte count
+// (MI355X_MICROARCH.md, HBM: "calibrate on a known byte count in your own access pattern").
+__global__ __launch_bounds__(64) void probe_read_kernel(const float *__restrict__ buf, size_t n, size_t pitch,
+                                                        uint32_t n_streams, float *__restrict__ sink) {
+  const uint32_t lane = threadIdx.x, sub_row = lane >> 2, chunk = lane & 3;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t t0 = 0; t0 + 16 <= n; t0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint32_t r = blockIdx.x * 64u + 16u * i + sub_row;
+      r = r < n_streams ? r : n_streams - 1;
+      const float4 v = *reinterpret_cast<const float4 *>(buf + (size_t)r * pitch + t0 + 4u * chunk);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;  // keeps the loads alive
+}
+hipError_t launch_probe_read(const float *buf, size_t n, size_t pitch, uint32_t n_streams, float *sink, hipStream_t st) {
+  hipLaunchKernelGGL(probe_read_kernel, dim3((n_streams + 63u) / 64u), dim3(64), 0, st, buf, n, pitch, n_streams, sink);
+  return hipGetLastError();
+}
+
 hipError_t launch_modulate(const ModParams &M, const double *coef, const uint8_t *payloads, const uint32_t *lens,
                            size_t payload_pitch, float *out, size_t out_pitch, uint32_t *out_lens, hipStream_t st) {
   const uint32_t blocks = (M.n_streams + 63u) / 64u;

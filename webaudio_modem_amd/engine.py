@@ -198,6 +198,9 @@ class FSKEngine:
     def add_awgn_device(self, d_buf, n_per_stream, pitch, snr_db, seed, stream=None):
         _lib.check(self._L.fskhip_add_awgn_device(self._h, d_buf, n_per_stream, pitch, snr_db, seed, stream))
 
+    def probe_read_device(self, d_buf, n_per_stream, pitch, stream=None):
+        _lib.check(self._L.fskhip_probe_read_device(self._h, d_buf, n_per_stream, pitch, stream))
+
     def synth_payload(self, seed, stream, frame, payload_len):
         f = self._L.fskhip_synth_payload_byte
         return bytes(f(seed, stream, frame, i) for i in range(payload_len))
