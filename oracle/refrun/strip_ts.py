@@ -17,6 +17,9 @@ import re
 import sys
 
 FILES = ["src/utils.ts", "src/dsp/filters.ts", "src/core.ts", "src/modems/fsk.ts"]
+# the "next" rows of SURVEY.md 8(f): CRC-16 / XModem packets, ChunkedModulator
+NEXT_FILES = ["src/utils/crc16.ts", "src/transports/xmodem/types.ts", "src/transports/xmodem/packet.ts",
+              "src/webaudio/chunked-modulator.ts"]
 
 TYPE_ATOM = (
     r"(?:number\[\]\[\]|number\[\]|number|void|boolean|string|unknown|any"
@@ -58,6 +61,17 @@ def strip(src, name):
         lines = src.split("\n")
         src = "\n".join(lines[203:289])
     src = re.sub(r"^import .*?;\s*$", "", src, flags=re.M)
+    # enum -> frozen object (types.ts:29-34)
+    def enum_to_obj(m):
+        body = re.sub(r"//[^\n]*", "", m.group(2))
+        items = [it.strip() for it in body.split(",") if it.strip()]
+        return "const %s = {%s};" % (m.group(1), ", ".join(it.replace("=", ":") for it in items))
+    src = re.sub(r"^(?:export )?enum (\w+) \{(.*?)^\}", enum_to_obj, src, flags=re.M | re.S)
+    src = src.replace("} as const;", "};")
+    src = re.sub(r"<TConfig extends BaseModulatorConfig = BaseModulatorConfig>", "", src)
+    src = re.sub(r":\s*IModulator<TConfig>", "", src)
+    src = re.sub(r":\s*(?:Float32Array|ChunkResult|DataPacket)(?:\s*\|\s*null)?(?=\s*[=;{])", "", src)
+    src = re.sub(r"static (POLYNOMIAL|INITIAL_VALUE|FINAL_XOR) = (0x[0-9A-Fa-f]+);", r"static get \1() { return \2; }", src)
     src = drop_blocks(src, r"^(?:export )?interface [A-Za-z0-9_<>, ]+ (?:extends [A-Za-z0-9_<>, ]+ )?\{")
     src = re.sub(r"^export type [^;]*;\s*$", "", src, flags=re.M)
     src = re.sub(r"^export ", "", src, flags=re.M)
@@ -97,12 +111,13 @@ def main():
     ref, out = sys.argv[1], sys.argv[2]
     os.makedirs(out, exist_ok=True)
     parts = []
-    for f in FILES:
+    for f in FILES + NEXT_FILES:
         with open(os.path.join(ref, f), encoding="utf-8") as fh:
             parts.append("// ---- %s ----\n%s" % (f, strip(fh.read(), f)))
     parts.append(
         "module.exports = {FSKCore, DEFAULT_FSK_CONFIG, IIRFilter, FIRFilter, "
-        "FilterDesign, FilterFactory, RingBuffer};\n"
+        "FilterDesign, FilterFactory, RingBuffer, CRC16, XModemPacket, ControlType, PacketConstants, "
+        "ChunkedModulator};\n"
     )
     with open(os.path.join(out, "ref_bundle.js"), "w", encoding="utf-8") as fh:
         fh.write("\n".join(parts))

@@ -32,7 +32,29 @@ class Golden:
         return self.arrays[case["input"]]
 
 
+class GoldenNext:
+    """tests/golden/golden_next.npz: CRC-16 / XModem packets / ChunkedModulator / FSKProcessor quantum loop, captured
+    from the real reference classes (oracle/refrun/golden_harness_next.js)."""
+
+    def __init__(self):
+        with open(os.path.join(GOLDEN_DIR, "manifest_next.json")) as fh:
+            self.manifest = json.load(fh)
+        self.arrays = np.load(os.path.join(GOLDEN_DIR, "golden_next.npz"))
+
+    def ragged(self, ref):
+        data, off = self.arrays[ref["data"]], self.arrays[ref["off"]]
+        return [bytes(data[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+
+
 _GOLDEN = None
+_GOLDEN_NEXT = None
+
+
+def golden_next():
+    global _GOLDEN_NEXT
+    if _GOLDEN_NEXT is None:
+        _GOLDEN_NEXT = GoldenNext()
+    return _GOLDEN_NEXT
 
 
 def golden():
