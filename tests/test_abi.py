@@ -24,8 +24,11 @@ def lib():
 
 
 def _declared_symbols():
-    with open(os.path.join(ROOT, "include", "fskhip.h")) as fh:
-        src = fh.read()
+    src = ""
+    for name in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if name.endswith(".h"):
+            with open(os.path.join(ROOT, "include", name)) as fh:
+                src += fh.read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(fskhip_[a-z0-9_]+)\s*\(", src)))
 
@@ -33,7 +36,7 @@ def _declared_symbols():
 def test_header_symbols_all_exported(lib):
     L = C.CDLL(lib.LIB_PATH)
     declared = _declared_symbols()
-    assert len(declared) >= 25
+    assert len(declared) >= 55
     for name in declared:
         assert hasattr(L, name), "libfskhip.so does not export %s" % name
     # and the ctypes table binds exactly the header's set
@@ -76,6 +79,35 @@ def test_synth_helpers_are_deterministic(lib):
     lead, amp = C.c_uint32(), C.c_double()
     L.fskhip_synth_stream_params(0xF5C0DE, 5, 400, 0.1, 1.0, C.byref(lead), C.byref(amp))
     assert 0 <= lead.value <= 400 and 0.1 <= amp.value <= 1.0
+
+
+def test_sinc_designs_match_reference(lib):
+    from webaudio_modem_amd import FilterDesign
+    n = 0
+    for fd in golden().manifest["filter_design"]:
+        if not fd["fn"].startswith("sinc"):
+            continue
+        got = getattr(FilterDesign, fd["fn"])(*fd["args"])
+        assert len(got) == len(fd["out"])
+        np.testing.assert_allclose(got, fd["out"], rtol=0, atol=1e-16)  # libm vs V8 fdlibm last ulp of sin/cos
+        n += 1
+    assert n >= 7
+
+
+def test_next_rows_fail_loudly_without_gpu(lib):
+    import webaudio_modem_amd as wm
+    if lib.lib().fskhip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    for call in (lambda: wm.CRC16.calculate(b"123456789"), lambda: wm.serialize_batch([1], [b"abc"]),
+                 lambda: wm.scan_bursts([b"\x04"], [1]), lambda: wm.FIRFilter([0.5, 0.5])):
+        with pytest.raises(wm.FskHipError) as ei:
+            call()
+        assert ei.value.code == -4 and "no CPU fallback" in str(ei.value)
+    # argument checks with the reference's texts come before any device work (packet.ts:22-27)
+    with pytest.raises(ValueError, match=r"Invalid sequence: 0\. Must be 1-255\."):
+        wm.serialize_batch([0], [b"x"])
+    with pytest.raises(ValueError, match=r"Payload too large: 256\. Max 255 bytes\."):
+        wm.serialize_batch([1], [bytes(256)])
 
 
 def test_no_gpu_means_loud_failure(lib):

@@ -6,8 +6,11 @@ include/fskhip.h).  There is no CPU path in this package.
 from ._lib import FskHipError, PRECISION_F32, PRECISION_F64, LIB_PATH  # noqa: F401
 from .engine import FSKEngine, DEFAULT_FSK_CONFIG, make_config  # noqa: F401
 from .fsk_core import FSKCore, Event, EventEmitter  # noqa: F401
-from .filters import FilterDesign  # noqa: F401
+from .filters import FilterDesign, FilterFactory, FIRFilter, FIRFilterBatch  # noqa: F401
+from .processor import ChunkedModulator, FSKProcessorBatch  # noqa: F401
+from .xmodem import CRC16, XModemPacket, ControlType, crc16_batch, serialize_batch, scan_bursts  # noqa: F401
 from . import sharding  # noqa: F401
 
-__all__ = ["FSKEngine", "FSKCore", "FilterDesign", "DEFAULT_FSK_CONFIG", "FskHipError",
-           "PRECISION_F32", "PRECISION_F64"]
+__all__ = ["FSKEngine", "FSKCore", "FilterDesign", "FilterFactory", "FIRFilter", "FIRFilterBatch", "ChunkedModulator",
+           "FSKProcessorBatch", "CRC16", "XModemPacket", "ControlType", "crc16_batch", "serialize_batch", "scan_bursts",
+           "DEFAULT_FSK_CONFIG", "FskHipError", "PRECISION_F32", "PRECISION_F64"]

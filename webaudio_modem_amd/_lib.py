@@ -1,4 +1,4 @@
-"""ctypes loader for libfskhip.so (the C ABI in include/fskhip.h).
+"""ctypes loader for libfskhip.so (the C ABI in include/fskhip.h and include/fskhip_next.h).
 
 There is no fallback of any kind: if the HIP extension is missing this raises, and every
 compute entry point fails with FSKHIP_E_NO_DEVICE when no GPU is present.
@@ -12,6 +12,9 @@ LIB_PATH = os.path.join(_HERE, "libfskhip.so")
 MAX_PATTERN_BYTES = 16
 OK = 0
 E_INVALID, E_NOT_CONFIGURED, E_UNSUPPORTED, E_NO_DEVICE, E_HIP, E_NOMEM, E_OVERFLOW = -1, -2, -3, -4, -5, -6, -7
+E_BUSY = -8
+PROC_CLEAR_RX_ON_TX_COMPLETE, PROC_GRAPH = 1, 2
+XM_NEED_MORE, XM_EOT, XM_TRUNCATED, XM_INVALID_SEQUENCE, XM_INVALID_CRC, XM_UNEXPECTED_SEQUENCE = 0, 1, 2, 3, 4, 5
 PRECISION_F32, PRECISION_F64 = 0, 1
 DEMOD_WRITEBACK_AGC = 1
 
@@ -40,7 +43,16 @@ class Status(C.Structure):
     ]
 
 
-# every symbol include/fskhip.h declares: (name, restype, argtypes)
+class XModemResult(C.Structure):
+    """fskhip_xmodem_result (include/fskhip_next.h)."""
+    _fields_ = [
+        ("status", C.c_uint32), ("expected_after", C.c_uint32), ("packets", C.c_uint32), ("dropped", C.c_uint32),
+        ("consumed", C.c_uint32), ("data_len", C.c_uint32), ("err_seq", C.c_int32), ("err_len", C.c_int32),
+        ("crc_rx", C.c_int32), ("crc_calc", C.c_int32),
+    ]
+
+
+# every symbol include/*.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _SYMBOLS = [
     ("fskhip_default_config", None, [C.POINTER(Config)]),
@@ -78,6 +90,30 @@ _SYMBOLS = [
     ("fskhip_last_error", C.c_char_p, []),
     ("fskhip_abi_version", C.c_int, []),
     ("fskhip_device_count", C.c_int, []),
+    # ---- include/fskhip_next.h ----
+    ("fskhip_crc16_device", C.c_int, [_P, C.c_size_t, _P, C.c_uint32, _P, _P]),
+    ("fskhip_crc16_host", C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_uint32, _P]),
+    ("fskhip_xmodem_serialize_device", C.c_int, [_P, C.c_size_t, _P, _P, C.c_uint32, _P, C.c_size_t, _P, _P]),
+    ("fskhip_xmodem_serialize_host", C.c_int, [C.c_int, _P, C.c_size_t, _P, _P, C.c_uint32, _P, C.c_size_t, _P]),
+    ("fskhip_xmodem_scan_device", C.c_int, [_P, C.c_size_t, _P, _P, C.c_uint32, _P, C.c_size_t, _P, _P]),
+    ("fskhip_xmodem_scan_host", C.c_int, [C.c_int, _P, C.c_size_t, _P, _P, C.c_uint32, _P, C.c_size_t, _P]),
+    ("fskhip_processor_create", C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
+    ("fskhip_processor_destroy", C.c_int, [_P]),
+    ("fskhip_processor_process_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_uint32, _P]),
+    ("fskhip_processor_process_host", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_uint32]),
+    ("fskhip_processor_modulate_host", C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    ("fskhip_processor_tx_state_host", C.c_int, [_P, _P, _P, _P, _P]),
+    ("fskhip_processor_rx_drain_host", C.c_int, [_P, _P, C.c_size_t, _P]),
+    ("fskhip_processor_rx_length_host", C.c_int, [_P, _P]),
+    ("fskhip_processor_reset", C.c_int, [_P, C.c_int64]),
+    ("fskhip_sinc_lowpass", C.c_int, [C.c_double, C.c_double, C.c_uint32, _P]),
+    ("fskhip_sinc_highpass", C.c_int, [C.c_double, C.c_double, C.c_uint32, _P]),
+    ("fskhip_sinc_bandpass", C.c_int, [C.c_double, C.c_double, C.c_double, C.c_uint32, _P]),
+    ("fskhip_fir_create", C.c_int, [C.c_int, _P, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    ("fskhip_fir_destroy", C.c_int, [_P]),
+    ("fskhip_fir_process_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P]),
+    ("fskhip_fir_process_host", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t]),
+    ("fskhip_fir_reset", C.c_int, [_P, C.c_int64]),
 ]
 SYMBOL_NAMES = [s[0] for s in _SYMBOLS]
 

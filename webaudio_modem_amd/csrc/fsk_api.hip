@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/fskhip.h"
+#include "fsk_host.h"
 #include "fsk_params.h"
 
 namespace fsk {
@@ -42,7 +42,7 @@ void host_synth_stream_params(uint64_t seed, uint32_t stream, uint32_t lead_max,
 using namespace fsk;
 
 static thread_local std::string g_err;
-static int fail(int code, const char *fmt, ...) {
+int fsk::fail(int code, const char *fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -51,11 +51,6 @@ static int fail(int code, const char *fmt, ...) {
   g_err = buf;
   return code;
 }
-#define HIP_TRY(expr)                                                                             \
-  do {                                                                                            \
-    hipError_t _e = (expr);                                                                       \
-    if (_e != hipSuccess) return fail(FSKHIP_E_HIP, "%s: %s", #expr, hipGetErrorString(_e));      \
-  } while (0)
 
 // ---- small device kernels for state management --------------------------------------------------
 namespace {
@@ -148,6 +143,27 @@ struct fskhip_engine {
   size_t ev_used = 0;
   hipStream_t timing_stream = nullptr;
 };
+
+int fsk::engine_device(const fskhip_engine *e) { return e->device; }
+namespace fsk {
+const ModParams &engine_mod_params(const fskhip_engine *e) { return e->M; }
+const double *engine_coef(const fskhip_engine *e) { return e->S.coef; }
+// upper bound on the bytes one call can return per stream: a byte takes bitsPerByte (>= 8) bit times of spb samples
+size_t engine_max_bytes(const fskhip_engine *e, size_t n_per_stream) {
+  const size_t spb = e->M.spb ? e->M.spb : 1;
+  return n_per_stream / (4 * spb) + 8;
+}
+// everything fskhip_demodulate_device's choice of launches depends on besides its arguments
+uint32_t engine_launch_key(const fskhip_engine *e) {
+  return (e->ds_uniform ? 1u : 0u) | (e->ds_parity << 1) | (e->force_generic ? 4u : 0u) | (e->timing ? 8u : 0u) |
+         (e->S.trace_stream != 0xFFFFFFFFu ? 16u : 0u);
+}
+void engine_note_replayed_call(fskhip_engine *e, size_t n) {
+  e->calls += 1;
+  e->total_samples += n;
+  e->ds_parity = (e->ds_parity + (uint32_t)(n & 1)) & 1u;
+}
+}  // namespace fsk
 
 static void ref_butter_lp(double cutoff, double sr, double b[3], double a[3]) {  // filters.ts:180-192
   double nyquist = sr / 2;

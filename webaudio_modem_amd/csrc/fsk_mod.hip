@@ -219,6 +219,158 @@ __global__ __launch_bounds__(64) void synth_kernel(ModParams M, const double *__
   }
 }
 
+// ---- FSKProcessor.process() for every stream ------------------------------------------------------
+// One launch per quantum after the demodulator: (1) processDemodulation's ring puts (fsk-processor.ts:310-318,
+// utils.ts:38-48) of the bytes the demod kernels just produced, (2) modulateTo (256-276): zero fill, then the next
+// n_out samples of the pending modulation from its generator state, completion bookkeeping, and optionally the RX
+// clear the 'modulate' handler does when the modulation resolves (228-235).
+__global__ __launch_bounds__(64) void processor_io_kernel(ModParams M, const double *__restrict__ coef, ProcState T,
+                                                          const uint8_t *__restrict__ demod_out, size_t demod_pitch,
+                                                          const uint32_t *__restrict__ demod_counts, int do_rx,
+                                                          float *__restrict__ out, size_t n_out, size_t out_pitch,
+                                                          int vec_ok, uint32_t clear_rx_on_complete) {
+  __shared__ float4 stage[kChunks * kSlotStride];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t stream = blockIdx.x * 64u + lane;
+  const bool valid = stream < M.n_streams;
+  const uint32_t row = valid ? stream : M.n_streams - 1;
+  const size_t ns = M.n_streams;
+
+  uint32_t w = T.rx_w[row], r = T.rx_r[row], len = T.rx_len[row];
+  bool rx_dirty = false;
+  if (do_rx && valid) {
+    uint32_t cnt = demod_counts[stream];
+    if ((size_t)cnt > demod_pitch) cnt = (uint32_t)demod_pitch;
+    const uint8_t *src = demod_out + (size_t)stream * demod_pitch;
+    uint8_t *ring = T.rx_buf + (size_t)stream * T.rx_cap;
+    for (uint32_t i = 0; i < cnt; i++) {  // put(): overwrite the oldest when full
+      ring[w] = src[i];
+      w = w + 1 == T.rx_cap ? 0u : w + 1;
+      if (len < T.rx_cap) len++;
+      else r = r + 1 == T.rx_cap ? 0u : r + 1;
+    }
+    rx_dirty = cnt != 0;
+  }
+
+  if (out != nullptr && n_out > 0) {
+    const uint32_t flen = T.tx_len[row];
+    const bool active = valid && T.tx_pending[row] != 0u && flen > 0u && T.tx_pos[row] < flen;
+    const uint8_t *prow = T.tx_payload + (size_t)row * T.tx_payload_pitch;
+    auto pb = [&](uint32_t i) -> uint8_t { return prow[i]; };
+    FrameGen G;
+    G.start(M, coef[(size_t)CF_mark_w * ns + row], coef[(size_t)CF_space_w * ns + row], T.tx_n_payload[row]);
+    if (active) {
+      G.phase = T.tx_phase[row]; G.pos = T.tx_pos[row]; G.in_bit = T.tx_in_bit[row];
+      G.bit_idx = T.tx_bit_idx[row]; G.cur_bit = T.tx_cur_bit[row];
+    } else {
+      G.pos = G.frame_len;  // nothing to emit: zeros
+    }
+    for (size_t t0 = 0; t0 < n_out; t0 += kTile) {
+      __syncthreads();
+      for (uint32_t c = 0; c < (uint32_t)kChunks; c++) {
+        // samples beyond n_out inside the last tile must not advance the generator
+        const size_t base = t0 + 4u * c;
+        float4 v;
+        v.x = (base + 0 < n_out && G.pos < G.frame_len) ? frame_next(G, M, pb) : 0.0f;
+        v.y = (base + 1 < n_out && G.pos < G.frame_len) ? frame_next(G, M, pb) : 0.0f;
+        v.z = (base + 2 < n_out && G.pos < G.frame_len) ? frame_next(G, M, pb) : 0.0f;
+        v.w = (base + 3 < n_out && G.pos < G.frame_len) ? frame_next(G, M, pb) : 0.0f;
+        stage[c * kSlotStride + lane] = v;
+      }
+      __syncthreads();
+      store_tile(stage, out, out_pitch, t0, n_out, M.n_streams, nullptr, vec_ok);
+    }
+    if (active) {
+      if (G.pos >= flen) {  // isComplete: ChunkedModulator.reset() + pendingModulation = null
+        T.tx_pos[stream] = 0u; T.tx_len[stream] = 0u; T.tx_pending[stream] = 0u;
+        T.tx_completed[stream] += 1u;
+        if (clear_rx_on_complete) { w = 0u; r = 0u; len = 0u; rx_dirty = true; }
+      } else {
+        T.tx_phase[stream] = G.phase; T.tx_pos[stream] = G.pos; T.tx_in_bit[stream] = G.in_bit;
+        T.tx_bit_idx[stream] = G.bit_idx; T.tx_cur_bit[stream] = G.cur_bit;
+      }
+    }
+  }
+  if (rx_dirty && valid) { T.rx_w[stream] = w; T.rx_r[stream] = r; T.rx_len[stream] = len; }
+}
+
+// startModulation() for the selected streams: take the payload, arm the generator at sample 0
+__global__ void processor_tx_start_kernel(ModParams M, ProcState T, const uint8_t *__restrict__ payloads,
+                                          const uint32_t *__restrict__ lens, size_t payload_pitch,
+                                          const uint8_t *__restrict__ mask) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= M.n_streams) return;
+  if (mask && !mask[s]) return;
+  const uint32_t n = lens[s];
+  T.tx_pending[s] = 1u;
+  T.tx_pos[s] = 0u;
+  if (n == 0u) {  // startModulation(empty) -> reset(): no signal, the modulator object stays pending
+    T.tx_len[s] = 0u;
+    T.tx_n_payload[s] = 0u;
+    return;
+  }
+  for (uint32_t i = 0; i < n; i++) T.tx_payload[(size_t)s * T.tx_payload_pitch + i] = payloads[(size_t)s * payload_pitch + i];
+  FrameGen G;
+  G.start(M, 0.0, 0.0, n);
+  T.tx_n_payload[s] = n;
+  T.tx_len[s] = G.frame_len;
+  T.tx_phase[s] = 0.0;
+  T.tx_in_bit[s] = G.in_bit; T.tx_bit_idx[s] = G.bit_idx; T.tx_cur_bit[s] = G.cur_bit;
+}
+
+// demodulate(): remove everything buffered, oldest first
+__global__ void processor_rx_drain_kernel(ProcState T, uint32_t n_streams, uint8_t *__restrict__ out, size_t out_pitch,
+                                          uint32_t *__restrict__ counts) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_streams) return;
+  uint32_t r = T.rx_r[s];
+  const uint32_t len = T.rx_len[s];
+  const uint8_t *ring = T.rx_buf + (size_t)s * T.rx_cap;
+  for (uint32_t i = 0; i < len; i++) {
+    if ((size_t)i < out_pitch) out[(size_t)s * out_pitch + i] = ring[r];
+    r = r + 1 == T.rx_cap ? 0u : r + 1;
+  }
+  counts[s] = len;
+  T.rx_r[s] = r;
+  T.rx_len[s] = 0u;
+}
+
+// FSKProcessor.reset() (fsk-processor.ts:140-146) / ChunkedModulator.cancel(); stream < 0 = all
+__global__ void processor_reset_kernel(ProcState T, uint32_t n_streams, int64_t stream, int rx, int tx) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_streams) return;
+  if (stream >= 0 && (int64_t)s != stream) return;
+  if (rx) { T.rx_w[s] = 0u; T.rx_r[s] = 0u; T.rx_len[s] = 0u; }
+  if (tx) { T.tx_pending[s] = 0u; T.tx_len[s] = 0u; T.tx_pos[s] = 0u; }
+}
+
+hipError_t launch_processor_io(const ModParams &M, const double *coef, const ProcState &T, const uint8_t *demod_out,
+                               size_t demod_pitch, const uint32_t *demod_counts, bool do_rx, float *out, size_t n_out,
+                               size_t out_pitch, bool clear_rx_on_complete, hipStream_t st) {
+  const uint32_t blocks = (M.n_streams + 63u) / 64u;
+  const int vec_ok = out && (out_pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+  hipLaunchKernelGGL(processor_io_kernel, dim3(blocks), dim3(64), 0, st, M, coef, T, demod_out, demod_pitch,
+                     demod_counts, do_rx ? 1 : 0, out, n_out, out_pitch, vec_ok, clear_rx_on_complete ? 1u : 0u);
+  return hipGetLastError();
+}
+hipError_t launch_processor_tx_start(const ModParams &M, const ProcState &T, const uint8_t *payloads, const uint32_t *lens,
+                                     size_t payload_pitch, const uint8_t *mask, hipStream_t st) {
+  hipLaunchKernelGGL(processor_tx_start_kernel, dim3((M.n_streams + 255u) / 256u), dim3(256), 0, st, M, T, payloads, lens,
+                     payload_pitch, mask);
+  return hipGetLastError();
+}
+hipError_t launch_processor_rx_drain(const ProcState &T, uint32_t n_streams, uint8_t *out, size_t out_pitch,
+                                     uint32_t *counts, hipStream_t st) {
+  hipLaunchKernelGGL(processor_rx_drain_kernel, dim3((n_streams + 255u) / 256u), dim3(256), 0, st, T, n_streams, out,
+                     out_pitch, counts);
+  return hipGetLastError();
+}
+hipError_t launch_processor_reset(const ProcState &T, uint32_t n_streams, int64_t stream, bool rx, bool tx, hipStream_t st) {
+  hipLaunchKernelGGL(processor_reset_kernel, dim3((n_streams + 255u) / 256u), dim3(256), 0, st, T, n_streams, stream,
+                     rx ? 1 : 0, tx ? 1 : 0);
+  return hipGetLastError();
+}
+
 // ---- AWGN ------------------------------------------------------------------------------------
 // pass 1: one wave per stream, coalesced row sweep, f64 sum of squares -> sigma[s]
 __global__ __launch_bounds__(64) void power_kernel(const float *__restrict__ buf, size_t n, size_t pitch,

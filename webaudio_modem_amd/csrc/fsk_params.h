@@ -120,6 +120,24 @@ struct ModParams {
   uint8_t pre[2 * 16];
 };
 
+// FSKProcessor + ChunkedModulator per stream (fsk-processor.ts, chunked-modulator.ts), device resident.
+// The pending signal is kept as the modulator's generator state (payload + phase + position), not as samples:
+// a slice of n samples is produced on demand and is bit-identical to the same slice of modulateData()'s output
+// because the reference's signal is itself one sequential f64 phase accumulation (fsk.ts:398-406).
+struct ProcState {
+  uint8_t *rx_buf;       // [stream][rx_cap] demodulatedBuffer storage (fsk-processor.ts:84)
+  uint32_t *rx_w, *rx_r, *rx_len;  // writeIndex / readIndex / _length (utils.ts:7-9)
+  uint32_t rx_cap;
+  uint8_t *tx_payload;   // [stream][tx_payload_pitch] bytes of the pending modulation
+  size_t tx_payload_pitch;
+  double *tx_phase;      // FrameGen state at samplePosition
+  uint32_t *tx_pos;      // samplePosition (chunked-modulator.ts:25)
+  uint32_t *tx_len;      // pendingSignal.length, 0 = no signal
+  uint32_t *tx_in_bit, *tx_bit_idx, *tx_cur_bit, *tx_n_payload;
+  uint32_t *tx_pending;  // pendingModulation != null (fsk-processor.ts:64)
+  uint32_t *tx_completed;
+};
+
 static constexpr uint32_t kBigWait = 0x40000000u;  // bit_wait while !started (12 h of decimated samples)
 #ifndef FSK_TILE
 #define FSK_TILE 32

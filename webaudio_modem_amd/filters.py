@@ -25,3 +25,102 @@ class FilterDesign:
     @staticmethod
     def butterworthBandpass(centerFreq, bandwidth, sampleRate):
         return _call(_lib.lib().fskhip_butterworth_bandpass, float(centerFreq), float(bandwidth), float(sampleRate))
+
+    # windowed-sinc FIR designs (filters.ts:243-314)
+    @staticmethod
+    def _sinc(fn, numTaps, *args):
+        taps = (C.c_double * (int(numTaps) + 1))()
+        n = fn(*[float(a) for a in args], int(numTaps), taps)
+        if n < 0:
+            _lib.check(n)
+        return list(taps)[:n]
+
+    @staticmethod
+    def sincLowpass(cutoffFreq, sampleRate, numTaps):
+        return FilterDesign._sinc(_lib.lib().fskhip_sinc_lowpass, numTaps, cutoffFreq, sampleRate)
+
+    @staticmethod
+    def sincHighpass(cutoffFreq, sampleRate, numTaps):
+        return FilterDesign._sinc(_lib.lib().fskhip_sinc_highpass, numTaps, cutoffFreq, sampleRate)
+
+    @staticmethod
+    def sincBandpass(centerFreq, bandwidth, sampleRate, numTaps):
+        return FilterDesign._sinc(_lib.lib().fskhip_sinc_bandpass, numTaps, centerFreq, bandwidth, sampleRate)
+
+
+class FIRFilterBatch:
+    """`new FIRFilter(coefficients)` (filters.ts:112-167) for n_streams streams on one GPU: `processBuffer` on a
+    float32 [S, N] block, delay lines carried across calls, `reset`, `getCoefficients`."""
+
+    def __init__(self, coefficients, n_streams=1, device=0, precision=_lib.PRECISION_F64):
+        import numpy as np
+        self._np = np
+        self.coefficients = [float(c) for c in coefficients]
+        if not self.coefficients:
+            raise ValueError("FIR needs at least one coefficient")
+        taps = (C.c_double * len(self.coefficients))(*self.coefficients)
+        h = C.c_void_p()
+        self._L = _lib.lib()
+        _lib.check(self._L.fskhip_fir_create(device, taps, len(self.coefficients), n_streams, precision, C.byref(h)))
+        self._h = h
+        self.n_streams = n_streams
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fskhip_fir_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def processBuffer(self, x):
+        np = self._np
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        single = x.ndim == 1
+        if single:
+            x = x[None, :]
+        if x.shape[0] != self.n_streams:
+            raise ValueError("input must be [n_streams, n]")
+        out = np.empty_like(x)
+        if x.shape[1]:
+            _lib.check(self._L.fskhip_fir_process_host(self._h, x.ctypes.data, x.shape[1], x.shape[1], out.ctypes.data,
+                                                       x.shape[1]))
+        return out[0] if single else out
+
+    def process_device(self, d_in, n, in_pitch, d_out, out_pitch, stream=None):
+        _lib.check(self._L.fskhip_fir_process_device(self._h, d_in, n, in_pitch, d_out, out_pitch, stream))
+
+    def reset(self, stream=-1):
+        _lib.check(self._L.fskhip_fir_reset(self._h, stream))
+
+    def getCoefficients(self):
+        return list(self.coefficients)
+
+
+class FIRFilter(FIRFilterBatch):
+    """One FIRFilter with the reference's per-sample surface: process(x) is a batch of one sample."""
+
+    def __init__(self, coefficients, device=0, precision=_lib.PRECISION_F64):
+        super().__init__(coefficients, 1, device, precision)
+
+    def process(self, x):
+        return float(self.processBuffer(self._np.array([x], dtype=self._np.float32))[0])
+
+
+class FilterFactory:
+    """FilterFactory.createFIR* (filters.ts:346-368)."""
+
+    @staticmethod
+    def createFIRLowpass(cutoffFreq, sampleRate, numTaps=51, **kw):
+        return FIRFilter(FilterDesign.sincLowpass(cutoffFreq, sampleRate, numTaps), **kw)
+
+    @staticmethod
+    def createFIRHighpass(cutoffFreq, sampleRate, numTaps=51, **kw):
+        return FIRFilter(FilterDesign.sincHighpass(cutoffFreq, sampleRate, numTaps), **kw)
+
+    @staticmethod
+    def createFIRBandpass(centerFreq, bandwidth, sampleRate, numTaps=51, **kw):
+        return FIRFilter(FilterDesign.sincBandpass(centerFreq, bandwidth, sampleRate, numTaps), **kw)
