@@ -153,3 +153,5 @@ def test_fast_kernel_never_spills():
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
     plain = [v for k, v in fast.items() if "ILb0E" in k][0]
     assert plain["VGPRs"] <= 128, plain
+    # the registers the asm prefetch lands in are never touched while a load may still be in flight
+    assert check_isa.prefetch_register_hazards() == []

@@ -31,7 +31,82 @@ def kernel_resources():
     return res
 
 
+def prefetch_register_hazards():
+    """The asm-issued tile prefetch lands asynchronously: between its issue and a vmcnt wait that covers it the
+    destination VGPRs must not be touched.  Returns a list of violations found in the fast kernels' ISA:
+    any instruction after the in-loop prefetch that uses those registers without an `s_waitcnt vmcnt(0)` (the
+    epilogue) or the loop-top `s_waitcnt vmcnt(8)` + ds_write (the next iteration) in between."""
+    src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_demod.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        asm = os.path.join(tmp, "d.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                        "-S", "--cuda-device-only", "-o", asm, src], capture_output=True, text=True, check=True)
+        text = open(asm).read()
+
+    def regs_of(line):
+        out = set()
+        for m in re.finditer(r"v\[(\d+):(\d+)\]", line):
+            out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bv(\d+)\b", line):
+            out.add(int(m.group(1)))
+        return out
+
+    problems = []
+    found = list(re.finditer(r"^(_ZN3fsk17demod_fast_kernel\w+):[^\n]*\n", text, re.M))
+    if len(found) != 2:
+        problems.append(("demod_fast_kernel", "expected 2 kernel bodies in the ISA, found %d" % len(found)))
+    for m in found:
+        body = text[m.end():text.index(".Lfunc_end", m.end())].split("\n")
+        loads = [i for i, l in enumerate(body) if "buffer_load_dwordx4" in l]
+        if len(loads) != 8:
+            problems.append((m.group(1), "expected 8 asm prefetch loads, found %d" % len(loads)))
+            continue
+        dst = set()
+        for i in loads[4:]:
+            dst |= regs_of(body[i].split(",")[0])
+        # loop top: the four ds_write_b128 of the staged tile, preceded by the vmcnt(8) wait
+        for i in range(loads[3] + 1, loads[4]):
+            if regs_of(body[i]) & dst and "ds_write_b128" in body[i]:
+                if not any("s_waitcnt vmcnt(8)" in body[j] for j in range(loads[3], i)):
+                    problems.append((m.group(1), "staging before the vmcnt(8) wait: " + body[i].strip()))
+                break
+        # epilogue = everything after the tile loop's back edge (the last branch to a label above the prefetch)
+        labels = {}
+        for i, l in enumerate(body):
+            ml = re.match(r"\s*(\.LBB\d+_\d+):", l)
+            if ml:
+                labels[ml.group(1)] = i
+        back = None
+        for i in range(loads[7] + 1, len(body)):
+            mb = re.match(r"\s*s_c?branch\S*\s+(\.LBB\d+_\d+)", body[i])
+            if mb and labels.get(mb.group(1), len(body)) < loads[4]:
+                back = i
+        if back is None:
+            problems.append((m.group(1), "tile loop back edge not found"))
+            continue
+        # inside the loop after the prefetch: nothing may touch the destination registers at all
+        for i in range(loads[7] + 1, back):
+            line = body[i].strip()
+            if line and not line.startswith(";") and regs_of(line) & dst:
+                problems.append((m.group(1), "prefetch destination touched inside the loop: " + line))
+                break
+        waited = False
+        for i in range(back + 1, len(body)):
+            line = body[i].strip()
+            if "s_waitcnt" in line and "vmcnt(0)" in line:
+                waited = True
+            if line.startswith(";") or not line:
+                continue
+            if regs_of(line) & dst and not waited:
+                problems.append((m.group(1), "prefetch destination touched while the load may be in flight: " + line))
+                break
+    return problems
+
+
 if __name__ == "__main__":
+    for name, what in prefetch_register_hazards():
+        print("HAZARD", name[:50], what)
+        sys.exit(2)
     r = kernel_resources()
     bad = 0
     for name, v in r.items():

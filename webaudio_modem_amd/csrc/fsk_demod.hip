@@ -1110,6 +1110,11 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
     }
   }
 
+  // The last iteration's prefetch is still in flight and its destination registers are dead to the compiler:
+  // without this wait the epilogue reuses them (e.g. as the high half of a store address) and a late-landing
+  // load overwrites them -- a wild global store.  Keep them allocated until the loads have landed.
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre0), "+v"(pre1), "+v"(pre2), "+v"(pre3) : : "memory");
+
   for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
   {
 #define RSTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)(v)), rs_rsrc, M.voff, (uint32_t)RF_##f * fld, 0)
