@@ -322,6 +322,8 @@ static napi_value DeviceCount(napi_env env, napi_callback_info) {
   return r;
 }
 
+napi_value InitNext(napi_env env, napi_value exports);  // fsk_addon_next.cc: include/fskhip_next.h
+
 static napi_value Init(napi_env env, napi_value exports) {
   const napi_property_descriptor props[] = {
       {"create", nullptr, Create, nullptr, nullptr, nullptr, napi_default, nullptr},
@@ -338,7 +340,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   napi_value v;
   napi_create_int32(env, fskhip_abi_version(), &v);
   napi_set_named_property(env, exports, "abiVersion", v);
-  return exports;
+  return InitNext(env, exports);
 }
 
 NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

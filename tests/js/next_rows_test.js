@@ -1,0 +1,136 @@
+'use strict';
+// The SURVEY 8(f) rows through the JS host classes (napi/*.js -> N-API -> libfskhip.so): the reference's own KATs
+// (tests/utils/crc16.node.test.ts, tests/webaudio/chunked-modulator.node.test.ts, tests/dsp/filters.node.test.ts) and
+// the golden manifest captured from the real reference classes.  usage: node next_rows_test.js cpu|gpu
+const assert = require('assert');
+const fs = require('fs');
+const path = require('path');
+const N = path.join(__dirname, '..', '..', 'napi');
+const M = require(path.join(N, 'fsk-core.js'));
+const X = require(path.join(N, 'xmodem.js'));
+const { ChunkedModulator } = require(path.join(N, 'chunked-modulator.js'));
+const { FSKProcessorBatch } = require(path.join(N, 'fsk-processor.js'));
+const F = require(path.join(N, 'filters.js'));
+const golden = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', 'manifest_next.json'), 'utf8'));
+const mode = process.argv[2] || 'cpu';
+
+async function cpuTests() {
+  for (const fn of ['crc16', 'xmodemSerialize', 'xmodemScan', 'processorCreate', 'processorProcess', 'firCreate', 'sincLowpass']) {
+    assert.strictEqual(typeof M.addon[fn], 'function', fn);
+  }
+  // createData's checks come before any device work, with the reference's texts (packet.ts:22-27)
+  for (const e of golden.packets.errors) {
+    assert.throws(() => X.XModemPacket.createData(e.seq, new Uint8Array(e.len)), (err) => err.message === e.error);
+  }
+  assert.deepStrictEqual(Object.assign({}, X.ControlType), { SOH: 1, ACK: 6, NAK: 21, EOT: 4 });
+  assert.deepStrictEqual(Object.assign({}, X.PacketConstants), golden.packets.constants);
+  // designs are host arithmetic: sincLowpass KAT from the reference (symmetric, odd length bumped)
+  const lp = F.FilterDesign.sincLowpass(1000, 48000, 50);
+  assert.strictEqual(lp.length, 51);
+  for (let i = 0; i < 25; i++) assert.ok(Math.abs(lp[i] - lp[50 - i]) < 1e-15);
+  if (M.addon.deviceCount() === 0) {
+    assert.throws(() => X.CRC16.calculate(Uint8Array.of(1, 2, 3)), /no CPU fallback/);
+    assert.throws(() => new F.FIRFilter([0.5, 0.5]), /no CPU fallback/);
+  }
+  console.log('js next cpu tests ok');
+}
+
+async function gpuTests() {
+  // ---- CRC16 (tests/utils/crc16.node.test.ts:12-60) ----
+  const s = (t) => Uint8Array.from(Buffer.from(t, 'ascii'));
+  assert.strictEqual(X.CRC16.calculate(new Uint8Array(0)), 0xFFFF);
+  assert.strictEqual(X.CRC16.calculate(s('A')), 0xB915);
+  assert.strictEqual(X.CRC16.calculate(s('123456789')), 0x29B1);
+  assert.strictEqual(X.CRC16.calculate(Uint8Array.of(0)), 0xE1F0);
+  assert.strictEqual(X.CRC16.calculate(Uint8Array.of(0xFF)), 0xFF00);
+  assert.strictEqual(X.CRC16.calculate(Uint8Array.of(0xAA, 0xAA)), 0xFB1A);
+  assert.strictEqual(X.CRC16.calculate(Uint8Array.from({ length: 256 }, (_, i) => i)), 0x3FBD);
+  assert.ok(X.CRC16.verify(s('123456789'), 0x29B1) && !X.CRC16.verify(s('123456789'), 0x29B0));
+  // ---- XModemPacket ----
+  const pk = X.XModemPacket.createData(3, Uint8Array.of(1, 2, 3));
+  assert.deepStrictEqual(Array.from(X.XModemPacket.serialize(pk)), [1, 3, 252, 3, 1, 2, 3, 173, 173]);
+  assert.ok(X.XModemPacket.verify(pk));
+  golden.packets.meta.slice(0, 8).forEach((m) => {
+    const p = X.XModemPacket.createData(m.seq, new Uint8Array(m.len));
+    assert.strictEqual(p.invSequence, m.inv);
+  });
+  // ---- scan: three packets + EOT, a corrupted one, a duplicate ----
+  const wires = X.serializeBatch([1, 2, 3], [s('hello'), s('world!'), new Uint8Array(0)]);
+  const cat = (...a) => Uint8Array.from([].concat(...a.map((x) => Array.from(x))));
+  const bad = Uint8Array.from(wires[0]); bad[5] ^= 0x10;
+  const res = X.scanBursts([cat(Uint8Array.of(0x55), wires[0], wires[1], wires[2], Uint8Array.of(4)), bad, cat(wires[0], wires[1])], [1, 1, 2]);
+  assert.strictEqual(res[0].statusName, 'eot'); assert.strictEqual(res[0].packets, 3); assert.strictEqual(res[0].expectedAfter, 4);
+  assert.strictEqual(Buffer.from(res[0].data).toString('ascii'), 'helloworld!');
+  assert.strictEqual(res[1].error, 'Invalid CRC'); assert.strictEqual(res[1].dropped, 1);
+  assert.strictEqual(res[2].packets, 1); assert.strictEqual(res[2].dropped, 1);   // seq 1 is the previous of 2: duplicate
+  assert.strictEqual(Buffer.from(res[2].data).toString('ascii'), 'world!');
+  // ---- ChunkedModulator against the reference's recorded steps ----
+  for (const c of golden.chunked) {
+    const core = new M.FSKCore();
+    core.configure(c.config);
+    const cm = new ChunkedModulator(core);
+    assert.strictEqual(cm.isModulating(), false); assert.strictEqual(cm.getNextSamples(128), null);
+    await cm.startModulation(Uint8Array.from(c.payload));
+    const direct = await core.modulateData(Uint8Array.from(c.payload));
+    assert.strictEqual(direct.length, c.total);
+    const steps = [];
+    let r, off = 0;
+    while ((r = cm.getNextSamples(c.chunk)) !== null) {
+      steps.push([r.signal.length, r.isComplete ? 1 : 0, r.samplesConsumed, r.totalSamples, cm.getProgress(), cm.isModulating() ? 1 : 0]);
+      for (let i = 0; i < r.signal.length; i++) assert.strictEqual(r.signal[i], direct[off + i]);
+      off += r.signal.length;
+    }
+    assert.strictEqual(steps.length, c.n_steps);
+    assert.deepStrictEqual(c.steps_truncated ? steps.slice(0, 8).concat(steps.slice(-8)) : steps, c.steps, c.name);
+    core.close();
+  }
+  // ---- FSKProcessorBatch: loopback -- stream 0 modulates a packet, its output is fed back as everyone's input ----
+  {
+    const S = 3;
+    const cfg = { baudRate: 1200, markFrequency: 1200, spaceFrequency: 2200 };
+    const batch = new M.FSKBatch(S, cfg, { precision: M.PRECISION_F64 });
+    const proc = new FSKProcessorBatch(batch, { clearRxOnTxComplete: false });
+    const wire = X.serializeBatch([1], [s('loopback over the GPU')])[0];
+    proc.modulate([wire, new Uint8Array(0), new Uint8Array(0)], [true, false, false]);
+    assert.throws(() => proc.modulate([wire, wire, wire], [true, false, false]), /Modulation already in progress/);
+    let st = proc.txState();
+    assert.deepStrictEqual(Array.from(st.pending), [1, 0, 0]);
+    const total = st.total[0];
+    let input = new Float32Array(S * 128), quanta = 0;
+    while (quanta < 400) {
+      const out = proc.process(input, 128, 128);
+      const next = new Float32Array(S * 128);
+      for (let k = 0; k < S; k++) next.set(out.subarray(0, 128), k * 128);   // everyone hears stream 0
+      input = next; quanta++;
+      if (!proc.txState().pending[0] && quanta * 128 > total + 2000) break;
+    }
+    assert.strictEqual(proc.txState().completed[0], 1);
+    assert.deepStrictEqual(Array.from(proc.rxLengths()), [wire.length, wire.length, wire.length]);
+    const got = proc.demodulate();
+    const scans = X.scanBursts(got, [1, 1, 1]);
+    for (const r of scans) { assert.strictEqual(r.packets, 1); assert.strictEqual(Buffer.from(r.data).toString('ascii'), 'loopback over the GPU'); }
+    assert.strictEqual(proc.status(1).demodulatedBufferLength, 0);
+    proc.reset();
+    proc.close(); batch.close();
+  }
+  // ---- FIR (tests/dsp/filters.node.test.ts:190-206: impulse response = taps) ----
+  {
+    const taps = [0.1, -0.2, 0.3, 0.25, -0.05];
+    const f = new F.FIRFilter(taps);
+    const y = [];
+    for (let i = 0; i < 8; i++) y.push(f.process(i === 0 ? 1 : 0));
+    assert.deepStrictEqual(y, taps.map((t) => Math.fround(t)).concat([0, 0, 0]));
+    f.reset();
+    assert.strictEqual(f.process(1), Math.fround(0.1));
+    f.close();
+    const lp = F.FilterFactory.createFIRLowpass(1000, 48000);
+    assert.strictEqual(lp.getCoefficients().length, 51);
+    const dc = lp.processBuffer(new Float32Array(200).fill(1));
+    const gain = lp.getCoefficients().reduce((a, b) => a + b, 0);
+    assert.ok(Math.abs(dc[199] - gain) < 1e-6);       // DC gain = sum of taps
+    lp.close();
+  }
+  console.log('js next gpu tests ok');
+}
+
+(mode === 'gpu' ? gpuTests() : cpuTests()).catch((e) => { console.error(e); process.exit(1); });

@@ -11,6 +11,7 @@ from conftest import ROOT
 
 NODE = shutil.which("node")
 JS = os.path.join(ROOT, "tests", "js", "fsk_core_test.js")
+JS_NEXT = os.path.join(ROOT, "tests", "js", "next_rows_test.js")
 
 
 def _build():
@@ -36,3 +37,20 @@ def test_node_host_gpu_roundtrips():
     out = subprocess.run([NODE, JS, "gpu"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "js gpu tests ok" in out.stdout
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_node_next_rows_cpu_side():
+    _build()
+    out = subprocess.run([NODE, JS_NEXT, "cpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "js next cpu tests ok" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_node_next_rows_gpu():
+    _build()
+    out = subprocess.run([NODE, JS_NEXT, "gpu"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "js next gpu tests ok" in out.stdout

@@ -1,8 +1,8 @@
 // fsk_fir.hip -- batched FIRFilter (src/dsp/filters.ts:112-167) and the windowed-sinc designs (243-314), SURVEY.md 8(f3).
 //
 // Unlike the IIR chain a FIR has no recurrence, so the batch is parallel over time as well as over streams: one
-// workgroup filters a 1024-sample segment of one stream.  The segment (plus the n_taps-1 samples before it) and the
-// taps are staged in LDS; each lane produces 4 consecutive outputs from a sliding window of two float4, so a single
+// workgroup filters a 1024-sample segment of one stream.  The segment (plus the n_taps-1 samples before it) is
+// staged in LDS, the taps ride in SGPRs; each lane produces 4 consecutive outputs from a sliding window of two float4, so a single
 // conflict-free ds_read_b128 feeds 16 multiply-adds.  Every output still accumulates its products in the
 // reference's order (i = 0 .. n_taps-1, `output += c[i] * delay[i]`, doubles in the parity path).
 #include <hip/hip_runtime.h>
@@ -32,12 +32,14 @@ __device__ __forceinline__ float mac<float>(float acc, float c, float x) { retur
 template <typename Real>
 __global__ __launch_bounds__(kFirBlock) void fir_kernel(const float *__restrict__ in, size_t n, size_t in_pitch,
                                                         float *__restrict__ out, size_t out_pitch, int vec_ok,
-                                                        const float *__restrict__ hist, const double *__restrict__ taps,
+                                                        const float *__restrict__ hist, const Real *__restrict__ taps,
                                                         uint32_t n_taps, uint32_t tiles_per_row) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const uint32_t pad = ((n_taps - 1 + 3) & ~3u) + 4;  // floats in front of the segment, multiple of 4
   float *xs = reinterpret_cast<float *>(lds_raw);                 // [pad + kFirTile]
-  Real *cs = reinterpret_cast<Real *>(xs + pad + kFirTile);       // [n_taps] (offset is a multiple of 16 B)
+  // the taps are wave-uniform: indexed by the (uniform) loop counter straight from the kernel-argument pointer
+  // they come in through the scalar cache into SGPRs and cost no LDS or vector-memory traffic
+  const Real *cs = taps;
   const uint32_t row = blockIdx.x / tiles_per_row;
   const size_t t0 = (size_t)(blockIdx.x % tiles_per_row) * kFirTile;
   const float *xrow = in + (size_t)row * in_pitch;
@@ -49,7 +51,6 @@ __global__ __launch_bounds__(kFirBlock) void fir_kernel(const float *__restrict_
     else if (t >= -(int64_t)(n_taps - 1)) v = hrow[(int64_t)(n_taps - 1) + t];
     xs[i] = v;
   }
-  for (uint32_t i = threadIdx.x; i < n_taps; i += kFirBlock) cs[i] = (Real)taps[i];
   __syncthreads();
 
   const uint32_t j = threadIdx.x;
@@ -141,7 +142,8 @@ struct fskhip_fir {
   int device = 0;
   int precision = 0;
   uint32_t n_taps = 0, S = 0;
-  double *d_taps = nullptr;
+  double *d_taps = nullptr;   // coefficients as given (fp64 path)
+  float *d_taps32 = nullptr;  // rounded once on the host (fp32 path)
   float *hist[2] = {nullptr, nullptr};  // ping-pong: [cur] is read by the next call
   int cur = 0;
   hipStream_t stream = nullptr;
@@ -182,7 +184,7 @@ int fskhip_fir_destroy(fskhip_fir *f) {
   if (!f) return FSKHIP_OK;
   (void)hipSetDevice(f->device);
   (void)hipDeviceSynchronize();
-  void *bufs[] = {f->d_taps, f->hist[0], f->hist[1], f->d_in, f->d_out};
+  void *bufs[] = {f->d_taps, f->d_taps32, f->hist[0], f->hist[1], f->d_in, f->d_out};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (f->stream) (void)hipStreamDestroy(f->stream);
@@ -206,7 +208,13 @@ int fskhip_fir_create(int device, const double *taps, uint32_t n_taps, uint32_t 
   hipError_t err = hipMalloc((void **)&f->d_taps, sizeof(double) * n_taps);
   if (err == hipSuccess) err = hipMalloc((void **)&f->hist[0], hsz);
   if (err == hipSuccess) err = hipMalloc((void **)&f->hist[1], hsz);
+  if (err == hipSuccess) err = hipMalloc((void **)&f->d_taps32, sizeof(float) * n_taps);
   if (err == hipSuccess) err = hipMemcpy(f->d_taps, taps, sizeof(double) * n_taps, hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    std::vector<float> t32(n_taps);
+    for (uint32_t i = 0; i < n_taps; i++) t32[i] = (float)taps[i];
+    err = hipMemcpy(f->d_taps32, t32.data(), sizeof(float) * n_taps, hipMemcpyHostToDevice);
+  }
   if (err == hipSuccess) err = hipMemset(f->hist[0], 0, hsz);
   if (err == hipSuccess) err = hipMemset(f->hist[1], 0, hsz);
   if (err == hipSuccess) err = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
@@ -230,8 +238,7 @@ int fskhip_fir_process_device(fskhip_fir *f, const float *d_in, size_t n, size_t
   const uint32_t tiles = (uint32_t)((n + kFirTile - 1) / kFirTile);
   if ((uint64_t)tiles * f->S > 0x7FFFFFFFull) return fail(FSKHIP_E_INVALID, "too many tiles for one launch");
   const uint32_t pad = ((f->n_taps - 1 + 3) & ~3u) + 4;
-  const size_t real = f->precision == FSKHIP_PRECISION_F64 ? sizeof(double) : sizeof(float);
-  const size_t lds = sizeof(float) * (pad + kFirTile) + real * f->n_taps;
+  const size_t lds = sizeof(float) * (pad + kFirTile);
   const int vec_ok = (out_pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
   dim3 g(tiles * f->S), b(kFirBlock);
   if (f->precision == FSKHIP_PRECISION_F64)
@@ -239,7 +246,7 @@ int fskhip_fir_process_device(fskhip_fir *f, const float *d_in, size_t n, size_t
                        f->d_taps, f->n_taps, tiles);
   else
     hipLaunchKernelGGL(fir_kernel<float>, g, b, lds, st, d_in, n, in_pitch, d_out, out_pitch, vec_ok, f->hist[f->cur],
-                       f->d_taps, f->n_taps, tiles);
+                       f->d_taps32, f->n_taps, tiles);
   HIP_TRY(hipGetLastError());
   if (f->n_taps > 1) {
     const size_t total = (size_t)f->S * (f->n_taps - 1);
