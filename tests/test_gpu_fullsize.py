@@ -1,0 +1,162 @@
+"""BASELINE.json's full stream counts on the GPU (-m gpu), checked through size-independent properties:
+
+* chunking invariance -- one call over the whole buffer, 128-sample quanta (FSKProcessor's cadence) and a ragged
+  chunk schedule must give the SAME bytes and eod counts for EVERY stream (the reference is a streaming state
+  machine: fsk-demodulation.node.test.ts:363-398, 668-753 pin this for one stream);
+* a checksum of per-stream checksums equal across the schedules, and determinism of a repeated run;
+* the oracle on a strided sample of the same buffers (byte-identical);
+* decoded bytes contain the synthesised payload for the streams the reference decodes.
+
+Sizes: config #3's 65 536 streams (Bell-202) and 262 144 (the bench's four-waves-per-SIMD point), config #4's
+32 768 per-stream tone pairs, config #5's 16 384 streams through 10 dB AWGN.  Device buffers only (ctypes + the C ABI's
+own allocator), so the host never holds more than the sampled rows.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BELL = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
+SEED = 0xF5C0DE
+
+
+def _demod_schedule(eng, d_x, N, pitch, schedule):
+    """Run the device buffer through `eng` in the given chunk sizes; returns (list of bytes per stream, eod totals)."""
+    S = eng.n_streams
+    out_pitch = eng.max_bytes(max(schedule))
+    d_out = eng.device_malloc(S * out_pitch)
+    d_cnt = eng.device_malloc(S * 4)
+    d_eod = eng.device_malloc(S * 4)
+    got = [bytearray() for _ in range(S)]
+    eod_tot = np.zeros(S, np.int64)
+    out = np.empty((S, out_pitch), np.uint8)
+    cnt = np.empty(S, np.uint32)
+    eod = np.empty(S, np.uint32)
+    off, i = 0, 0
+    while off < N:
+        n = min(schedule[i % len(schedule)], N - off)
+        eng.demodulate_device(d_x + off * 4, n, pitch, d_out, out_pitch, d_cnt, d_eod)
+        eng.synchronize()
+        eng.d2h(cnt, d_cnt)
+        eng.d2h(eod, d_eod)
+        eod_tot += eod
+        if cnt.any():
+            assert int(cnt.max()) <= out_pitch
+            eng.d2h(out, d_out)
+            for s in np.nonzero(cnt)[0]:
+                got[s] += out[s, :cnt[s]].tobytes()
+        off += n
+        i += 1
+    for p in (d_out, d_cnt, d_eod):
+        eng.device_free(p)
+    return [bytes(g) for g in got], eod_tot
+
+
+def _digest(rows, eod):
+    per_stream = np.array([zlib.crc32(r) for r in rows], dtype=np.uint32)
+    return zlib.crc32(per_stream.tobytes() + eod.astype(np.int64).tobytes())
+
+
+@pytest.mark.parametrize("S,seconds", [(65536, 1.0), (262144, 0.25)], ids=["c3_65536", "bench_262144"])
+def test_full_size_chunking_invariance_and_oracle_sample(S, seconds):
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    N = int(seconds * 48000) // 128 * 128
+    pitch = N
+    gen = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    d_x = gen.device_malloc(S * pitch * 4)
+    gen.synth_device(d_x, N, pitch, 20, SEED, 400, 0.1, 1.0)
+    gen.synchronize()
+    results = {}
+    for name, schedule in (("one_call", [N]), ("quanta_128", [128]), ("ragged", [1000, 17, 4096, 3, 128, 2049])):
+        if name == "quanta_128" and S > 65536:
+            schedule = [256]
+        eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+        results[name] = _demod_schedule(eng, d_x, N, pitch, schedule)
+        eng.close()
+    base_rows, base_eod = results["one_call"]
+    base_digest = _digest(base_rows, base_eod)
+    for name, (rows, eod) in results.items():
+        if _digest(rows, eod) != base_digest:
+            bad = [s for s in range(S) if rows[s] != base_rows[s] or eod[s] != base_eod[s]]
+            raise AssertionError("%s differs from one_call on %d streams, first %s" % (name, len(bad), bad[:5]))
+    # determinism
+    eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    again = _demod_schedule(eng, d_x, N, pitch, [N])
+    eng.close()
+    assert _digest(*again) == base_digest
+    # the oracle on a strided sample of the same buffers, and payload round trips
+    row = np.empty(pitch, np.float32)
+    decoded = 0
+    sample = list(range(0, S, S // 48)) + [S - 1]
+    for s in sample:
+        gen.d2h(row, d_x + s * pitch * 4)
+        ob, oe = po.OracleCore(BELL).demodulate(row[:N])
+        assert base_rows[s] == ob, s
+        assert int(base_eod[s]) == oe, s
+        if gen.synth_payload(SEED, s, 0, 20) in base_rows[s]:
+            decoded += 1
+    assert decoded >= len(sample) * 0.6  # sanity only: the reference misses frames at some odd lead-ins, and so must we
+    total = sum(1 for s in range(S) if len(base_rows[s]) >= 20)
+    assert total >= S * 0.6, "only %d/%d streams produced a frame" % (total, S)
+    gen.device_free(d_x)
+    gen.close()
+
+
+def test_config4_per_stream_tones_full_size():
+    """BASELINE config #4: 32 768 streams, mark_s = 1000 + 10*(s mod 100), space_s = mark_s + 200, 300 baud."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    S = 32768
+    cfgs = [dict(baudRate=300, markFrequency=1000 + 10 * (s % 100), spaceFrequency=1200 + 10 * (s % 100)) for s in range(S)]
+    N = 48000  # one 16-byte frame at 300 baud is 30 560 samples
+    eng = wm.FSKEngine(S, cfgs, precision=wm.PRECISION_F32)
+    d_x = eng.device_malloc(S * N * 4)
+    eng.synth_device(d_x, N, N, 16, SEED, 1600, 0.1, 1.0)
+    eng.synchronize()
+    rows, eod = _demod_schedule(eng, d_x, N, N, [N])
+    eng2 = wm.FSKEngine(S, cfgs, precision=wm.PRECISION_F32)
+    rows2, eod2 = _demod_schedule(eng2, d_x, N, N, [128 * 7])
+    assert _digest(rows, eod) == _digest(rows2, eod2)
+    row = np.empty(N, np.float32)
+    ok = 0
+    sample = list(range(0, S, 331))
+    for s in sample:
+        eng.d2h(row, d_x + s * N * 4)
+        ob, oe = po.OracleCore(cfgs[s]).demodulate(row)
+        assert rows[s] == ob and int(eod[s]) == oe, s
+        ok += eng.synth_payload(SEED, s, 0, 16) in rows[s]
+    assert ok >= len(sample) * 0.6  # sanity only (bytes were already required to equal the oracle's)
+    eng.device_free(d_x)
+    eng.close()
+    eng2.close()
+
+
+def test_config5_awgn_full_size():
+    """BASELINE config #5: 16 384 streams modulate -> AWGN 10 dB -> demodulate, all on the GPU."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    S, N, P = 16384, 48000, 40
+    eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    d_x = eng.device_malloc(S * N * 4)
+    eng.synth_device(d_x, N, N, P, SEED, 400, 0.1, 1.0)
+    eng.add_awgn_device(d_x, N, N, 10.0, 0xA36)
+    eng.synchronize()
+    rows, eod = _demod_schedule(eng, d_x, N, N, [N])
+    eng2 = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    rows2, eod2 = _demod_schedule(eng2, d_x, N, N, [128])
+    assert _digest(rows, eod) == _digest(rows2, eod2)
+    row = np.empty(N, np.float32)
+    sample = list(range(0, S, 257))
+    for s in sample:
+        eng.d2h(row, d_x + s * N * 4)
+        ob, oe = po.OracleCore(BELL).demodulate(row)
+        assert rows[s] == ob and int(eod[s]) == oe, s
+    frames_ok = sum(1 for s in range(S) if eng.synth_payload(SEED, s, 0, P) in rows[s]) if S <= 4096 else \
+        sum(1 for s in sample if eng.synth_payload(SEED, s, 0, P) in rows[s]) * S // len(sample)
+    assert frames_ok >= S * 0.5  # sanity: at 10 dB the reference itself loses frames
+    eng.device_free(d_x)
+    eng.close()
+    eng2.close()
