@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--probe-reads", type=int, default=0,
                     help="also launch the read-pattern probe kernel this many times (FETCH_SIZE calibration)")
     ap.add_argument("--pitch-pad", type=int, default=0, help="extra floats of row pitch (experiments)")
+    ap.add_argument("--literal-streams", type=int, default=65536,
+                    help="also time this many streams (BASELINE config #3's count) on rank 0; 0 = skip")
     ap.add_argument("--snr-db", type=float, default=None, help="add AWGN at this SNR (BASELINE config #5 shape)")
     args = ap.parse_args()
 
@@ -158,6 +160,28 @@ def main():
     from webaudio_modem_amd.sharding import max_over_ranks
     elapsed = max_over_ranks(elapsed, dist, "cuda")
 
+    # BASELINE config #3's literal stream count (65 536 on one GPU = one wave per SIMD), measured beside the headline
+    # on the first 65 536 rows of the same buffer: reported in `config`, never as `value`
+    literal = None
+    if rank == 0 and args.literal_streams and args.literal_streams < S:
+        Sl = args.literal_streams
+        eng_l = wm.FSKEngine(Sl, cfg, device=local_rank, precision=prec)
+
+        def step_l():
+            eng_l.demodulate_device(x.data_ptr(), N, pitch, out.data_ptr(), out_pitch, counts.data_ptr(), eod.data_ptr(), 0, stream)
+        step_l()
+        torch.cuda.synchronize()
+        eng_l.timing_begin()
+        for _ in range(args.steps):
+            step_l()
+        torch.cuda.synchronize()
+        nl, ms_l = eng_l.timing_end()
+        rate = Sl * N * nl / (ms_l / 1e3) / 1e6
+        literal = {"streams": Sl, "kernel": "fsk::demod_split_kernel<false> (two waves per 64-stream group; chosen by the library "
+                   "when a batch gives the SIMDs at most one wave each)", "Msamples_per_s": round(rate, 1), "algorithmic_GBps": round(rate * 4 / 1e3, 1),
+                   "frac_of_hbm_peak": round(rate * 4 / 1e3 / HBM_PEAK_GBS, 4), "avg_kernel_ms": round(ms_l / max(1, nl), 4)}
+        eng_l.close()
+
     total_samples = float(S) * N * args.steps * world
     value = total_samples / elapsed / 1e6
     alg_bytes_per_launch = 4.0 * S * N  # 4 B read per input sample
@@ -187,6 +211,7 @@ def main():
                 "streams_per_gpu": S, "samples_per_stream": N, "row_pitch_floats": pitch,
                 "parallelism": "streams sharded across %d GPU(s), no collective" % world,
                 "decoded_bytes_first_pass_rank0": decoded,
+                "same_kernel_at_config3_stream_count": literal,
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

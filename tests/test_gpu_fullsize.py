@@ -60,7 +60,7 @@ def _digest(rows, eod):
 
 
 @pytest.mark.parametrize("S,seconds", [(65536, 1.0), (262144, 0.25)], ids=["c3_65536", "bench_262144"])
-def test_full_size_chunking_invariance_and_oracle_sample(S, seconds):
+def test_full_size_chunking_invariance_and_oracle_sample(S, seconds, monkeypatch):
     import webaudio_modem_amd as wm
     from oracle import pyoracle as po
     N = int(seconds * 48000) // 128 * 128
@@ -82,11 +82,17 @@ def test_full_size_chunking_invariance_and_oracle_sample(S, seconds):
         if _digest(rows, eod) != base_digest:
             bad = [s for s in range(S) if rows[s] != base_rows[s] or eod[s] != base_eod[s]]
             raise AssertionError("%s differs from one_call on %d streams, first %s" % (name, len(bad), bad[:5]))
-    # determinism
+    # determinism, and the other whole-tile kernel (one wave per group <-> two-wave split) on the same buffer
     eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
     again = _demod_schedule(eng, d_x, N, pitch, [N])
     eng.close()
     assert _digest(*again) == base_digest
+    monkeypatch.setenv("FSKHIP_SPLIT", "0" if S <= 65536 else "1")
+    eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    other = _demod_schedule(eng, d_x, N, pitch, [N // 2 // 16 * 16, N])
+    eng.close()
+    monkeypatch.delenv("FSKHIP_SPLIT")
+    assert _digest(*other) == base_digest
     # the oracle on a strided sample of the same buffers, and payload round trips
     row = np.empty(pitch, np.float32)
     decoded = 0

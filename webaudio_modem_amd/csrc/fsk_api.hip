@@ -24,6 +24,10 @@ bool demod_fast_applicable(int precision, bool uniform_even, const DemodParams &
 hipError_t launch_demod_fast(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream);
+hipError_t launch_demod_split(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
+                              uint32_t *eod_counts, hipStream_t stream);
+size_t demod_split_lds_bytes(const DemodParams &P);
 hipError_t set_demod_lds_limit(size_t lds_bytes);
 size_t demod_lds_bytes(const DemodParams &P);
 hipError_t launch_modulate(const ModParams &M, const double *coef, const uint8_t *payloads, const uint32_t *lens,
@@ -126,6 +130,7 @@ struct fskhip_engine {
   bool ds_uniform = true;
   uint32_t ds_parity = 0;        // downsample.counter shared by all streams while ds_uniform
   bool force_generic = false;    // FSKHIP_FORCE_GENERIC=1: never use the fast kernel (tests)
+  bool use_split = false;        // two waves per 64-stream group (demod_split_kernel): batches of at most one wave per SIMD
   bool demod_ok = true;          // false: configuration the demodulator kernels do not implement
   std::string demod_why;
   uint32_t trace_cap = 0;
@@ -156,6 +161,7 @@ size_t engine_max_bytes(const fskhip_engine *e, size_t n_per_stream) {
 // everything fskhip_demodulate_device's choice of launches depends on besides its arguments
 uint32_t engine_launch_key(const fskhip_engine *e) {
   return (e->ds_uniform ? 1u : 0u) | (e->ds_parity << 1) | (e->force_generic ? 4u : 0u) | (e->timing ? 8u : 0u) |
+         (e->use_split ? 32u : 0u) |
          (e->S.trace_stream != 0xFFFFFFFFu ? 16u : 0u);
 }
 void engine_note_replayed_call(fskhip_engine *e, size_t n) {
@@ -281,6 +287,16 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   if (!e) return fail(FSKHIP_E_NOMEM, "out of host memory");
   e->device = device; e->precision = precision; e->n_streams = n_streams; e->cfg0 = c0;
   if (const char *fg = getenv("FSKHIP_FORCE_GENERIC")) e->force_generic = fg[0] == '1';
+  {
+    // with at most one wave per SIMD the one-wave-per-group kernel cannot hide its own dependency stalls; the
+    // split kernel gives every group two instruction streams (measured: +12 % at 65 536 streams, +17 % at 4 096,
+    // no gain from 131 072 up).  FSKHIP_SPLIT=0/1 overrides (tests, measurements).
+    hipDeviceProp_t prop;
+    int simds = 1024;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) simds = prop.multiProcessorCount * 4;
+    e->use_split = (n_streams + 63) / 64 <= (uint32_t)simds;
+    if (const char *sp = getenv("FSKHIP_SPLIT")) e->use_split = sp[0] == '1';
+  }
 
   // calculateParameters (fsk.ts:426-444), in doubles like the reference
   const double downsampleRate = c0.sampleRate / 2;
@@ -508,8 +524,11 @@ int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_
     if (!e->force_generic && demod_fast_applicable(e->precision, e->ds_uniform && e->ds_parity == 0, e->P,
                                                    e->S, d_samples, pitch))
       n_fast = n & ~(size_t)15;
-    if (n_fast) HIP_TRY(launch_demod_fast(wb, e->P, e->S, d_samples, n_fast, pitch, d_out, out_pitch, d_out_counts,
-                                          d_eod_counts, st));
+    if (n_fast && e->use_split && demod_split_lds_bytes(e->P) <= 64 * 1024)
+      HIP_TRY(launch_demod_split(wb, e->P, e->S, d_samples, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+    else if (n_fast)
+      HIP_TRY(launch_demod_fast(wb, e->P, e->S, d_samples, n_fast, pitch, d_out, out_pitch, d_out_counts,
+                                d_eod_counts, st));
     if (n_fast < n || n == 0)
       HIP_TRY(launch_demod(e->precision, e->ds_uniform, wb, n_fast != 0, e->P, e->S, d_samples + n_fast, n - n_fast,
                            pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));

@@ -1145,6 +1145,233 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
 #undef FSK_BLOAD4
 }
 
+
+// ================================================================================================
+// Split variant of the fast kernel for batches too small to give every SIMD more than one wave (one wave per
+// 64 streams cannot hide its own dependency stalls): TWO waves share a 64-stream group as a two-stage pipeline
+// over 16-sample tiles.  Wave 0 ("front") stages the raw tile, runs AGC + pre-filter and leaves the filtered
+// samples in a double-buffered LDS tile; wave 1 ("back") runs NCO / mix / low-pass / discriminator / state machine
+// one tile behind.  The cut is where the reference's resetState() stops reaching (fsk.ts:175-188 resets neither
+// the AGC nor the pre-filter), so a reset in the back wave never invalidates anything the front wave has produced.
+// One s_barrier per tile.  Same arithmetic, same state layout, interchangeable with demod_fast_kernel call by
+// call.  (A more even cut -- NCO, mixer and I/Q low-pass in the front wave too, run speculatively and repaired
+// after a reset -- was built, passed parity, and was slower: 269 vs 285 Gsamples/s at 65 536 streams; the lock
+// step of the two waves costs more than the better balance gains.  Dealing the roles by CU arrival order read
+// from HW_ID made no difference either.)
+// ================================================================================================
+template <bool WB>
+__global__ __launch_bounds__(128) void demod_split_kernel(
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch,
+    uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
+    uint32_t *__restrict__ eod_counts) {
+  extern __shared__ float4 lds[];
+  v4f *stage = reinterpret_cast<v4f *>(lds);                                  // [4 chunks][kSlotStride]
+  v4f *ybuf = reinterpret_cast<v4f *>(lds + 4 * kSlotStride);                 // [2 tiles][4 chunks][64 lanes]
+  uint32_t *poly = (uint32_t *)(lds + 4 * kSlotStride + 2 * 4 * 64);          // [d][64]
+  uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
+
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t stream = blockIdx.x * 64u + lane;
+  const bool valid = stream < P.n_streams;
+  const uint32_t row = valid ? stream : P.n_streams - 1;
+  const uint32_t fld = P.n_streams * 4u;
+  const __amdgpu_buffer_rsrc_t rs_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.rs, 0, (int)(fld * RF_COUNT), 0x00020000);
+  const __amdgpu_buffer_rsrc_t cf_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)S.coef, 0, (int)(2u * fld * CF_COUNT), 0x00020000);
+  const uint32_t row4 = row * 4u;
+  const uint32_t voff = valid ? row * 4u : 0xFFFFFFF0u;
+  const size_t n_tiles = n / kFastTile;
+#define RLOAD(f) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rsrc, row4, (uint32_t)RF_##f * fld, 0))
+#define CLOAD(f) ((float)__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cf_rsrc, row4 * 2u, (uint32_t)(f) * fld * 2u, 0)))
+#define RSTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)(v)), rs_rsrc, voff, (uint32_t)RF_##f * fld, 0)
+  // LDS hand-off: this wave's ds ops are done, then the workgroup barrier
+#define TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+  if (wave == 0) {
+    // ------------------------------------------------------------------ front: AGC + pre-filter
+    float g = RLOAD(agc_gain), bx1 = RLOAD(bp_x1), bx2 = RLOAD(bp_x2), by1 = RLOAD(bp_y1), by2 = RLOAD(bp_y2);
+    const float bp_b0 = (float)(__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cf_rsrc, row4 * 2u, (uint32_t)CF_bp_b0 * fld * 2u, 0)) * (0.5 * P.lp_b0));
+    const float bp_a1 = CLOAD(CF_bp_a1), bp_a2 = CLOAD(CF_bp_a2);
+    const float agc_att = P.f_agc_att, agc_rel = P.f_agc_rel;
+    // per-wave descriptor over this group's 64 rows; rows beyond the batch read as 0 through the bounds check
+    const uint32_t sub_row = lane >> 2, chunk = lane & 3;
+    const uint32_t rows_here = P.n_streams - blockIdx.x * 64u < 64u ? P.n_streams - blockIdx.x * 64u : 64u;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        samples + (size_t)blockIdx.x * 64u * pitch, 0, (int)(uint32_t)(rows_here * pitch * 4u), 0x00020000);
+    const uint32_t in_voff = (uint32_t)((sub_row * pitch + 4u * chunk) * 4u);
+    const uint32_t in_row16 = (uint32_t)(16u * pitch * 4u);
+    const uint32_t st_slot = chunk * kSlotStride + sub_row;
+    // compiler-visible loads: this wave has a quarter of the back wave's arithmetic per tile, so the vmcnt waits
+    // hipcc places (conservative at the loop header) are hidden behind the barrier it would wait at anyway
+    auto load_tile = [&](size_t t, v4f &a, v4f &b, v4f &c, v4f &d) {
+      const uint32_t tn = (uint32_t)((t < n_tiles ? t : n_tiles - 1) * kFastTile * 4u);
+      a = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff, tn, 0));
+      b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff, tn + in_row16, 0));
+      c = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff, tn + 2u * in_row16, 0));
+      d = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff, tn + 3u * in_row16, 0));
+    };
+    v4f a0, a1, a2, a3, b0, b1, b2, b3;
+    load_tile(0, a0, a1, a2, a3);
+    load_tile(1, b0, b1, b2, b3);
+    for (size_t t = 0; t <= n_tiles; t++) {
+      if (t < n_tiles) {
+        stage[st_slot] = a0; stage[st_slot + 16] = a1; stage[st_slot + 32] = a2; stage[st_slot + 48] = a3;
+        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+        load_tile(t + 2, b0, b1, b2, b3);
+        v4f *yb = ybuf + (t & 1) * 256u;
+#pragma unroll 1
+        for (uint32_t c = 0; c < 4; c++) {
+          const v4f x4 = stage[c * kSlotStride + lane];   // written by this wave: a wave's ds ops are ordered
+          const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
+          float xs[4], y[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            // AGC (fsk.ts:52-76), branch-free; exact zero holds the gain
+            const float xv = xin[j] * g;
+            xs[j] = xv;
+            const float level = __builtin_fabsf(xv);
+            const float tt = __builtin_fmaf(0.5f, __builtin_amdgcn_rcpf(level), -g);
+            const float rate = level > 0.5f ? agc_att : agc_rel;
+            float gn = __builtin_fmaf(tt, rate, g);
+            gn = level > 0.0f ? gn : g;
+            g = __builtin_amdgcn_fmed3f(gn, 0.1f, 10.0f);
+            // pre-filter (filters.ts:47-87): y = b0*(x - x2) - a2*y2 - a1*y1
+            float v = bp_b0 * (xv - bx2);
+            v = __builtin_fmaf(-bp_a2, by2, v);
+            v = __builtin_fmaf(-bp_a1, by1, v);
+            bx2 = bx1; bx1 = xv;
+            by2 = by1; by1 = v;
+            y[j] = v;
+          }
+          yb[c * 64u + lane] = (v4f){y[0], y[1], y[2], y[3]};
+          if (WB) {
+            if (valid) *reinterpret_cast<v4f *>(samples + (size_t)row * pitch + t * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
+          }
+        }
+      }
+      TILE_BARRIER();
+    }
+    RSTORE(agc_gain, g);
+    RSTORE(bp_x1, bx1); RSTORE(bp_x2, bx2); RSTORE(bp_y1, by1); RSTORE(bp_y2, by2);
+  } else {
+    // ------------------------------------------------------------------ back: everything resetState() reaches
+    FastMem M;
+    M.is_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.is, 0, (int)(fld * IF_COUNT), 0x00020000);
+    M.fld = fld;
+    M.voff = voff;
+#define ILOAD(f) __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, row4, (uint32_t)IF_##f * fld, 0)
+#define ISTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(v), M.is_rsrc, M.voff, (uint32_t)IF_##f * fld, 0)
+    FastLane F;
+    F.g = 0.f; F.bx1 = 0.f; F.bx2 = 0.f; F.by1 = 0.f; F.by2 = 0.f;   // front-wave state, unused here
+    F.lx1 = (f2){RLOAD(li_x1), RLOAD(lq_x1)}; F.lx2 = (f2){RLOAD(li_x2), RLOAD(lq_x2)};
+    F.ly = (f2){RLOAD(li_y1), RLOAD(lq_y1)}; F.lv = (f2){RLOAD(li_y2), RLOAD(lq_y2)};
+    F.px1 = RLOAD(po_x1); F.px2 = RLOAD(po_x2); F.py = RLOAD(po_y1); F.pv = RLOAD(po_y2);
+    F.last_phase = RLOAD(last_phase); F.thr = RLOAD(sil_thr);
+    F.nco_lo = ILOAD(nco_lo); F.nco_hi = ILOAD(nco_hi);
+    F.cad = ILOAD(cad_ctr); F.sil = ILOAD(sil_cnt); F.acc = ILOAD(bit_acc); F.wait = ILOAD(bit_wait);
+    F.reload = ILOAD(bit_reload); F.byte_cur = ILOAD(byte_cur); F.bit_pos = ILOAD(bit_pos);
+    F.matched = ILOAD(matched);
+    F.thr_eff = ILOAD(started) ? kStarted : P.matched_min;
+    F.out_cnt = 0;
+    if (valid && eod_counts) eod_counts[stream] = 0;
+    FastConst K;
+    K.bp_b0 = 0.f; K.bp_a1 = 0.f; K.bp_a2 = 0.f;
+    K.w1 = (f2){CLOAD(CF_w1_re), CLOAD(CF_w1_im)};
+    {
+      const uint64_t inc = S.nco_inc[row];
+      K.inc2_lo = (uint32_t)(inc << 1); K.inc2_hi = (uint32_t)((inc << 1) >> 32);
+    }
+    FastUni U;
+    U.lp_b0 = P.f_lp_b0; U.lp_a2 = P.f_lp_a2; U.lp_delta = P.f_lp_delta;
+    U.agc_att = P.f_agc_att; U.agc_rel = P.f_agc_rel;
+    U.a2v = bc2(P.f_lp_a2); U.ndv = bc2(-P.f_lp_delta);
+    for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
+    uint32_t phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)ILOAD(poly_phase));
+    const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ILOAD(amp_pos));
+    uint32_t k = 0;
+    const uint32_t amp_row_bytes = P.n_streams * 4u;
+    uint32_t amp_soff = amp_pos0 * amp_row_bytes;
+    const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
+    const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
+
+    for (size_t t = 0; t <= n_tiles; t++) {
+      if (t > 0) {
+        const v4f *yb = ybuf + ((t - 1) & 1) * 256u;
+#pragma unroll 1
+        for (uint32_t c = 0; c < 4; c++) {
+          const v4f y4 = yb[c * 64u + lane];
+          const uint32_t ph0 = phase, ph1 = (phase + 1 == P.d) ? 0u : phase + 1;
+          const uint32_t r0 = poly[ph0 * 64u + lane];
+          const uint32_t r1 = poly[ph1 * 64u + lane];
+          const float yin[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            // NCO (fsk.ts:228-232): first sample from the exact 64-bit turn accumulator, second = first * e^{j omega}
+            const float turns = (float)F.nco_hi * 2.3283064365386963e-10f;
+            const f2 z0 = (f2){__builtin_amdgcn_cosf(turns), __builtin_amdgcn_sinf(turns)};
+            const f2 z1 = cmul(z0, K.w1);
+            {
+              const uint32_t lo = F.nco_lo + K.inc2_lo;
+              F.nco_hi = F.nco_hi + K.inc2_hi + (lo < F.nco_lo ? 1u : 0u);
+              F.nco_lo = lo;
+            }
+            const f2 o0 = fast_lp2(F, U, bc2(yin[2 * h]) * z0);
+            const f2 o1 = fast_lp2(F, U, bc2(yin[2 * h + 1]) * z1);
+            float amp;
+            const bool bit = fast_disc(F, U, o0 + o1, amp);
+            k++;
+            fast_fsm(F, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, bit, amp, h ? r1 : r0,
+                     h ? ph1 : ph0, k, amp_soff);
+            amp_soff += amp_row_bytes; if (amp_soff == amp_wrap) amp_soff = 0;
+          }
+          phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
+        }
+      }
+      TILE_BARRIER();
+    }
+
+    for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
+    RSTORE(li_x1, F.lx1.x); RSTORE(lq_x1, F.lx1.y); RSTORE(li_x2, F.lx2.x); RSTORE(lq_x2, F.lx2.y);
+    RSTORE(li_y1, F.ly.x); RSTORE(lq_y1, F.ly.y); RSTORE(li_y2, F.lv.x); RSTORE(lq_y2, F.lv.y);
+    RSTORE(po_x1, F.px1); RSTORE(po_x2, F.px2); RSTORE(po_y1, F.py); RSTORE(po_y2, F.pv);
+    RSTORE(last_phase, F.last_phase); RSTORE(sil_thr, F.thr);
+    ISTORE(nco_lo, F.nco_lo); ISTORE(nco_hi, F.nco_hi);
+    ISTORE(cad_ctr, F.cad); ISTORE(sil_cnt, F.sil); ISTORE(bit_acc, F.acc); ISTORE(bit_wait, F.wait);
+    ISTORE(bit_reload, F.reload); ISTORE(byte_cur, F.byte_cur); ISTORE(bit_pos, F.bit_pos);
+    ISTORE(started, F.thr_eff == kStarted ? 1u : 0u); ISTORE(matched, F.matched);
+    ISTORE(gsc, k + ILOAD(gsc));
+    const uint32_t rl = ILOAD(ring_len) + k, al = ILOAD(amp_len) + k;
+    ISTORE(ring_len, rl < P.ring_cap ? rl : P.ring_cap);
+    ISTORE(amp_len, al < P.amp_cap ? al : P.amp_cap);
+    ISTORE(poly_phase, phase);
+    ISTORE(amp_pos, amp_soff / amp_row_bytes);
+    if (valid) out_counts[stream] = F.out_cnt;
+#undef ILOAD
+#undef ISTORE
+  }
+#undef RLOAD
+#undef CLOAD
+#undef RSTORE
+#undef TILE_BARRIER
+}
+
+size_t demod_split_lds_bytes(const DemodParams &P) {
+  return sizeof(float4) * (4 * kSlotStride + 2 * 4 * 64) + sizeof(uint32_t) * 64u * P.d;
+}
+hipError_t launch_demod_split(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
+                              uint32_t *eod_counts, hipStream_t stream) {
+  const uint32_t blocks = (P.n_streams + 63u) / 64u;
+  if (writeback)
+    hipLaunchKernelGGL(demod_split_kernel<true>, dim3(blocks), dim3(128), demod_split_lds_bytes(P), stream, P, S,
+                       samples, n, pitch, out, out_pitch, out_counts, eod_counts);
+  else
+    hipLaunchKernelGGL(demod_split_kernel<false>, dim3(blocks), dim3(128), demod_split_lds_bytes(P), stream, P, S,
+                       samples, n, pitch, out, out_pitch, out_counts, eod_counts);
+  return hipGetLastError();
+}
+
 size_t demod_fast_lds_bytes(const DemodParams &P) { return sizeof(float4) * 4 * kSlotStride + sizeof(uint32_t) * 64u * P.d; }
 
 // The fast kernel applies to fp32 engines with narrow integer-capacity rings whose streams are in lock
