@@ -1220,9 +1220,11 @@ __global__ __launch_bounds__(128) void demod_split_kernel(
         a0 = b0; a1 = b1; a2 = b2; a3 = b3;
         load_tile(t + 2, b0, b1, b2, b3);
         v4f *yb = ybuf + (t & 1) * 256u;
+        v4f xnext = stage[lane];                          // written by this wave: a wave's ds ops are ordered
 #pragma unroll 1
         for (uint32_t c = 0; c < 4; c++) {
-          const v4f x4 = stage[c * kSlotStride + lane];   // written by this wave: a wave's ds ops are ordered
+          const v4f x4 = xnext;
+          xnext = stage[(c < 3 ? c + 1 : 3u) * kSlotStride + lane];
           const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
           float xs[4], y[4];
 #pragma unroll
@@ -1298,9 +1300,11 @@ __global__ __launch_bounds__(128) void demod_split_kernel(
     for (size_t t = 0; t <= n_tiles; t++) {
       if (t > 0) {
         const v4f *yb = ybuf + ((t - 1) & 1) * 256u;
+        v4f ynext = yb[lane];
 #pragma unroll 1
         for (uint32_t c = 0; c < 4; c++) {
-          const v4f y4 = yb[c * 64u + lane];
+          const v4f y4 = ynext;
+          ynext = yb[(c < 3 ? c + 1 : 3u) * 64u + lane];   // next chunk's read in flight while this one computes
           const uint32_t ph0 = phase, ph1 = (phase + 1 == P.d) ? 0u : phase + 1;
           const uint32_t r0 = poly[ph0 * 64u + lane];
           const uint32_t r1 = poly[ph1 * 64u + lane];
