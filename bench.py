@@ -226,6 +226,7 @@ def main():
         print(json.dumps(line))
     eng.close()
     if dist is not None:
+        dist.barrier()  # rank 0 may still have been timing the extra stream count
         dist.destroy_process_group()
 
 
