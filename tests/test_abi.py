@@ -148,10 +148,11 @@ def test_fast_kernel_never_spills():
     import check_isa
     res = check_isa.kernel_resources()
     fast = {k: v for k, v in res.items() if "demod_fast_kernel" in k}
-    assert len(fast) == 2
+    assert len(fast) == 4  # <write-back, uniform-constants>
     for name, v in fast.items():
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
-    plain = [v for k, v in fast.items() if "ILb0E" in k][0]
-    assert plain["VGPRs"] <= 128, plain
+    for k, v in fast.items():
+        if "ILb0E" in k:  # the plain (no write-back) variants are built for 4 waves per SIMD
+            assert v["VGPRs"] <= 128, (k, v)
     # the registers the asm prefetch lands in are never touched while a load may still be in flight
     assert check_isa.prefetch_register_hazards() == []

@@ -53,8 +53,8 @@ def prefetch_register_hazards():
 
     problems = []
     found = list(re.finditer(r"^(_ZN3fsk17demod_fast_kernel\w+):[^\n]*\n", text, re.M))
-    if len(found) != 2:
-        problems.append(("demod_fast_kernel", "expected 2 kernel bodies in the ISA, found %d" % len(found)))
+    if len(found) != 4:
+        problems.append(("demod_fast_kernel", "expected 4 kernel bodies in the ISA, found %d" % len(found)))
     for m in found:
         body = text[m.end():text.index(".Lfunc_end", m.end())].split("\n")
         loads = [i for i, l in enumerate(body) if "buffer_load_dwordx4" in l]

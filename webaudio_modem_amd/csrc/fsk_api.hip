@@ -445,6 +445,20 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     inc[s] = scaled >= 18446744073709551615.0L ? 0xFFFFFFFFFFFFFFFFull : (uint64_t)(scaled + 0.5L);
   }
 
+  P.uni_cfg = n_cfgs == 1 ? 1u : 0u;
+  {
+    const double b0 = coef[(size_t)CF_bp_b0 * n_streams], a1 = coef[(size_t)CF_bp_a1 * n_streams],
+                 a2 = coef[(size_t)CF_bp_a2 * n_streams];
+    P.u_bp_b0h = (float)(b0 * (0.5 * P.lp_b0));
+    P.u_bp_na1 = (float)(-a1); P.u_bp_na2 = (float)(-a2);
+    P.u_bp_c1y = (float)(a1 * a1 - a2); P.u_bp_c2y = (float)(a1 * a2);
+    P.u_w1_re = (float)coef[(size_t)CF_w1_re * n_streams]; P.u_w1_im = (float)coef[(size_t)CF_w1_im * n_streams];
+    P.u_w2_re = (float)coef[(size_t)CF_w2_re * n_streams]; P.u_w2_im = (float)coef[(size_t)CF_w2_im * n_streams];
+    const uint64_t inc2 = inc[0] << 1, inc16 = inc[0] << 4;
+    P.u_inc2_lo = (uint32_t)inc2; P.u_inc2_hi = (uint32_t)(inc2 >> 32);
+    P.u_inc16_lo = (uint32_t)inc16; P.u_inc16_hi = (uint32_t)(inc16 >> 32);
+  }
+
 #define CREATE_TRY(expr)                                                                          \
   do {                                                                                            \
     hipError_t _e = (expr);                                                                       \

@@ -779,8 +779,21 @@ __device__ inline void ist_store(const FastMem &M, uint32_t field, uint32_t v) {
 }
 
 // resetState() fsk.ts:175-188.  globalSampleCounter = k + koff with koff kept in the gsc state word.
-__device__ inline void fast_reset(FastLane &F, const FastMem &M, uint32_t k, uint32_t matched_min) {
-  F.nco_lo = 0; F.nco_hi = 0;
+// UNI (demod_fast_kernel with wave-uniform constants): the NCO runs as a phasor recurrence that is re-seeded from
+// the exact 64-bit accumulator at every tile top, and the accumulator only advances per tile (+16 steps); a reset
+// after pair p of the tile (k counts pairs of this launch, tiles are 8 pairs) restarts the phasor at 1 and sets the
+// accumulator so that the tile-end advance lands on the phase of the next tile's first sample: -(p+1) pair steps.
+template <bool UNI>
+__device__ inline void fast_reset(FastLane &F, const FastMem &M, uint32_t k, uint32_t matched_min, f2 &z,
+                                  uint32_t inc2_lo, uint32_t inc2_hi) {
+  if (UNI) {
+    const uint64_t back = (uint64_t)(((k - 1u) & 7u) + 1u) * (((uint64_t)inc2_hi << 32) | inc2_lo);
+    const uint64_t acc = 0ull - back;
+    F.nco_lo = (uint32_t)acc; F.nco_hi = (uint32_t)(acc >> 32);
+    z = (f2){1.0f, 0.0f};
+  } else {
+    F.nco_lo = 0; F.nco_hi = 0;
+  }
   F.last_phase = 0.0f;
   ist_store(M, IF_gsc, 0u - k);
   F.cad = 0;
@@ -810,10 +823,9 @@ __device__ inline bool fast_disc(FastLane &F, const FastUni &U, f2 sum, float &a
   const float PI = 3.14159265358979323846f;
   const float phase = atan2_fast(sum.y, sum.x);
   amp = __builtin_amdgcn_sqrtf(__builtin_fmaf(sum.x, sum.x, sum.y * sum.y));
+  // wrap into (-pi, pi] (fsk.ts:255-257): |dphi| <= 2 pi, so one rounded quotient does both branches
   float dphi = phase - F.last_phase;
-  float wrap = dphi > PI ? -2.0f * PI : 0.0f;
-  wrap = dphi < -PI ? 2.0f * PI : wrap;
-  dphi += wrap;
+  dphi = __builtin_fmaf(-2.0f * PI, __builtin_rintf(dphi * (0.5f / PI)), dphi);
   F.last_phase = phase;
   const float f = lp32(U.lp_b0, U.lp_a2, U.lp_delta, F.px1, F.px2, F.py, F.pv, dphi);
   return f > 0.0f;
@@ -821,10 +833,12 @@ __device__ inline bool fast_disc(FastLane &F, const FastUni &U, f2 sum, float &a
 
 // processDownsampledBit (fsk.ts:278-344); k = pushes of this launch including this one (SGPR),
 // phase = push slot (SGPR), amp_soff = byte offset of the amplitude-ring row (SGPR).
+template <bool UNI>
 __device__ inline void fast_fsm(FastLane &F, const DemodParams &P, const DemodState &S, const FastMem &M,
                                 uint32_t *poly, uint32_t lane, __amdgpu_buffer_rsrc_t amp_rsrc, uint8_t *out,
                                 uint32_t out_pitch, uint32_t *eod_counts, bool bitb, float amp, uint32_t r_old,
-                                uint32_t phase, uint32_t k, uint32_t amp_soff) {
+                                uint32_t phase, uint32_t k, uint32_t amp_soff, f2 &z, uint32_t inc2_lo,
+                                uint32_t inc2_hi) {
   const uint32_t qn = ~(uint32_t)P.pat_q, mask = (uint32_t)P.pat_mask;
   const uint32_t bit = bitb ? 1u : 0u;
   // syncSamplesBuffer.put(bit)
@@ -851,7 +865,7 @@ __device__ inline void fast_fsm(FastLane &F, const DemodParams &P, const DemodSt
     if (eod) {                                                   // fsk.ts:288-291
       ist_store(M, IF_eod_total, ist_load(M, IF_eod_total) + 1u);
       if (eod_counts && M.voff < 0xFFFFFFF0u) eod_counts[M.voff >> 2] += 1u;
-      fast_reset(F, M, k, P.matched_min);
+      fast_reset<UNI>(F, M, k, P.matched_min, z, inc2_lo, inc2_hi);
     }
     // ring length >= preamble window? (fsk.ts:302); ring_len / amp_len in HBM hold the launch-start values
     bool sync_now = false;
@@ -909,7 +923,7 @@ __device__ inline void fast_fsm(FastLane &F, const DemodParams &P, const DemodSt
       }
     }
     if (__builtin_amdgcn_ballot_w64(bad_start | bad_stop | stale)) {
-      if (bad_start) fast_reset(F, M, k, P.matched_min);                          // fsk.ts:352-355
+      if (bad_start) fast_reset<UNI>(F, M, k, P.matched_min, z, inc2_lo, inc2_hi);   // fsk.ts:352-355
       if (bad_stop) { F.thr_eff = P.matched_min; F.wait = kBigWait; F.bit_pos = P.stop_pos; }  // fsk.ts:363-366
       if (stale) F.wait = kBigWait;
     }
@@ -926,7 +940,13 @@ __device__ inline void fast_fsm(FastLane &F, const DemodParams &P, const DemodSt
 
 // WB: also write the AGC-scaled samples back (fsk.ts:55); that variant keeps four more values live per
 // chunk and is built for 3 waves/SIMD, the plain one for FSK_FAST_WAVES (4: 128 VGPRs).
-template <bool WB>
+// UNI: every stream shares one configuration (DemodParams::uni_cfg): pre-filter coefficients, NCO phasors and
+// increments are wave-uniform constants in SGPRs instead of seven VGPRs per lane, which pays for
+//   * the pre-filter evaluated two samples at a time in look-ahead form as packed math,
+//     (y0, y1) = (u0, u1 - a1 u0) + (-a1, a1^2 - a2) y[-1] + (-a2, a1 a2) y[-2]        (5 instructions instead of 8),
+//   * the NCO as a phasor recurrence z <- z e^{2j omega} per pair, re-seeded from the exact 64-bit turn accumulator
+//     with v_cos/v_sin at every tile top (8 pairs: drift <= 1e-6), the accumulator advancing once per tile.
+template <bool WB, bool UNI>
 __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kernel(
     DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
@@ -972,13 +992,21 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
   if (valid && eod_counts) eod_counts[stream] = 0;  // incremented in memory by the (rare) EOD path
 
   FastConst K;
-  K.bp_b0 = (float)(__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cf_rsrc, row4 * 2u, (uint32_t)CF_bp_b0 * fld * 2u, 0)) * (0.5 * P.lp_b0));
-  K.bp_a1 = CLOAD(CF_bp_a1); K.bp_a2 = CLOAD(CF_bp_a2);
-  K.w1 = (f2){CLOAD(CF_w1_re), CLOAD(CF_w1_im)};
-  {
+  if (UNI) {
+    K.bp_b0 = P.u_bp_b0h; K.bp_a1 = -P.u_bp_na1; K.bp_a2 = -P.u_bp_na2;
+    K.w1 = (f2){P.u_w1_re, P.u_w1_im};
+    K.inc2_lo = P.u_inc2_lo; K.inc2_hi = P.u_inc2_hi;
+  } else {
+    K.bp_b0 = (float)(__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cf_rsrc, row4 * 2u, (uint32_t)CF_bp_b0 * fld * 2u, 0)) * (0.5 * P.lp_b0));
+    K.bp_a1 = CLOAD(CF_bp_a1); K.bp_a2 = CLOAD(CF_bp_a2);
+    K.w1 = (f2){CLOAD(CF_w1_re), CLOAD(CF_w1_im)};
     const uint64_t inc = S.nco_inc[row];
     K.inc2_lo = (uint32_t)(inc << 1); K.inc2_hi = (uint32_t)((inc << 1) >> 32);
   }
+  // UNI state views: pre-filter history as (older, newer) pairs, NCO phasor of the next pair's first sample
+  f2 ubx = (f2){F.bx2, F.bx1}, uby = (f2){F.by2, F.by1};
+  f2 z = (f2){1.0f, 0.0f};
+  const f2 w2 = (f2){P.u_w2_re, P.u_w2_im};
   FastUni U;
   U.lp_b0 = P.f_lp_b0; U.lp_a2 = P.f_lp_a2; U.lp_delta = P.f_lp_delta;
   U.agc_att = P.f_agc_att; U.agc_rel = P.f_agc_rel;
@@ -1046,6 +1074,11 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
       FSK_BLOAD4(pre0, s0); FSK_BLOAD4(pre1, s1); FSK_BLOAD4(pre2, s2); FSK_BLOAD4(pre3, s3);
     }
 
+    if (UNI) {  // re-seed the phasor from the exact accumulator (first sample of this tile)
+      const float turns = (float)F.nco_hi * 2.3283064365386963e-10f;
+      z = (f2){__builtin_amdgcn_cosf(turns), __builtin_amdgcn_sinf(turns)};
+    }
+
 #pragma unroll 1
     for (uint32_t c = 0; c < 4; c++) {
       const v4f x4 = stage[c * kSlotStride + lane];
@@ -1072,19 +1105,35 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
           float g = __builtin_fmaf(t, rate, F.g);
           g = level > 0.0f ? g : F.g;
           F.g = __builtin_amdgcn_fmed3f(g, 0.1f, 10.0f);
-          // pre-filter (filters.ts:47-87): y = b0*(x - x2) - a2*y2 - a1*y1
-          float v = K.bp_b0 * (xv - F.bx2);
-          v = __builtin_fmaf(-K.bp_a2, F.by2, v);
-          v = __builtin_fmaf(-K.bp_a1, F.by1, v);
-          F.bx2 = F.bx1; F.bx1 = xv;
-          F.by2 = F.by1; F.by1 = v;
-          y[j] = v;
+          if (!UNI) {
+            // pre-filter (filters.ts:47-87): y = b0*(x - x2) - a2*y2 - a1*y1
+            float v = K.bp_b0 * (xv - F.bx2);
+            v = __builtin_fmaf(-K.bp_a2, F.by2, v);
+            v = __builtin_fmaf(-K.bp_a1, F.by1, v);
+            F.bx2 = F.bx1; F.bx1 = xv;
+            F.by2 = F.by1; F.by1 = v;
+            y[j] = v;
+          }
         }
-        // NCO (fsk.ts:228-232): first sample from the exact 64-bit turn accumulator, second = first * e^{j omega}
-        const float turns = (float)F.nco_hi * 2.3283064365386963e-10f;
-        const f2 z0 = (f2){__builtin_amdgcn_cosf(turns), __builtin_amdgcn_sinf(turns)};
-        const f2 z1 = cmul(z0, K.w1);
-        {
+        f2 z0, z1;
+        if (UNI) {
+          // pre-filter, both samples of the pair at once (look-ahead form, see the kernel comment)
+          const f2 xv2 = (f2){xs[2 * h], xs[2 * h + 1]};
+          f2 u = bc2(P.u_bp_b0h) * (xv2 - ubx);
+          u.y = __builtin_fmaf(P.u_bp_na1, u.x, u.y);
+          f2 yy = fma2((f2){P.u_bp_na1, P.u_bp_c1y}, bc2(uby.y), u);
+          yy = fma2((f2){P.u_bp_na2, P.u_bp_c2y}, bc2(uby.x), yy);
+          ubx = xv2; uby = yy;
+          y[0] = yy.x; y[1] = yy.y;
+          // NCO: phasor recurrence
+          z0 = z;
+          z1 = cmul(z0, K.w1);
+          z = cmul(z0, w2);
+        } else {
+          // NCO (fsk.ts:228-232): first sample from the exact 64-bit turn accumulator, second = first * e^{j omega}
+          const float turns = (float)F.nco_hi * 2.3283064365386963e-10f;
+          z0 = (f2){__builtin_amdgcn_cosf(turns), __builtin_amdgcn_sinf(turns)};
+          z1 = cmul(z0, K.w1);
           const uint32_t lo = F.nco_lo + K.inc2_lo;
           F.nco_hi = F.nco_hi + K.inc2_hi + (lo < F.nco_lo ? 1u : 0u);
           F.nco_lo = lo;
@@ -1095,8 +1144,8 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
         float amp;
         const bool bit = fast_disc(F, U, o0 + o1, amp);
         k++;
-        fast_fsm(F, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, bit, amp, h ? r1 : r0,
-                 h ? ph1 : ph0, k, amp_soff);
+        fast_fsm<UNI>(F, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, bit, amp, h ? r1 : r0,
+                      h ? ph1 : ph0, k, amp_soff, z, K.inc2_lo, K.inc2_hi);
         amp_soff += amp_row_bytes; if (amp_soff == amp_wrap) amp_soff = 0;
       }
       phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
@@ -1108,7 +1157,13 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
         }
       }
     }
+    if (UNI) {  // the accumulator moves one tile at a time (fast_reset accounts for that)
+      const uint32_t lo = F.nco_lo + P.u_inc16_lo;
+      F.nco_hi = F.nco_hi + P.u_inc16_hi + (lo < F.nco_lo ? 1u : 0u);
+      F.nco_lo = lo;
+    }
   }
+  if (UNI) { F.bx2 = ubx.x; F.bx1 = ubx.y; F.by2 = uby.x; F.by1 = uby.y; }
 
   // The last iteration's prefetch is still in flight and its destination registers are dead to the compiler:
   // without this wait the epilogue reuses them (e.g. as the high half of a store address) and a late-landing
@@ -1325,8 +1380,9 @@ __global__ __launch_bounds__(128) void demod_split_kernel(
             float amp;
             const bool bit = fast_disc(F, U, o0 + o1, amp);
             k++;
-            fast_fsm(F, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, bit, amp, h ? r1 : r0,
-                     h ? ph1 : ph0, k, amp_soff);
+            f2 z_unused = bc2(0.f);
+            fast_fsm<false>(F, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, bit, amp, h ? r1 : r0,
+                            h ? ph1 : ph0, k, amp_soff, z_unused, 0u, 0u);
             amp_soff += amp_row_bytes; if (amp_soff == amp_wrap) amp_soff = 0;
           }
           phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
@@ -1391,12 +1447,14 @@ hipError_t launch_demod_fast(bool writeback, const DemodParams &P, const DemodSt
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream) {
   const uint32_t blocks = (P.n_streams + 63u) / 64u;
-  if (writeback)
-    hipLaunchKernelGGL(demod_fast_kernel<true>, dim3(blocks), dim3(64), demod_fast_lds_bytes(P), stream, P, S,
-                       samples, n, pitch, out, out_pitch, out_counts, eod_counts);
-  else
-    hipLaunchKernelGGL(demod_fast_kernel<false>, dim3(blocks), dim3(64), demod_fast_lds_bytes(P), stream, P, S,
-                       samples, n, pitch, out, out_pitch, out_counts, eod_counts);
+  const size_t lds = demod_fast_lds_bytes(P);
+#define FSK_LAUNCH_FAST(WBV, UNIV)                                                                          \
+  hipLaunchKernelGGL((demod_fast_kernel<WBV, UNIV>), dim3(blocks), dim3(64), lds, stream, P, S, samples, n, pitch, \
+                     out, out_pitch, out_counts, eod_counts)
+  const bool uni = P.uni_cfg != 0;
+  if (writeback) { if (uni) FSK_LAUNCH_FAST(true, true); else FSK_LAUNCH_FAST(true, false); }
+  else { if (uni) FSK_LAUNCH_FAST(false, true); else FSK_LAUNCH_FAST(false, false); }
+#undef FSK_LAUNCH_FAST
   return hipGetLastError();
 }
 

@@ -92,6 +92,16 @@ struct DemodParams {
   // the same constants rounded once on the host for the fp32 kernels (a device-side (float) of the
   // f64 fields gets re-materialised by hipcc with a quarter-rate v_cvt_f32_f64 at every use)
   float f_lp_b0, f_lp_b0h, f_lp_a2, f_lp_delta, f_agc_att, f_agc_rel;
+  // uni_cfg = 1: every stream shares one configuration, so what is otherwise a per-stream array entry is a
+  // wave-uniform constant (SGPRs instead of VGPRs in the fast kernel)
+  uint32_t uni_cfg;
+  float u_bp_b0h;                  // pre-filter b0 with the low-pass gain b0/2 folded in
+  float u_bp_na1, u_bp_na2;        // -a1, -a2
+  float u_bp_c1y, u_bp_c2y;        // a1*a1 - a2, a1*a2: second row of the two-sample look-ahead form
+  float u_w1_re, u_w1_im;          // e^{j omega}
+  float u_w2_re, u_w2_im;          // e^{2 j omega}
+  uint32_t u_inc2_lo, u_inc2_hi;   // 2 NCO steps (turns * 2^64)
+  uint32_t u_inc16_lo, u_inc16_hi; // 16 NCO steps = one tile
 };
 
 struct DemodState {
