@@ -218,7 +218,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_note": "GB/s of HBM traffic = 7.07 B/input sample (rocprofv3 FETCH_SIZE x1.794 calibrated on probe_read_kernel "
                                 "+ WRITE_SIZE, profiles/r01_traffic.json) vs 4 B algorithmic: the extra is the reference's amplitude ring",
-                "kernel": "fsk::demod_fast_kernel<false>", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
+                "kernel": "fsk::demod_fast_kernel<false, true>", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
             },
             "cpu_baseline": cpu_obj,
