@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
 // step of the two waves costs more than the better balance gains.  Dealing the roles by CU arrival order read
 // from HW_ID made no difference either.)
 // ================================================================================================
-template <bool WB>
+template <bool WB, bool UNI>
 __global__ __launch_bounds__(128) void demod_split_kernel(
     DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
@@ -1334,11 +1334,16 @@ __global__ __launch_bounds__(128) void demod_split_kernel(
     if (valid && eod_counts) eod_counts[stream] = 0;
     FastConst K;
     K.bp_b0 = 0.f; K.bp_a1 = 0.f; K.bp_a2 = 0.f;
-    K.w1 = (f2){CLOAD(CF_w1_re), CLOAD(CF_w1_im)};
-    {
+    if (UNI) {
+      K.w1 = (f2){P.u_w1_re, P.u_w1_im};
+      K.inc2_lo = P.u_inc2_lo; K.inc2_hi = P.u_inc2_hi;
+    } else {
+      K.w1 = (f2){CLOAD(CF_w1_re), CLOAD(CF_w1_im)};
       const uint64_t inc = S.nco_inc[row];
       K.inc2_lo = (uint32_t)(inc << 1); K.inc2_hi = (uint32_t)((inc << 1) >> 32);
     }
+    f2 z = (f2){1.0f, 0.0f};
+    const f2 w2 = (f2){P.u_w2_re, P.u_w2_im};
     FastUni U;
     U.lp_b0 = P.f_lp_b0; U.lp_a2 = P.f_lp_a2; U.lp_delta = P.f_lp_delta;
     U.agc_att = P.f_agc_att; U.agc_rel = P.f_agc_rel;
@@ -1356,6 +1361,10 @@ __global__ __launch_bounds__(128) void demod_split_kernel(
       if (t > 0) {
         const v4f *yb = ybuf + ((t - 1) & 1) * 256u;
         v4f ynext = yb[lane];
+        if (UNI) {  // phasor recurrence as in demod_fast_kernel<.., true>: re-seed from the exact accumulator per tile
+          const float turns = (float)F.nco_hi * 2.3283064365386963e-10f;
+          z = (f2){__builtin_amdgcn_cosf(turns), __builtin_amdgcn_sinf(turns)};
+        }
 #pragma unroll 1
         for (uint32_t c = 0; c < 4; c++) {
           const v4f y4 = ynext;
@@ -1366,11 +1375,16 @@ __global__ __launch_bounds__(128) void demod_split_kernel(
           const float yin[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
           for (int h = 0; h < 2; h++) {
-            // NCO (fsk.ts:228-232): first sample from the exact 64-bit turn accumulator, second = first * e^{j omega}
-            const float turns = (float)F.nco_hi * 2.3283064365386963e-10f;
-            const f2 z0 = (f2){__builtin_amdgcn_cosf(turns), __builtin_amdgcn_sinf(turns)};
-            const f2 z1 = cmul(z0, K.w1);
-            {
+            f2 z0, z1;
+            if (UNI) {
+              z0 = z;
+              z1 = cmul(z0, K.w1);
+              z = cmul(z0, w2);
+            } else {
+              // NCO (fsk.ts:228-232): first sample from the exact 64-bit turn accumulator, second = first * e^{j omega}
+              const float turns = (float)F.nco_hi * 2.3283064365386963e-10f;
+              z0 = (f2){__builtin_amdgcn_cosf(turns), __builtin_amdgcn_sinf(turns)};
+              z1 = cmul(z0, K.w1);
               const uint32_t lo = F.nco_lo + K.inc2_lo;
               F.nco_hi = F.nco_hi + K.inc2_hi + (lo < F.nco_lo ? 1u : 0u);
               F.nco_lo = lo;
@@ -1380,12 +1394,16 @@ __global__ __launch_bounds__(128) void demod_split_kernel(
             float amp;
             const bool bit = fast_disc(F, U, o0 + o1, amp);
             k++;
-            f2 z_unused = bc2(0.f);
-            fast_fsm<false>(F, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, bit, amp, h ? r1 : r0,
-                            h ? ph1 : ph0, k, amp_soff, z_unused, 0u, 0u);
+            fast_fsm<UNI>(F, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, bit, amp, h ? r1 : r0,
+                          h ? ph1 : ph0, k, amp_soff, z, K.inc2_lo, K.inc2_hi);
             amp_soff += amp_row_bytes; if (amp_soff == amp_wrap) amp_soff = 0;
           }
           phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
+        }
+        if (UNI) {  // the accumulator moves one tile at a time (fast_reset accounts for that)
+          const uint32_t lo = F.nco_lo + P.u_inc16_lo;
+          F.nco_hi = F.nco_hi + P.u_inc16_hi + (lo < F.nco_lo ? 1u : 0u);
+          F.nco_lo = lo;
         }
       }
       TILE_BARRIER();
@@ -1423,12 +1441,14 @@ hipError_t launch_demod_split(bool writeback, const DemodParams &P, const DemodS
                               size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                               uint32_t *eod_counts, hipStream_t stream) {
   const uint32_t blocks = (P.n_streams + 63u) / 64u;
-  if (writeback)
-    hipLaunchKernelGGL(demod_split_kernel<true>, dim3(blocks), dim3(128), demod_split_lds_bytes(P), stream, P, S,
-                       samples, n, pitch, out, out_pitch, out_counts, eod_counts);
-  else
-    hipLaunchKernelGGL(demod_split_kernel<false>, dim3(blocks), dim3(128), demod_split_lds_bytes(P), stream, P, S,
-                       samples, n, pitch, out, out_pitch, out_counts, eod_counts);
+  const size_t lds = demod_split_lds_bytes(P);
+#define FSK_LAUNCH_SPLIT(WBV, UNIV)                                                                          \
+  hipLaunchKernelGGL((demod_split_kernel<WBV, UNIV>), dim3(blocks), dim3(128), lds, stream, P, S, samples, n, pitch, \
+                     out, out_pitch, out_counts, eod_counts)
+  const bool uni = P.uni_cfg != 0;
+  if (writeback) { if (uni) FSK_LAUNCH_SPLIT(true, true); else FSK_LAUNCH_SPLIT(true, false); }
+  else { if (uni) FSK_LAUNCH_SPLIT(false, true); else FSK_LAUNCH_SPLIT(false, false); }
+#undef FSK_LAUNCH_SPLIT
   return hipGetLastError();
 }
 
