@@ -289,8 +289,8 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   if (const char *fg = getenv("FSKHIP_FORCE_GENERIC")) e->force_generic = fg[0] == '1';
   {
     // with at most one wave per SIMD the one-wave-per-group kernel cannot hide its own dependency stalls; the
-    // split kernel gives every group two instruction streams (measured: +12 % at 65 536 streams, +17 % at 4 096,
-    // no gain from 131 072 up).  FSKHIP_SPLIT=0/1 overrides (tests, measurements).
+    // split kernel gives every group two instruction streams (measured: 254 -> 303 Gsamples/s at 65 536 streams,
+    // 16 -> 21 at 4 096, no gain from 131 072 up).  FSKHIP_SPLIT=0/1 overrides (tests, measurements).
     hipDeviceProp_t prop;
     int simds = 1024;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) simds = prop.multiProcessorCount * 4;
