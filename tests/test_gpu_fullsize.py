@@ -166,3 +166,29 @@ def test_config5_awgn_full_size():
     eng.device_free(d_x)
     eng.close()
     eng2.close()
+
+
+@pytest.mark.parametrize("S", [1, 63, 65, 1000, 4096])
+def test_whole_tile_kernels_agree_on_ragged_batches(S, monkeypatch):
+    """The one-wave kernel, the two-wave split kernel and the generic kernel (FSKHIP_FORCE_GENERIC) must produce the same
+    bytes / eod for every stream of a batch whose size is not a multiple of the wave, under a ragged chunk schedule."""
+    import webaudio_modem_amd as wm
+    N = 48000
+    gen = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    d_x = gen.device_malloc(S * N * 4)
+    gen.synth_device(d_x, N, N, 12, SEED + 1, 300, 0.1, 1.0)
+    gen.synchronize()
+    digests = {}
+    for name, env in (("split", {"FSKHIP_SPLIT": "1"}), ("one_wave", {"FSKHIP_SPLIT": "0"}), ("generic", {"FSKHIP_FORCE_GENERIC": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+        for k in env:
+            monkeypatch.delenv(k)
+        rows, eod = _demod_schedule(eng, d_x, N, N, [4096, 16, 1000, 48, 20000])
+        digests[name] = (_digest(rows, eod), sum(len(r) for r in rows))
+        eng.close()
+    assert digests["split"] == digests["one_wave"] == digests["generic"], digests
+    assert digests["split"][1] >= 12 * S * 0.5
+    gen.device_free(d_x)
+    gen.close()
