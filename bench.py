@@ -66,8 +66,6 @@ def main():
     import numpy as np
     import torch
     import __graft_entry__ as ge
-    ge.build()
-    import webaudio_modem_amd as wm
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
@@ -77,6 +75,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    # one rank runs make (a no-op when the shipped libraries are current); the others must not race it in the same tree
+    if rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+    import webaudio_modem_amd as wm
 
     wl = WORKLOADS[args.workload]
     cfg = wl["cfg"]
