@@ -37,6 +37,8 @@ export class FSKCore extends EventEmitter {
 export class FSKBatch {
   constructor(nStreams: number, configs: Partial<FSKConfig> | Partial<FSKConfig>[], options?: { device?: number; precision?: 0 | 1 });
   demodulateData(samples: Float32Array, nPerStream: number, pitch?: number, writebackAgc?: boolean): { bytes: Uint8Array[]; eod: Uint32Array };
+  /** the same on a libuv worker thread (N-API async work); one call in flight per batch */
+  demodulateDataAsync(samples: Float32Array, nPerStream: number, pitch?: number, writebackAgc?: boolean): Promise<{ bytes: Uint8Array[]; eod: Uint32Array }>;
   modulateData(payloads: Uint8Array[]): Float32Array[];
   reset(stream?: number): void;
   getStatus(stream?: number): FSKStatus;

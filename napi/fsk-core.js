@@ -128,6 +128,14 @@ class FSKBatch {
     for (let s = 0; s < this.nStreams; s++) bytes.push(r.out.slice(s * r.outPitch, s * r.outPitch + r.counts[s]));
     return { bytes, eod: r.eod };
   }
+  // the same off the event loop (N-API async work): the promise resolves with {bytes, eod}; `samples` must not be
+  // touched until it settles, and one call may be in flight per batch
+  async demodulateDataAsync(samples, nPerStream, pitch, writebackAgc) {
+    const r = await addon.demodulateAsync(this.handle, samples, nPerStream, pitch || nPerStream, writebackAgc ? DEMOD_WRITEBACK_AGC : 0);
+    const bytes = [];
+    for (let s = 0; s < this.nStreams; s++) bytes.push(r.out.slice(s * r.outPitch, s * r.outPitch + r.counts[s]));
+    return { bytes, eod: r.eod };
+  }
   // payloads: Uint8Array[S] -> Float32Array[S]
   modulateData(payloads) {
     let pitch = 1;

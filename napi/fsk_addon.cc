@@ -8,6 +8,7 @@
 //   create(configs: object | object[], nStreams, device, precision) -> handle
 //   destroy(handle)
 //   demodulate(handle, samples: Float32Array, nPerStream, pitch, flags) -> {out: Uint8Array, outPitch, counts: Uint32Array, eod: Uint32Array}
+//   demodulateAsync(... same ...) -> Promise of the same object; runs on a libuv worker thread
 //   modulate(handle, payloads: Uint8Array, lens: Uint32Array, payloadPitch) -> {out: Float32Array, outPitch, lens: Uint32Array}
 //   modulatedLength(handle, nBytes) -> number
 //   reset(handle, stream)            stream < 0: all
@@ -202,6 +203,99 @@ static napi_value Demodulate(napi_env env, napi_callback_info info) {
   return res;
 }
 
+// demodulateAsync: the same call on a libuv worker thread, for batches big enough to matter to the event loop
+// (SURVEY 8b "Threading").  Output arrays are created up front on the JS thread; the input Float32Array is
+// referenced until the work completes.  One call in flight per engine: a second one rejects.
+struct DemodWork {
+  napi_async_work work = nullptr;
+  napi_deferred deferred = nullptr;
+  napi_ref in_ref = nullptr, out_ref = nullptr, cnt_ref = nullptr, eod_ref = nullptr;
+  fskhip_engine *e = nullptr;
+  float *samples = nullptr;
+  uint8_t *out = nullptr;
+  uint32_t *counts = nullptr, *eod = nullptr;
+  uint32_t n = 0, pitch = 0, flags = 0;
+  size_t out_pitch = 0;
+  int rc = 0;
+  std::string err;
+};
+static std::vector<fskhip_engine *> g_busy;  // engines with an async call in flight (JS thread only)
+
+static void demod_execute(napi_env, void *data) {
+  DemodWork *w = (DemodWork *)data;
+  w->rc = fskhip_demodulate_host(w->e, w->samples, w->n, w->pitch, w->out, w->out_pitch, w->counts, w->eod, w->flags);
+  if (w->rc != FSKHIP_OK) w->err = fskhip_last_error();  // thread-local: read it on the thread that failed
+}
+static void demod_complete(napi_env env, napi_status, void *data) {
+  DemodWork *w = (DemodWork *)data;
+  for (size_t i = 0; i < g_busy.size(); i++)
+    if (g_busy[i] == w->e) { g_busy.erase(g_busy.begin() + i); break; }
+  if (w->rc == FSKHIP_OK) {
+    napi_value res, out_v, cnt_v, eod_v, op;
+    napi_create_object(env, &res);
+    napi_get_reference_value(env, w->out_ref, &out_v);
+    napi_get_reference_value(env, w->cnt_ref, &cnt_v);
+    napi_get_reference_value(env, w->eod_ref, &eod_v);
+    napi_create_uint32(env, (uint32_t)w->out_pitch, &op);
+    napi_set_named_property(env, res, "out", out_v);
+    napi_set_named_property(env, res, "outPitch", op);
+    napi_set_named_property(env, res, "counts", cnt_v);
+    napi_set_named_property(env, res, "eod", eod_v);
+    napi_resolve_deferred(env, w->deferred, res);
+  } else {
+    napi_value msg, errv;
+    napi_create_string_utf8(env, w->err.c_str(), NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, nullptr, msg, &errv);
+    napi_reject_deferred(env, w->deferred, errv);
+  }
+  napi_delete_reference(env, w->in_ref);
+  napi_delete_reference(env, w->out_ref);
+  napi_delete_reference(env, w->cnt_ref);
+  napi_delete_reference(env, w->eod_ref);
+  napi_delete_async_work(env, w->work);
+  delete w;
+}
+
+static napi_value DemodulateAsync(napi_env env, napi_callback_info info) {
+  size_t argc = 5;
+  napi_value argv[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  fskhip_engine *e = get_engine(env, argv[0]);
+  if (!e) return nullptr;
+  napi_typedarray_type tt;
+  size_t len = 0;
+  void *data = nullptr;
+  NAPI_OK(napi_get_typedarray_info(env, argv[1], &tt, &len, &data, nullptr, nullptr));
+  if (tt != napi_float32_array) { napi_throw_type_error(env, nullptr, "samples must be a Float32Array"); return nullptr; }
+  DemodWork *w = new DemodWork();
+  w->e = e; w->samples = (float *)data;
+  napi_get_value_uint32(env, argv[2], &w->n);
+  napi_get_value_uint32(env, argv[3], &w->pitch);
+  napi_get_value_uint32(env, argv[4], &w->flags);
+  const uint32_t S = fskhip_n_streams(e);
+  if (w->pitch < w->n || (size_t)w->pitch * (S ? S - 1 : 0) + w->n > len) { delete w; napi_throw_range_error(env, nullptr, "samples too short"); return nullptr; }
+  for (fskhip_engine *b : g_busy)
+    if (b == e) { delete w; napi_throw_error(env, nullptr, "an asynchronous call is already in flight on this engine"); return nullptr; }
+  w->out_pitch = w->n / 32 + 8;
+  void *out = nullptr, *counts = nullptr, *eod = nullptr;
+  napi_value out_v = make_typed(env, napi_uint8_array, w->out_pitch * S, 1, &out);
+  napi_value cnt_v = make_typed(env, napi_uint32_array, S, 4, &counts);
+  napi_value eod_v = make_typed(env, napi_uint32_array, S, 4, &eod);
+  if (!out_v || !cnt_v || !eod_v) { delete w; napi_throw_error(env, nullptr, "allocation failed"); return nullptr; }
+  w->out = (uint8_t *)out; w->counts = (uint32_t *)counts; w->eod = (uint32_t *)eod;
+  napi_create_reference(env, argv[1], 1, &w->in_ref);
+  napi_create_reference(env, out_v, 1, &w->out_ref);
+  napi_create_reference(env, cnt_v, 1, &w->cnt_ref);
+  napi_create_reference(env, eod_v, 1, &w->eod_ref);
+  napi_value promise, name;
+  napi_create_promise(env, &w->deferred, &promise);
+  napi_create_string_utf8(env, "fskhip_demodulate", NAPI_AUTO_LENGTH, &name);
+  napi_create_async_work(env, nullptr, name, demod_execute, demod_complete, w, &w->work);
+  g_busy.push_back(e);
+  napi_queue_async_work(env, w->work);
+  return promise;
+}
+
 // modulateData (fsk.ts:377-424) for every stream
 static napi_value Modulate(napi_env env, napi_callback_info info) {
   size_t argc = 4;
@@ -329,6 +423,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"create", nullptr, Create, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"destroy", nullptr, Destroy, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"demodulate", nullptr, Demodulate, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"demodulateAsync", nullptr, DemodulateAsync, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"modulate", nullptr, Modulate, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"modulatedLength", nullptr, ModulatedLength, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"reset", nullptr, Reset, nullptr, nullptr, nullptr, napi_default, nullptr},

@@ -113,6 +113,30 @@ async function gpuTests() {
     proc.reset();
     proc.close(); batch.close();
   }
+  // ---- FSKBatch.demodulateDataAsync: same result as the synchronous call, event loop free meanwhile ----
+  {
+    const S = 16;
+    const cfg = { baudRate: 1200, markFrequency: 1200, spaceFrequency: 2200 };
+    const a = new M.FSKBatch(S, cfg), b = new M.FSKBatch(S, cfg);
+    const payloads = [];
+    for (let k = 0; k < S; k++) payloads.push(s('async stream ' + k));
+    const sigs = a.modulateData(payloads);
+    const n = sigs.reduce((m, x) => Math.max(m, x.length), 0) + 64;
+    const buf = new Float32Array(S * n);
+    sigs.forEach((x, k) => buf.set(x, k * n));
+    const want = a.demodulateData(Float32Array.from(buf), n, n, false);
+    let ticks = 0;
+    const timer = setInterval(() => { ticks++; }, 0);
+    const pending = b.demodulateDataAsync(buf, n, n, false);
+    await assert.rejects(b.demodulateDataAsync(buf, n, n, false), /already in flight/);
+    const got = await pending;
+    clearInterval(timer);
+    for (let k = 0; k < S; k++) {
+      assert.deepStrictEqual(Array.from(got.bytes[k]), Array.from(want.bytes[k]));
+      assert.strictEqual(Buffer.from(got.bytes[k]).toString('ascii'), 'async stream ' + k);
+    }
+    a.close(); b.close();
+  }
   // ---- FIR (tests/dsp/filters.node.test.ts:190-206: impulse response = taps) ----
   {
     const taps = [0.1, -0.2, 0.3, 0.25, -0.05];
