@@ -125,6 +125,10 @@ int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n_per_st
  * payloads[s*payload_pitch .. + lens[s]) with ITS configuration into out[s*out_pitch ...];
  * out_lens[s] receives the signal length: totalBytes*bitsPerByte*spb + 2*spb + bitsPerByte*spb
  * (fsk.ts:391-394).  fskhip_modulated_length() gives that length for a payload size.
+ * FSKHIP_PRECISION_F64 engines evaluate Math.sin with the operation sequence of the engine the reference runs on
+ * (V8's fdlibm port), so the Float32Array is bit-identical at any length; FSKHIP_PRECISION_F32 engines use the
+ * device library's sin() (about 1.8x faster; a sample can differ by one float ulp where two correct libms round the
+ * double differently, about once in 1e9 samples).
  */
 size_t fskhip_modulated_length(const fskhip_engine *e, size_t n_bytes);
 int fskhip_modulate_host(fskhip_engine *e, const uint8_t *payloads, const uint32_t *lens,

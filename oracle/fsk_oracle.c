@@ -7,6 +7,7 @@
  * src/dsp/filters.ts, src/utils.ts).
  */
 #include "fsk_oracle.h"
+#include "v8_sin.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -599,6 +600,11 @@ long fsko_demodulate(fsko_core *c, float *samples, size_t n, uint8_t *out, size_
   return produced;
 }
 
+void fsko_v8_sin(const double *x, double *y, size_t n) {
+  size_t i;
+  for (i = 0; i < n; i++) y[i] = v8_sin(x[i]);
+}
+
 /* generateFSKSignalInternal fsk.ts:389-424 */
 long fsko_modulate_length(const fsko_core *c, size_t n_bytes) {
   double totalBytes, padding, silence;
@@ -614,7 +620,7 @@ static void gen_bit(modstate *m, int bit) { /* fsk.ts:400-406 */
   double frequency = bit == 1 ? m->c->cfg.markFrequency : m->c->cfg.spaceFrequency;
   long i;
   for (i = 0; i < (long)m->c->samplesPerBit && m->idx < m->n; i++) {
-    m->out[m->idx++] = (float)sin(m->phase);
+    m->out[m->idx++] = (float)v8_sin(m->phase); /* Math.sin as V8 computes it: v8_sin.h */
     m->phase += 2 * M_PI * frequency / m->c->cfg.sampleRate;
   }
 }

@@ -82,6 +82,8 @@ def lib():
             f.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.fsko_butterworth_bandpass.argtypes = [C.c_double, C.c_double, C.c_double,
                                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.fsko_v8_sin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.fsko_v8_sin.restype = None
         L.fsko_sinc_lowpass.argtypes = [C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
         L.fsko_sinc_highpass.argtypes = [C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
         L.fsko_sinc_bandpass.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
@@ -284,3 +286,11 @@ class FIR:
     def __del__(self):
         if getattr(self, "_h", None):
             lib().fsko_fir_destroy(self._h)
+
+
+def v8_sin(x):
+    """Math.sin as V8 computes it (oracle/v8_sin.h) for an array of doubles."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    lib().fsko_v8_sin(x.ctypes.data, y.ctypes.data, x.size)
+    return y

@@ -329,6 +329,22 @@ async function main() {
     }
     manifest.processor = runs;
   }
+  // ---------------- Math.sin of the engine the reference runs on (V8's fdlibm port), for oracle/v8_sin.h and the
+  // device modulator's fsk_fdlibm.h: uniform samples of the phase range modulateData reaches, plus the corners of
+  // fdlibm's argument reduction (multiples of pi/2, the 2^-27 and pi/4 thresholds, the end of the medium range)
+  {
+    const rand = rng32(0x51115);
+    const xs = [0, 1e-9, 7.450580596923828e-9, 0.3, 0.78125, Math.PI / 4, 0.7853981633974484, 2.356194490192345, Math.PI / 2, Math.PI,
+      1.5707963267948966, 1.5707963705062866, 3 * Math.PI / 2, 2 * Math.PI, 100 * Math.PI, 823549.6, 823549.66, 1e5, 12345.678];
+    for (let n = 1; n <= 40; n++) { xs.push(n * Math.PI / 2); xs.push(n * 1.5707963267948966 * (1 + 1e-15)); xs.push(n * 1.5707963267948966 * (1 - 1e-15)); }
+    for (let i = 0; i < 3000; i++) xs.push(rand() * 20000);
+    for (let i = 0; i < 1500; i++) xs.push(rand() * 823549);
+    for (let i = 0; i < 500; i++) xs.push(-rand() * 1000);
+    const x = Float64Array.from(xs);
+    const y = new Float64Array(x.length);
+    for (let i = 0; i < x.length; i++) y[i] = Math.sin(x[i]);
+    manifest.sin = { x: saveArray('sin.x', x), y: saveArray('sin.y', y) };
+  }
   manifest.arrays = arrays;
   fs.writeFileSync(path.join(OUT, 'manifest.json'), JSON.stringify(manifest));
   console.log('next-row goldens: arrays', Object.keys(arrays).length);

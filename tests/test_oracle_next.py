@@ -144,3 +144,17 @@ def test_processor_loop_matches_reference(name):
         k = run["start_quantum"] * 128
         want[k:k + len(direct)] = direct
         assert np.array_equal(out, want)
+
+
+def test_v8_sin_restatement_is_bit_identical_to_node():
+    """oracle/v8_sin.h (fdlibm's sin, the algorithm V8 ports) against Math.sin of the Node that ran the reference:
+    5 000+ arguments over the modulator's phase range and the corners of the argument reduction, compared bit for bit."""
+    g = golden_next()
+    x, want = g.arrays[g.manifest["sin"]["x"]], g.arrays[g.manifest["sin"]["y"]]
+    assert x.size > 5000
+    got = po.v8_sin(x)
+    bad = np.nonzero(got.view(np.uint64) != want.view(np.uint64))[0]
+    # beyond 2^19*pi/2 the restatement defers to the C library (Payne-Hanek range, not restated): allow 1 ulp there
+    inside = np.abs(x) <= 823549.6
+    assert not np.any(inside[bad]), (x[bad][:5], got[bad][:5], want[bad][:5])
+    assert np.all(np.abs(got[bad] - want[bad]) <= 2.3e-16)

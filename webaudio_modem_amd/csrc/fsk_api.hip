@@ -405,6 +405,7 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   M.spb = (uint32_t)e->spb;
   M.bits_per_byte = (uint32_t)e->bpb;
   M.start_bits = c0.startBits; M.stop_bits = c0.stopBits; M.parity = c0.parity;
+  M.exact_sin = precision == FSKHIP_PRECISION_F64 ? 1u : 0u;
   M.n_pre = c0.preambleLen + c0.sfdLen;
   for (int i = 0; i < c0.preambleLen; i++) M.pre[i] = (uint8_t)c0.preamblePattern[i];
   for (int i = 0; i < c0.sfdLen; i++) M.pre[c0.preambleLen + i] = (uint8_t)c0.sfdPattern[i];

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fsk_fdlibm.h"
 #include "fsk_params.h"
 
 namespace fsk {
@@ -83,6 +84,14 @@ __device__ inline uint32_t frame_bit(const ModParams &M, uint32_t bit_idx, ByteF
   return 1u;  // stop bits
 }
 
+// Math.sin(phase) as the reference's engine computes it (fsk_fdlibm.h), rounded to f32 like the Float32Array store
+__device__ inline double ref_sin(double phase) {
+  bool exact;
+  double sv = fdlibm::sin_medium(phase, &exact);
+  if (!exact) sv = sin(phase);  // > 2^19*pi/2 rad: device library (see fsk_fdlibm.h)
+  return sv;
+}
+
 // next sample of the frame (f32 like the Float32Array store, fsk.ts:403)
 template <typename ByteFn>
 __device__ inline float frame_next(FrameGen &G, const ModParams &M, ByteFn payload_byte) {
@@ -93,12 +102,68 @@ __device__ inline float frame_next(FrameGen &G, const ModParams &M, ByteFn paylo
       G.bit_idx++;
       G.cur_bit = frame_bit(M, G.bit_idx, payload_byte);
     }
-    v = (float)sin(G.phase);
+    v = (float)sin(G.phase);  // (synthetic workload generator: device library sin)
     G.phase += G.cur_bit ? G.w_mark : G.w_space;
     G.in_bit++;
   }
   G.pos++;
   return v;
+}
+
+// Four consecutive samples.  The sequential part -- bit boundaries and the phase accumulation, in the reference's order
+// of additions -- runs first; the four sines, which are independent of each other, are then evaluated as one
+// straight-line block so their dependent chains overlap (one lane per stream means there is no other parallelism to
+// hide an f64 polynomial behind).  en[j] = false leaves sample j untouched (0 returned, generator not advanced).
+template <int N, bool EXACT, typename ByteFn>
+__device__ inline void frame_next_block(FrameGen &G, const ModParams &M, ByteFn payload_byte, uint32_t en_mask, float *out) {
+  double ph[N];
+  bool tone[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    tone[j] = false;
+    ph[j] = 4.0;  // any value of the straight-line case; unused unless tone[j]
+    if (((en_mask >> j) & 1u) && G.pos < G.frame_len) {
+      if (G.pos >= G.sig_begin && G.pos < G.sig_end) {
+        if (G.in_bit == M.spb) {
+          G.in_bit = 0;
+          G.bit_idx++;
+          G.cur_bit = frame_bit(M, G.bit_idx, payload_byte);
+        }
+        tone[j] = true;
+        ph[j] = G.phase;
+        G.phase += G.cur_bit ? G.w_mark : G.w_space;
+        G.in_bit++;
+      }
+      G.pos++;
+    }
+  }
+  double sv[N];
+  if (EXACT) {
+    bool slow[N];
+    bool any_slow = false;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      sv[j] = fdlibm::sin_straight(ph[j], &slow[j]);
+      any_slow |= slow[j] & tone[j];
+    }
+    if (__builtin_amdgcn_ballot_w64(any_slow)) {
+#pragma unroll
+      for (int j = 0; j < N; j++)
+        if (slow[j] & tone[j]) sv[j] = ref_sin(ph[j]);  // first samples of a frame (phase < 3pi/4), near-multiples of pi/2, ...
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; j++) sv[j] = sin(ph[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < N; j++) out[j] = tone[j] ? (float)sv[j] : 0.0f;
+}
+template <bool EXACT, typename ByteFn>
+__device__ inline float4 frame_next4(FrameGen &G, const ModParams &M, ByteFn payload_byte, bool e0, bool e1, bool e2,
+                                     bool e3) {
+  float o[4];
+  frame_next_block<4, EXACT>(G, M, payload_byte, (e0 ? 1u : 0u) | (e1 ? 2u : 0u) | (e2 ? 4u : 0u) | (e3 ? 8u : 0u), o);
+  return make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // coalesced store of a 64-row x 32-sample LDS tile (rows = this wave's streams)
@@ -127,6 +192,7 @@ __device__ inline void store_tile(const float4 *stage, float *out, size_t pitch,
 }
 
 // modulateData for every stream: payloads [n_streams][payload_pitch] bytes, lens[s] bytes used.
+template <bool EXACT>
 __global__ __launch_bounds__(64) void modulate_kernel(ModParams M, const double *__restrict__ coef,
                                                       const uint8_t *__restrict__ payloads,
                                                       const uint32_t *__restrict__ lens, size_t payload_pitch,
@@ -160,13 +226,11 @@ __global__ __launch_bounds__(64) void modulate_kernel(ModParams M, const double 
   float *stage_f = reinterpret_cast<float *>(stage);
   for (uint32_t t0 = 0; t0 < max_len; t0 += kTile) {
     __syncthreads();
-    for (uint32_t c = 0; c < (uint32_t)kChunks; c++) {
-      float4 v;
-      v.x = G.pos < G.frame_len ? frame_next(G, M, pb) : 0.0f;
-      v.y = G.pos < G.frame_len ? frame_next(G, M, pb) : 0.0f;
-      v.z = G.pos < G.frame_len ? frame_next(G, M, pb) : 0.0f;
-      v.w = G.pos < G.frame_len ? frame_next(G, M, pb) : 0.0f;
-      stage[c * kSlotStride + lane] = v;
+    for (uint32_t c = 0; c < (uint32_t)kChunks; c += 2) {   // eight sines per straight-line block
+      float o[8];
+      frame_next_block<8, EXACT>(G, M, pb, 0xFFu, o);
+      stage[c * kSlotStride + lane] = make_float4(o[0], o[1], o[2], o[3]);
+      stage[(c + 1) * kSlotStride + lane] = make_float4(o[4], o[5], o[6], o[7]);
     }
     __syncthreads();
     store_tile(stage, out, out_pitch, t0, 0, M.n_streams, row_len, vec_ok);
@@ -224,6 +288,7 @@ __global__ __launch_bounds__(64) void synth_kernel(ModParams M, const double *__
 // utils.ts:38-48) of the bytes the demod kernels just produced, (2) modulateTo (256-276): zero fill, then the next
 // n_out samples of the pending modulation from its generator state, completion bookkeeping, and optionally the RX
 // clear the 'modulate' handler does when the modulation resolves (228-235).
+template <bool EXACT>
 __global__ __launch_bounds__(64) void processor_io_kernel(ModParams M, const double *__restrict__ coef, ProcState T,
                                                           const uint8_t *__restrict__ demod_out, size_t demod_pitch,
                                                           const uint32_t *__restrict__ demod_counts, int do_rx,
@@ -270,12 +335,7 @@ __global__ __launch_bounds__(64) void processor_io_kernel(ModParams M, const dou
       for (uint32_t c = 0; c < (uint32_t)kChunks; c++) {
         // samples beyond n_out inside the last tile must not advance the generator
         const size_t base = t0 + 4u * c;
-        float4 v;
-        v.x = (base + 0 < n_out && G.pos < G.frame_len) ? frame_next(G, M, pb) : 0.0f;
-        v.y = (base + 1 < n_out && G.pos < G.frame_len) ? frame_next(G, M, pb) : 0.0f;
-        v.z = (base + 2 < n_out && G.pos < G.frame_len) ? frame_next(G, M, pb) : 0.0f;
-        v.w = (base + 3 < n_out && G.pos < G.frame_len) ? frame_next(G, M, pb) : 0.0f;
-        stage[c * kSlotStride + lane] = v;
+        stage[c * kSlotStride + lane] = frame_next4<EXACT>(G, M, pb, base + 0 < n_out, base + 1 < n_out, base + 2 < n_out, base + 3 < n_out);
       }
       __syncthreads();
       store_tile(stage, out, out_pitch, t0, n_out, M.n_streams, nullptr, vec_ok);
@@ -349,8 +409,12 @@ hipError_t launch_processor_io(const ModParams &M, const double *coef, const Pro
                                size_t out_pitch, bool clear_rx_on_complete, hipStream_t st) {
   const uint32_t blocks = (M.n_streams + 63u) / 64u;
   const int vec_ok = out && (out_pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
-  hipLaunchKernelGGL(processor_io_kernel, dim3(blocks), dim3(64), 0, st, M, coef, T, demod_out, demod_pitch,
-                     demod_counts, do_rx ? 1 : 0, out, n_out, out_pitch, vec_ok, clear_rx_on_complete ? 1u : 0u);
+  if (M.exact_sin)
+    hipLaunchKernelGGL(processor_io_kernel<true>, dim3(blocks), dim3(64), 0, st, M, coef, T, demod_out, demod_pitch,
+                       demod_counts, do_rx ? 1 : 0, out, n_out, out_pitch, vec_ok, clear_rx_on_complete ? 1u : 0u);
+  else
+    hipLaunchKernelGGL(processor_io_kernel<false>, dim3(blocks), dim3(64), 0, st, M, coef, T, demod_out, demod_pitch,
+                       demod_counts, do_rx ? 1 : 0, out, n_out, out_pitch, vec_ok, clear_rx_on_complete ? 1u : 0u);
   return hipGetLastError();
 }
 hipError_t launch_processor_tx_start(const ModParams &M, const ProcState &T, const uint8_t *payloads, const uint32_t *lens,
@@ -431,8 +495,12 @@ hipError_t launch_modulate(const ModParams &M, const double *coef, const uint8_t
                            size_t payload_pitch, float *out, size_t out_pitch, uint32_t *out_lens, hipStream_t st) {
   const uint32_t blocks = (M.n_streams + 63u) / 64u;
   const int vec_ok = (out_pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
-  hipLaunchKernelGGL(modulate_kernel, dim3(blocks), dim3(64), 0, st, M, coef, payloads, lens, payload_pitch, out,
-                     out_pitch, vec_ok, out_lens);
+  if (M.exact_sin)
+    hipLaunchKernelGGL(modulate_kernel<true>, dim3(blocks), dim3(64), 0, st, M, coef, payloads, lens, payload_pitch, out,
+                       out_pitch, vec_ok, out_lens);
+  else
+    hipLaunchKernelGGL(modulate_kernel<false>, dim3(blocks), dim3(64), 0, st, M, coef, payloads, lens, payload_pitch, out,
+                       out_pitch, vec_ok, out_lens);
   return hipGetLastError();
 }
 hipError_t launch_synth(const ModParams &M, const double *coef, float *out, size_t n, size_t pitch,

@@ -128,6 +128,8 @@ struct ModParams {
   uint32_t start_bits, stop_bits, parity; // parity 0/1/2
   uint32_t n_pre;         // preamble + sfd bytes
   uint8_t pre[2 * 16];
+  uint32_t exact_sin;     // 1 (fp64 engines): Math.sin by V8's own operation sequence (fsk_fdlibm.h), bit-identical signal;
+                          // 0 (fp32 engines): the device library's sin(), ~1.8x faster, may differ by one f32 ulp on ~1e-9 of samples
 };
 
 // FSKProcessor + ChunkedModulator per stream (fsk-processor.ts, chunked-modulator.ts), device resident.
