@@ -335,3 +335,42 @@ def test_processor_batch_random_schedule_matches_oracle(use_graph):
     assert proc.rx_lengths()[5] == 0 and not proc.tx_state()["pendingModulation"][5]
     proc.close()
     eng.close()
+
+
+def test_xmodem_scan_kernels_agree_across_layouts():
+    """The tiled kernel (16-byte aligned rows, what the host entry point uses) and the row-walking kernels (4-byte
+    aligned / unaligned rows, reachable through the device entry point) give identical results and payloads."""
+    import ctypes as C
+    import webaudio_modem_amd as wm
+    from webaudio_modem_amd import _lib
+    g = golden_next()
+    sc = g.manifest["scans"]
+    bursts = g.ragged(sc["bytes"])
+    expected = np.array([c["expected"] for c in sc["cases"]], np.uint32)
+    ref = wm.scan_bursts(bursts, expected)
+    n = len(bursts)
+    counts = np.array([len(b) for b in bursts], np.uint32)
+    eng = wm.FSKEngine(1, {})
+    L = _lib.lib()
+    for pitch, data_pitch in ((int(counts.max()) + 1 | 1, 601), (int(counts.max()) + 4 & ~3, 604)):
+        slab = np.zeros((n, pitch), np.uint8)
+        for i, b in enumerate(bursts):
+            slab[i, :len(b)] = np.frombuffer(b, np.uint8)
+        d_b, d_c, d_e = eng.device_malloc(slab.nbytes), eng.device_malloc(4 * n), eng.device_malloc(4 * n)
+        d_d, d_r = eng.device_malloc(data_pitch * n), eng.device_malloc(C.sizeof(_lib.XModemResult) * n)
+        eng.h2d(d_b, slab); eng.h2d(d_c, counts); eng.h2d(d_e, expected)
+        _lib.check(L.fskhip_xmodem_scan_device(d_b, pitch, d_c, d_e, n, d_d, data_pitch, d_r, None))
+        eng.synchronize()
+        data = np.zeros((n, data_pitch), np.uint8)
+        res = np.zeros(n * 10, np.int32)
+        eng.d2h(data, d_d); eng.d2h(res, d_r)
+        res = res.reshape(n, 10)
+        for i, want in enumerate(ref):
+            got = dict(zip(("status", "expected_after", "packets", "dropped", "consumed", "data_len", "err_seq", "err_len", "crc_rx", "crc_calc"),
+                           (int(v) for v in res[i])))
+            for k, v in got.items():
+                assert v == want[k], (pitch, sc["cases"][i]["name"], k)
+            assert data[i, :got["data_len"]].tobytes() == want["data"]
+        for p in (d_b, d_c, d_e, d_d, d_r):
+            eng.device_free(p)
+    eng.close()

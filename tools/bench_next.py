@@ -107,7 +107,7 @@ def main():
     pl = torch.randint(0, 256, (Sx, payload_len), dtype=torch.uint8, device="cuda")
     lens = torch.full((Sx,), payload_len, dtype=torch.int32, device="cuda")
     seqs = torch.randint(1, 256, (Sx,), dtype=torch.int32, device="cuda")
-    pitch = 136
+    pitch = 144  # 16-byte rows: the tiled scan kernel applies
     wire = torch.zeros((Sx, pitch), dtype=torch.uint8, device="cuda")
     wlen = torch.zeros((Sx,), dtype=torch.int32, device="cuda")
     ms_ser = timed(lambda: _lib.check(L.fskhip_xmodem_serialize_device(pl.data_ptr(), payload_len, lens.data_ptr(), seqs.data_ptr(),

@@ -97,25 +97,42 @@ __global__ __launch_bounds__(kBlock) void serialize_kernel(const uint8_t *payloa
 // per-byte state machine of the receive grammar; every lane walks its own burst front to back
 enum : uint32_t { ST_IDLE, ST_SEQ, ST_NSEQ, ST_LEN, ST_PAYLOAD, ST_CRC_HI, ST_CRC_LO, ST_DONE };
 
-template <bool ALIGNED>
-__global__ __launch_bounds__(kBlock) void scan_kernel(const uint8_t *bytes, size_t pitch, const uint32_t *counts,
-                                                       const uint32_t *expected_in, uint32_t n_streams, uint8_t *data,
-                                                       size_t data_pitch, fskhip_xmodem_result *results) {
-  __shared__ uint32_t table[256];
-  build_crc_table(table);
-  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
-  if (s >= n_streams) return;
-  RowReader<ALIGNED> rd(bytes + (size_t)s * pitch);
-  uint8_t *drow = data ? data + (size_t)s * data_pitch : nullptr;
-  const uint32_t n = counts[s];
-  uint32_t expected = expected_in[s];
-  uint32_t state = ST_IDLE, status = FSKHIP_XM_NEED_MORE;
-  uint32_t seq = 0, nseq = 0, len = 0, k = 0, crc = 0, rx = 0, start = 0;
-  uint32_t packets = 0, dropped = 0, consumed = 0, data_len = 0;
-  int32_t err_seq = -1, err_len = -1, crc_rx = -1, crc_calc = -1;
-  bool accept = false;
-  for (uint32_t pos = 0; pos < n && state != ST_DONE; pos++) {
-    const uint32_t b = rd.get(pos);
+struct Scan {
+  uint32_t state, status, expected;
+  uint32_t seq, nseq, len, k, crc, rx, start;
+  uint32_t packets, dropped, consumed, data_len;
+  int32_t err_seq, err_len, crc_rx, crc_calc;
+  bool accept;
+  uint32_t word;  // payload bytes on their way to data[]: stored a dword at a time where the row allows it
+
+  __device__ __forceinline__ void init(uint32_t expected_seq) {
+    state = ST_IDLE; status = FSKHIP_XM_NEED_MORE; expected = expected_seq;
+    seq = nseq = len = k = crc = rx = start = 0;
+    packets = dropped = consumed = data_len = 0;
+    err_seq = err_len = crc_rx = crc_calc = -1;
+    accept = false;
+    word = 0;
+  }
+
+  // assembleData (xmodem.ts:322-333): byte `off` of the stream's assembled payload.  Tentative until the packet's CRC
+  // has matched -- only data[0 .. data_len) is meaningful afterwards.  With a 4-byte aligned row the bytes are merged
+  // into dwords (one store per 4 bytes); a partial dword is flushed bytewise when its packet ends.
+  template <bool DW>
+  __device__ __forceinline__ void put(uint8_t *drow, size_t data_pitch, uint32_t off, uint32_t b, bool last) {
+    if (!drow || (size_t)off >= data_pitch) return;
+    if (!DW) { drow[off] = (uint8_t)b; return; }
+    const uint32_t sh = (off & 3u) * 8u;
+    word = (word & ~(0xFFu << sh)) | (b << sh);
+    if ((off & 3u) == 3u && (size_t)off < data_pitch) {
+      // full dword: bytes before this packet's first byte inside it were written by an earlier flush and are in `word`
+      *reinterpret_cast<uint32_t *>(drow + (off & ~3u)) = word;
+    } else if (last) {
+      for (uint32_t q = off & ~3u; q <= off; q++) drow[q] = (uint8_t)(word >> ((q & 3u) * 8u));
+    }
+  }
+
+  template <bool DW>
+  __device__ __forceinline__ void byte(const uint32_t *table, uint32_t b, uint32_t pos, uint8_t *drow, size_t data_pitch) {
     switch (state) {
       case ST_IDLE:  // xmodem.ts:238-252
         if (b == kEOT) {
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const uint8_t *bytes, size
       }
       case ST_PAYLOAD:
         if (accept) {
-          if (drow && (size_t)data_len + k < data_pitch) drow[data_len + k] = (uint8_t)b;
+          put<DW>(drow, data_pitch, data_len + k, b, k + 1 == len);
           crc = crc_step(table, crc, b);
         }
         if (++k == len) state = ST_CRC_HI;
@@ -197,26 +214,99 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const uint8_t *bytes, size
         break;
     }
   }
-  if (state != ST_IDLE && state != ST_DONE) {  // ran out of bytes inside a packet
-    status = FSKHIP_XM_TRUNCATED;
-    consumed = start;
-    if (state >= ST_PAYLOAD) {
-      err_seq = (int32_t)seq;
-      err_len = (int32_t)len;
+
+  __device__ __forceinline__ void finish(fskhip_xmodem_result *out) {
+    if (state != ST_IDLE && state != ST_DONE) {  // ran out of bytes inside a packet
+      status = FSKHIP_XM_TRUNCATED;
+      consumed = start;
+      if (state >= ST_PAYLOAD) {
+        err_seq = (int32_t)seq;
+        err_len = (int32_t)len;
+      }
+    }
+    fskhip_xmodem_result r;
+    r.status = status;
+    r.expected_after = expected;
+    r.packets = packets;
+    r.dropped = dropped;
+    r.consumed = consumed;
+    r.data_len = data_len;
+    r.err_seq = err_seq;
+    r.err_len = err_len;
+    r.crc_rx = crc_rx;
+    r.crc_calc = crc_calc;
+    *out = r;
+  }
+};
+
+// any layout: every lane walks its own row
+template <bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void scan_kernel(const uint8_t *bytes, size_t pitch, const uint32_t *counts,
+                                                       const uint32_t *expected_in, uint32_t n_streams, uint8_t *data,
+                                                       size_t data_pitch, fskhip_xmodem_result *results) {
+  __shared__ uint32_t table[256];
+  build_crc_table(table);
+  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n_streams) return;
+  RowReader<ALIGNED> rd(bytes + (size_t)s * pitch);
+  uint8_t *drow = data ? data + (size_t)s * data_pitch : nullptr;
+  const uint32_t n = counts[s];
+  Scan sc;
+  sc.init(expected_in[s]);
+  for (uint32_t pos = 0; pos < n && sc.state != ST_DONE; pos++) sc.byte<false>(table, rd.get(pos), pos, drow, data_pitch);
+  sc.finish(&results[s]);
+}
+
+// 16-byte aligned rows (the demodulator's own output slab qualifies when its pitch is a multiple of 16): one wave per
+// 64 rows walks them in 64-byte tiles staged through LDS exactly like the demodulator's sample tiles -- four coalesced
+// 16-B/lane loads of 16 rows x 64 B, chunk-major with a one-slot pad, then every lane reads its own 64 bytes -- instead
+// of 64 lanes each chasing its own cache line one dword at a time.
+__global__ __launch_bounds__(64) void scan_tiled_kernel(const uint8_t *bytes, size_t pitch, const uint32_t *counts,
+                                                         const uint32_t *expected_in, uint32_t n_streams, uint8_t *data,
+                                                         size_t data_pitch, int data_dw, fskhip_xmodem_result *results) {
+  __shared__ uint32_t table[256];
+  __shared__ uint4 stage[4 * 65];
+  build_crc_table(table);
+  const uint32_t lane = threadIdx.x;
+  const uint32_t s = blockIdx.x * 64u + lane;
+  const bool valid = s < n_streams;
+  uint8_t *drow = (data && valid) ? data + (size_t)s * data_pitch : nullptr;
+  const uint32_t n = valid ? counts[s] : 0u;
+  uint32_t n_max = n;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(n_max, o, 64); n_max = t > n_max ? t : n_max; }
+  Scan sc;
+  sc.init(valid ? expected_in[s] : 1u);
+  const uint32_t sub_row = lane >> 2, chunk = lane & 3;
+  for (uint32_t t0 = 0; t0 < n_max; t0 += 64u) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t r = blockIdx.x * 64u + 16u * i + sub_row;
+      const size_t off = (size_t)t0 + 16u * chunk;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (r < n_streams && off + 16u <= pitch) v = *reinterpret_cast<const uint4 *>(bytes + (size_t)r * pitch + off);
+      stage[chunk * 65u + 16u * i + sub_row] = v;
+    }
+    __syncthreads();
+    if (t0 < n && sc.state != ST_DONE) {
+#pragma unroll 1
+      for (uint32_t c = 0; c < 4; c++) {
+        const uint4 v = stage[c * 65u + lane];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const uint32_t pos = t0 + 16u * c + (uint32_t)q;
+          if (pos < n && sc.state != ST_DONE) {
+            const uint32_t b = (w[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+            if (data_dw) sc.byte<true>(table, b, pos, drow, data_pitch);
+            else sc.byte<false>(table, b, pos, drow, data_pitch);
+          }
+        }
+      }
     }
   }
-  fskhip_xmodem_result r;
-  r.status = status;
-  r.expected_after = expected;
-  r.packets = packets;
-  r.dropped = dropped;
-  r.consumed = consumed;
-  r.data_len = data_len;
-  r.err_seq = err_seq;
-  r.err_len = err_len;
-  r.crc_rx = crc_rx;
-  r.crc_calc = crc_calc;
-  results[s] = r;
+  if (valid) sc.finish(&results[s]);
 }
 
 bool aligned4(const void *p, size_t pitch) { return ((uintptr_t)p & 3u) == 0 && (pitch & 3u) == 0; }
@@ -339,7 +429,11 @@ int fskhip_xmodem_scan_device(const uint8_t *d_bytes, size_t pitch, const uint32
   if (!d_counts || !d_expected || !d_results) return fail(FSKHIP_E_INVALID, "fskhip_xmodem_scan_device: null buffer");
   hipStream_t st = (hipStream_t)hip_stream;
   dim3 g((n_streams + kBlock - 1) / kBlock), b(kBlock);
-  if (aligned4(d_bytes, pitch))
+  if (((uintptr_t)d_bytes & 15u) == 0 && (pitch & 15u) == 0 && pitch >= 16) {
+    const int data_dw = d_data && ((uintptr_t)d_data & 3u) == 0 && (data_pitch & 3u) == 0;
+    hipLaunchKernelGGL(scan_tiled_kernel, dim3((n_streams + 63u) / 64u), dim3(64), 0, st, d_bytes, pitch, d_counts, d_expected,
+                       n_streams, d_data, data_pitch, data_dw, d_results);
+  } else if (aligned4(d_bytes, pitch))
     hipLaunchKernelGGL(scan_kernel<true>, g, b, 0, st, d_bytes, pitch, d_counts, d_expected, n_streams, d_data, data_pitch,
                        d_results);
   else
@@ -360,7 +454,7 @@ int fskhip_xmodem_scan_host(int device, const uint8_t *bytes, size_t pitch, cons
   if (rc != FSKHIP_OK) return rc;
   DevBufs B;
   uint8_t *d_b = nullptr, *d_d = nullptr; uint32_t *d_c = nullptr, *d_e = nullptr; fskhip_xmodem_result *d_r = nullptr;
-  const size_t dp = (pitch + 3) & ~(size_t)3;
+  const size_t dp = (pitch + 15) & ~(size_t)15;  // 16-byte rows: the tiled kernel applies
   if ((rc = B.alloc(d_b, dp * n_streams)) || (rc = B.alloc(d_d, data_pitch * n_streams)) || (rc = B.alloc(d_c, n_streams)) ||
       (rc = B.alloc(d_e, n_streams)) || (rc = B.alloc(d_r, n_streams)))
     return rc;
