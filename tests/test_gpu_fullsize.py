@@ -192,3 +192,32 @@ def test_whole_tile_kernels_agree_on_ragged_batches(S, monkeypatch):
     assert digests["split"][1] >= 12 * S * 0.5
     gen.device_free(d_x)
     gen.close()
+
+
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_partial_wave_lanes_stay_out_of_rare_paths(split, monkeypatch):
+    """Regression (found by tools/soak.py): one stream in a 64-lane wave, lowered syncThreshold, a chunk schedule that
+    hands a synced state to the whole-tile kernels.  The 63 lanes beyond the batch used to reach the sync path, whose
+    amplitude-column read took their out-of-range row index as an address and faulted.  Bytes must equal the oracle's
+    (fp64: eod and status too)."""
+    import os
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    x = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_partial_wave_sync.npy"))
+    cfg = dict(syncThreshold=0.75)
+    schedule = [(0, 128), (128, 128), (256, 128), (384, 3), (387, 3), (390, 16), (406, 1000), (1406, 6038)]
+    monkeypatch.setenv("FSKHIP_SPLIT", split)
+    for prec in (wm.PRECISION_F32, wm.PRECISION_F64):
+        eng = wm.FSKEngine(1, cfg, precision=prec)
+        o = po.OracleCore(cfg)
+        for off, n in schedule:
+            out, eod = eng.demodulate_data(np.ascontiguousarray(x[:, off:off + n]))
+            ob, oe = o.demodulate(x[0, off:off + n])
+            assert out[0] == ob
+            if prec == wm.PRECISION_F64:
+                assert int(eod[0]) == oe
+        if prec == wm.PRECISION_F64:
+            st, ost = eng.get_status(0), o.status()
+            for k in ("frameStarted", "globalSampleCounter", "receivedBitsLength", "syncDetections"):
+                assert st[k] == ost[k], k
+        eng.close()

@@ -227,11 +227,17 @@ __device__ inline float lp32(float b0, float a2, float delta, float &x1, float &
 // atan2 for the discriminator: |error| <= 1.5e-7 rad.  min/max ratio through v_rcp_f32, odd
 // minimax polynomial on [0,1] (coefficients fitted for this file), quadrant by compares.  -0 counts
 // as +0 for x (the reference's averages are never -0: its sums start at +0), atan2(0, 0) = 0.
-__device__ inline float atan2_fast(float y, float x) {
+// Also returns the magnitude sqrt(x^2 + y^2) as max * sqrt(1 + (min/max)^2) -- same instruction count as squaring,
+// but it cannot underflow: in the exact-zero tail after a frame the I/Q averages decay through 1e-20 .. 1e-38, their
+// squares are zero in fp32 long before the values are, and a (false) sync detected there would set the silence
+// threshold to the mean of zeros where the reference's doubles still see the decaying amplitudes (found by
+// tools/soak.py: eod counts diverged).  Below fp32's own range (~1e-38) the paths still differ; see DESIGN.md.
+__device__ inline float atan2_amp_fast(float y, float x, float &amp) {
   const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
   const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
   const float a = mn * __builtin_amdgcn_rcpf(__builtin_fmaxf(mx, 1.0e-37f));
   const float s = a * a;
+  amp = mx * __builtin_amdgcn_sqrtf(s + 1.0f);
   float p = -4.355408570e-03f;
   p = __builtin_fmaf(p, s, 2.304014596e-02f);
   p = __builtin_fmaf(p, s, -5.777360382e-02f);
@@ -285,8 +291,7 @@ __device__ inline bool discriminate(Lane<float> &L, const Consts<float> &C, floa
   const float PI = 3.14159265358979323846f;
   float avg_i = sum_i;  // sums of the half-scale low-pass outputs = the averages (see lp_b0h)
   float avg_q = sum_q;
-  float phase = atan2_fast(avg_q, avg_i);
-  amp = __builtin_amdgcn_sqrtf(__builtin_fmaf(avg_i, avg_i, avg_q * avg_q));
+  float phase = atan2_amp_fast(avg_q, avg_i, amp);
   float dphi = phase - L.last_phase;
   float wrap = dphi > PI ? -2.0f * PI : 0.0f;
   wrap = dphi < -PI ? 2.0f * PI : wrap;
@@ -799,7 +804,7 @@ __device__ inline void fast_reset(FastLane &F, const FastMem &M, uint32_t k, uin
   F.cad = 0;
   F.acc = 0; F.wait = kBigWait; F.reload = 0;
   F.byte_cur = 0; F.bit_pos = 0;
-  F.thr_eff = matched_min;
+  F.thr_eff = M.voff < 0xFFFFFFF0u ? matched_min : 0xFFFFFFFEu;  // lanes beyond the batch stay parked
   F.sil = 0;
   F.lx1 = bc2(0.f); F.lx2 = bc2(0.f); F.ly = bc2(0.f); F.lv = bc2(0.f);
   F.px1 = 0.f; F.px2 = 0.f; F.py = 0.f; F.pv = 0.f;
@@ -821,8 +826,7 @@ __device__ inline f2 cmul(f2 z, f2 w) {  // z * w
 // phase / amplitude / slicer of one decimated sample from the pair sums (fsk.ts:247-264)
 __device__ inline bool fast_disc(FastLane &F, const FastUni &U, f2 sum, float &amp) {
   const float PI = 3.14159265358979323846f;
-  const float phase = atan2_fast(sum.y, sum.x);
-  amp = __builtin_amdgcn_sqrtf(__builtin_fmaf(sum.x, sum.x, sum.y * sum.y));
+  const float phase = atan2_amp_fast(sum.y, sum.x, amp);
   // wrap into (-pi, pi] (fsk.ts:255-257): |dphi| <= 2 pi, so one rounded quotient does both branches
   float dphi = phase - F.last_phase;
   dphi = __builtin_fmaf(-2.0f * PI, __builtin_rintf(dphi * (0.5f / PI)), dphi);
@@ -872,7 +876,8 @@ __device__ inline void fast_fsm(FastLane &F, const DemodParams &P, const DemodSt
     uint32_t slen = 0;
     if (cand & !eod) {
       const uint32_t ring_base = ist_load(M, IF_ring_len);
-      sync_now = ring_base + k >= P.sample_count;
+      // (lanes beyond the batch are parked at kernel entry and never get here; the row index below must be a real one)
+      sync_now = (ring_base + k >= P.sample_count) & (M.voff < 0xFFFFFFF0u);
       const uint32_t pushes = ist_load(M, IF_amp_len) + k;
       slen = pushes < P.amp_cap ? pushes : P.amp_cap;
     }
@@ -990,6 +995,13 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
   F.thr_eff = ILOAD(started) ? kStarted : P.matched_min;
   F.out_cnt = 0;
   if (valid && eod_counts) eod_counts[stream] = 0;  // incremented in memory by the (rare) EOD path
+  if (!valid) {
+    // Lanes beyond the batch run on zeros with a copy of the last stream's state.  Park them: no sync candidate (a
+    // threshold `matched` cannot reach), no silence run (nothing is below a negative threshold), no bit clock -- so
+    // they never enter a rare path, where their out-of-range row index would be used as an address (the sync path's
+    // amplitude-column read faulted on exactly that: tools/soak.py, S = 1 with a lowered syncThreshold).
+    F.thr_eff = 0xFFFFFFFEu; F.thr = -1.0f; F.wait = kBigWait;
+  }
 
   FastConst K;
   if (UNI) {
@@ -1027,8 +1039,8 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
   const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
 
   // Tile prefetch: 4 loads of 16 rows x 64 B; lane -> (row 16*i + lane/4, chunk lane%4), through a per-wave
-  // buffer descriptor over this wave's 64 rows (rows beyond the batch read as 0 via the bounds check, so
-  // one VGPR offset serves all four loads).  Inline asm on purpose: vmcnt counts loads AND stores in issue
+  // buffer descriptor over this wave's 64 rows (rows beyond the batch read as 0 via the bounds check on the
+  // VGPR offset).  Inline asm on purpose: vmcnt counts loads AND stores in issue
   // order and hipcc cannot count the stores this loop issues conditionally, so with compiler-visible loads
   // it waits vmcnt(0) at the top of every tile -- i.e. for the amplitude-ring stores issued a few hundred
   // cycles earlier (~1-2 us each).  With asm loads the wait is ours: each tile issues at least 8 VMEM ops
@@ -1047,11 +1059,15 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
   const uint32_t in_voff = (uint32_t)((sub_row * pitch + 4u * chunk) * 4u);
   const uint32_t in_row16 = (uint32_t)(16u * pitch * 4u);   // byte step between the four loads
   v4f pre0, pre1, pre2, pre3;
-#define FSK_BLOAD4(dst, soff) \
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(in_voff), "s"(in_rsrc), "s"(soff) : "memory")
+  // The 16-row step between the four loads rides in the VGPR offset, not in soffset: the bounds check that turns rows
+  // beyond the batch into zeros covers voffset only -- soffset is added to the address unchecked, and with it a partial
+  // wave read (and for a small batch faulted on) memory past the end of the buffer (found by tools/soak.py).
+#define FSK_BLOAD4(dst, rows16, soff)                                                                      \
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(in_voff + (rows16) * in_row16), \
+               "s"(in_rsrc), "s"(soff) : "memory")
   {
-    const uint32_t s0 = 0u, s1 = in_row16, s2 = 2u * in_row16, s3 = 3u * in_row16;
-    FSK_BLOAD4(pre0, s0); FSK_BLOAD4(pre1, s1); FSK_BLOAD4(pre2, s2); FSK_BLOAD4(pre3, s3);
+    const uint32_t s0 = 0u;
+    FSK_BLOAD4(pre0, 0u, s0); FSK_BLOAD4(pre1, 1u, s0); FSK_BLOAD4(pre2, 2u, s0); FSK_BLOAD4(pre3, 3u, s0);
   }
   // everything loaded so far (state, constants, first tile) is complete before the loop; the builtin form
   // also tells hipcc's own scoreboard, so it needs no vmcnt wait inside the loop
@@ -1070,8 +1086,7 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
     {
       // next tile (the last iteration re-reads its own tile: always in bounds, never used)
       const uint32_t tn = (uint32_t)((t0 + kFastTile < n ? t0 + kFastTile : t0) * 4u);
-      const uint32_t s0 = tn, s1 = tn + in_row16, s2 = tn + 2u * in_row16, s3 = tn + 3u * in_row16;
-      FSK_BLOAD4(pre0, s0); FSK_BLOAD4(pre1, s1); FSK_BLOAD4(pre2, s2); FSK_BLOAD4(pre3, s3);
+      FSK_BLOAD4(pre0, 0u, tn); FSK_BLOAD4(pre1, 1u, tn); FSK_BLOAD4(pre2, 2u, tn); FSK_BLOAD4(pre3, 3u, tn);
     }
 
     if (UNI) {  // re-seed the phasor from the exact accumulator (first sample of this tile)
@@ -1261,10 +1276,11 @@ __global__ __launch_bounds__(128) void demod_split_kernel(
     // hipcc places (conservative at the loop header) are hidden behind the barrier it would wait at anyway
     auto load_tile = [&](size_t t, v4f &a, v4f &b, v4f &c, v4f &d) {
       const uint32_t tn = (uint32_t)((t < n_tiles ? t : n_tiles - 1) * kFastTile * 4u);
+      // (row step in the bounds-checked VGPR offset, see demod_fast_kernel)
       a = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff, tn, 0));
-      b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff, tn + in_row16, 0));
-      c = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff, tn + 2u * in_row16, 0));
-      d = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff, tn + 3u * in_row16, 0));
+      b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff + in_row16, tn, 0));
+      c = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff + 2u * in_row16, tn, 0));
+      d = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff + 3u * in_row16, tn, 0));
     };
     v4f a0, a1, a2, a3, b0, b1, b2, b3;
     load_tile(0, a0, a1, a2, a3);
@@ -1332,6 +1348,7 @@ __global__ __launch_bounds__(128) void demod_split_kernel(
     F.thr_eff = ILOAD(started) ? kStarted : P.matched_min;
     F.out_cnt = 0;
     if (valid && eod_counts) eod_counts[stream] = 0;
+    if (!valid) { F.thr_eff = 0xFFFFFFFEu; F.thr = -1.0f; F.wait = kBigWait; }  // park lanes beyond the batch (see demod_fast_kernel)
     FastConst K;
     K.bp_b0 = 0.f; K.bp_a1 = 0.f; K.bp_a2 = 0.f;
     if (UNI) {
