@@ -33,13 +33,15 @@ def counts_comparable(cfg, prec):
 SOFT = {"n": 0, "first": None}
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0x50A4
+def main(budget=None, seed=None, max_rounds=None):
+    if budget is None:
+        budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    if seed is None:
+        seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0x50A4
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     rounds = streams = 0
-    while time.time() < t_end:
+    while time.time() < t_end and (max_rounds is None or rounds < max_rounds):
         if os.environ.get("SOAK_ONLY_ROUND") and rounds > int(os.environ["SOAK_ONLY_ROUND"]):
             break
         cfg = CONFIGS[int(rng.integers(len(CONFIGS)))]
@@ -127,6 +129,7 @@ def main():
         streams += S
     print("soak ok: %d rounds, %d stream-runs, seed %#x; fp32 timing differences with identical bytes: %d %s"
           % (rounds, streams, seed, SOFT["n"], SOFT["first"] or ""))
+    return rounds, streams, SOFT["n"]
 
 
 if __name__ == "__main__":

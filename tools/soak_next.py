@@ -133,13 +133,17 @@ def fir_round(rng):
     return S
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0x4E58
+def main(budget=None, seed=None, max_rounds=None):
+    if budget is None:
+        budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    if seed is None:
+        seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0x4E58
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     counts = {"processor": 0, "scan": 0, "fir": 0}
-    while time.time() < t_end:
+    rounds = 0
+    while time.time() < t_end and (max_rounds is None or rounds < max_rounds):
+        rounds += 1
         r = rng.random()
         if r < 0.6:
             counts["processor"] += processor_round(rng)
@@ -148,6 +152,7 @@ def main():
         else:
             counts["fir"] += fir_round(rng)
     print("soak_next ok: seed %#x, stream-runs %s" % (seed, counts))
+    return counts
 
 
 if __name__ == "__main__":
