@@ -55,14 +55,22 @@ def main(budget=None, seed=None, max_rounds=None):
         if target and os.environ.get("SOAK_FORCE_SPLIT"):
             os.environ["FSKHIP_SPLIT"] = os.environ["SOAK_FORCE_SPLIT"]
         os.environ["FSKHIP_SPLIT_LAST"] = os.environ["FSKHIP_SPLIT"]
-        eng = wm.FSKEngine(S, cfg, precision=prec)
+        # a quarter of the rounds: per-stream tone pairs (BASELINE config #4) -> the per-stream-constant kernel variants
+        per_stream = rng.random() < 0.25 and "markFrequency" not in cfg and cfg.get("sampleRate", 48000) == 48000
+        if per_stream:
+            base = float(rng.choice([900, 1300, 1700]))
+            cfgs = [dict(cfg, markFrequency=base + 13 * (s % 40), spaceFrequency=base + 200 + 13 * (s % 40)) for s in range(S)]
+        else:
+            cfgs = [cfg] * S
+        writeback = rng.random() < 0.3
+        eng = wm.FSKEngine(S, cfgs if per_stream else cfg, precision=prec)
         os.environ.pop("FSKHIP_SPLIT")
         if os.environ.get("SOAK_VERBOSE"):
             print("round", rounds, cfg, "prec", prec, "S", S, "split", eng and os.environ.get("FSKHIP_SPLIT_LAST"), flush=True)
         if not eng.demod_supported():
             eng.close()
             continue
-        oracles = [po.OracleCore(cfg) for _ in range(S)]
+        oracles = [po.OracleCore(cfgs[s]) for s in range(S)]
         frames = int(rng.integers(1, 4))
         payloads = [[bytes(rng.integers(0, 256, int(rng.integers(1, 24)), dtype=np.uint8)) for _ in range(frames)] for _ in range(S)]
         sigs = [np.concatenate([np.zeros(int(rng.integers(0, 300)), np.float32)] +
@@ -95,10 +103,24 @@ def main(budget=None, seed=None, max_rounds=None):
                 continue
             if os.environ.get("SOAK_VERBOSE"):
                 print("  call", off, n, flush=True)
-            out, eod = eng.demodulate_data(x[:, off:off + n])
+            chunk = x[:, off:off + n].copy()  # (ascontiguousarray would alias x when the chunk is the whole buffer)
+            out, eod = eng.demodulate_data(chunk, writeback_agc=writeback)
             log.append(("call", off, n))
             for s in range(S):
                 ob, oe = oracles[s].demodulate(x[s, off:off + n])
+                if writeback and cfg.get("agcEnabled", True):
+                    # fsk.ts:55: the input buffer holds the AGC-scaled samples afterwards (fp64 engines: the same floats)
+                    ref = oracles[s].last_agc_out
+                    if prec == wm.PRECISION_F64:
+                        assert np.array_equal(chunk[s], ref), ("agc writeback", cfg, S, s, off, n)
+                    else:
+                        d = np.abs(chunk[s] - ref)
+                        i = int(np.argmax(d))
+                        # fp32: where |x*g| lands within an ulp of the 0.5 attack/release boundary (fsk.ts:60) the two
+                        # paths can take different branches; the gains then differ by up to (1-g)*(attack-release),
+                        # a few per cent for a few hundred samples, until the AGC has pulled them together again
+                        assert d[i] <= 0.05 * max(1.0, float(np.max(np.abs(ref)))), (
+                            "agc writeback", cfg, S, s, off, n, i, float(d[i]), float(chunk[s, i]), float(ref[i]), float(x[s, off + i]), per_stream)
                 got[s] += out[s]
                 want[s] += ob
                 if int(eod[s]) != oe and counts_comparable(cfg, prec) and prec == wm.PRECISION_F32 and out[s] == ob:
