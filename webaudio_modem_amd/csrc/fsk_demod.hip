@@ -1227,7 +1227,8 @@ __global__ __launch_bounds__(64, (WB ? 3 : FSK_FAST_WAVES)) void demod_fast_kern
 // call.  (A more even cut -- NCO, mixer and I/Q low-pass in the front wave too, run speculatively and repaired
 // after a reset -- was built, passed parity, and was slower: 269 vs 285 Gsamples/s at 65 536 streams; the lock
 // step of the two waves costs more than the better balance gains.  Dealing the roles by CU arrival order read
-// from HW_ID made no difference either.)
+// from HW_ID made no difference either, and running both pairs of a chunk as one straight-line block in the back wave, with a
+// recompute of the second pair after a reset, was slower as well: 287 vs 307.)
 // ================================================================================================
 template <bool WB, bool UNI>
 __global__ __launch_bounds__(128) void demod_split_kernel(
