@@ -361,3 +361,33 @@ def test_errors_are_loud():
     with pytest.raises(ValueError):
         eng.demodulate_data(np.zeros((3, 16), np.float32))
     eng.close()
+
+
+@pytest.mark.parametrize("pname,prec,tol", PRECISIONS)
+def test_single_stream_reset_at_odd_decimator_phase(pname, prec, tol):
+    """Regression (tools/soak.py): a one-stream engine reset while its /2 decimator is mid-pair.  The device restarts the
+    decimator; the host's notion of the phase has to follow, or a later odd-length call flips it the wrong way and the
+    whole-tile kernels are handed a stream that is mid-pair."""
+    from oracle import pyoracle as po
+    g = golden()
+    base = g.array("d_default_Hello_c128.in")
+    x = np.concatenate([np.zeros(700, np.float32), base, np.zeros(300, np.float32)])
+    eng = _engine({}, prec)
+    o = po.OracleCore({})
+    got = want = b""
+    off = 0
+    for step in (129, 128, "reset", 128, 129, 1000, 10 ** 9):
+        if step == "reset":
+            eng.reset(0)
+            o.reset()
+            continue
+        n = min(step, x.size - off)
+        out, eod = eng.demodulate_data(x[off:off + n].reshape(1, -1).copy())
+        ob, oe = o.demodulate(x[off:off + n])
+        got += out[0]
+        want += ob
+        assert int(eod[0]) == oe
+        off += n
+    assert got == want == b"Hello"
+    _check_status(eng.get_status(0), o.status(), tol, o.status()["agcGain"])
+    eng.close()

@@ -652,6 +652,9 @@ int fskhip_reset(fskhip_engine *e, int64_t stream) {
     // the other streams may sit mid-pair of the /2 decimator: from now on this stream pushes into its
     // rings at other instants than its neighbours, for good (ring positions are never re-aligned)
     if (e->n_streams > 1 && e->ds_parity) e->ds_uniform = false;
+    // a one-stream engine: its only decimator has just restarted at a pair boundary (found by tools/soak.py: the
+    // host kept believing in the odd phase and later handed a mid-pair stream to the whole-tile kernels)
+    if (e->n_streams == 1) e->ds_parity = 0;
   }
   return FSKHIP_OK;
 }
