@@ -100,7 +100,7 @@ def main(budget=None, seed=None, max_rounds=None):
                 off += n
                 if rng.random() < 0.03:
                     rng.integers(S)
-                continue
+                continue  # (replay mode: the reset-all / empty-call branches draw nothing)
             if os.environ.get("SOAK_VERBOSE"):
                 print("  call", off, n, flush=True)
             chunk = x[:, off:off + n].copy()  # (ascontiguousarray would alias x when the chunk is the whole buffer)
@@ -130,11 +130,23 @@ def main(budget=None, seed=None, max_rounds=None):
                     np.save("gpurun_out/soak_fail_x.npy", x[s])
                     raise AssertionError(("mismatch", cfg, prec, S, s, off, n, int(eod[s]), oe, out[s], ob, log[-12:]))
             off += n
-            if rng.random() < 0.03:
+            u = rng.random()
+            if u < 0.03:
                 r = int(rng.integers(S))
                 eng.reset(r)
                 oracles[r].reset()
                 log.append(("reset", r, off))
+            elif u < 0.04:
+                eng.reset(-1)
+                for o in oracles:
+                    o.reset()
+                log.append(("reset all", off))
+            elif u < 0.05:
+                out0, eod0 = eng.demodulate_data(np.zeros((S, 0), np.float32))  # empty call (fsk-demodulation.node.test.ts:38-41)
+                for s in range(S):
+                    ob, oe = oracles[s].demodulate(np.zeros(0, np.float32))
+                    assert out0[s] == ob == b"" and int(eod0[s]) == oe == 0
+                log.append(("empty", off))
         for s in range(S):
             assert got[s] == want[s], ("bytes", cfg, prec, S, s, got[s][:8], want[s][:8])
         sel = rng.choice(S, min(S, 8), replace=False) if counts_comparable(cfg, draw_prec) else []
