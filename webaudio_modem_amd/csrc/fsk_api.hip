@@ -130,7 +130,9 @@ struct fskhip_engine {
   bool ds_uniform = true;
   uint32_t ds_parity = 0;        // downsample.counter shared by all streams while ds_uniform
   bool force_generic = false;    // FSKHIP_FORCE_GENERIC=1: never use the fast kernel (tests)
-  bool use_split = false;        // two waves per 64-stream group (demod_split_kernel): batches of at most one wave per SIMD
+  bool use_split = false;        // two waves per 64-stream group (demod_split_kernel): batches of fewer than two waves per SIMD
+  uint32_t split_cus = 256;
+  bool split_forced = false;     // FSKHIP_SPLIT was set: skip the residency check too
   bool demod_ok = true;          // false: configuration the demodulator kernels do not implement
   std::string demod_why;
   uint32_t trace_cap = 0;
@@ -288,14 +290,17 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   e->device = device; e->precision = precision; e->n_streams = n_streams; e->cfg0 = c0;
   if (const char *fg = getenv("FSKHIP_FORCE_GENERIC")) e->force_generic = fg[0] == '1';
   {
-    // with at most one wave per SIMD the one-wave-per-group kernel cannot hide its own dependency stalls; the
-    // split kernel gives every group two instruction streams (measured: 254 -> 303 Gsamples/s at 65 536 streams,
-    // 16 -> 21 at 4 096, no gain from 131 072 up).  FSKHIP_SPLIT=0/1 overrides (tests, measurements).
+    // below two waves per SIMD the one-wave-per-group kernel cannot hide its own dependency stalls; the split kernel
+    // gives every group two instruction streams (measured, Gsamples/s one-wave -> split: 16 -> 21 at 4 096 streams,
+    // 254 -> 307 at 65 536, 328 -> 356 at 98 304, 383 -> 399 at 114 688, equal at 131 072), as long as all its
+    // workgroups' LDS tiles fit on the CUs at once.  FSKHIP_SPLIT=0/1 overrides (tests, measurements).
     hipDeviceProp_t prop;
-    int simds = 1024;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) simds = prop.multiProcessorCount * 4;
-    e->use_split = (n_streams + 63) / 64 <= (uint32_t)simds;
-    if (const char *sp = getenv("FSKHIP_SPLIT")) e->use_split = sp[0] == '1';
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const uint32_t n_blocks = (n_streams + 63) / 64;
+    e->use_split = n_blocks < (uint32_t)cus * 8u;  // < 2 waves per SIMD (4 SIMDs per CU)
+    e->split_cus = (uint32_t)cus;
+    if (const char *sp = getenv("FSKHIP_SPLIT")) { e->use_split = sp[0] == '1'; e->split_forced = true; }
   }
 
   // calculateParameters (fsk.ts:426-444), in doubles like the reference
@@ -539,7 +544,10 @@ int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_
     if (!e->force_generic && demod_fast_applicable(e->precision, e->ds_uniform && e->ds_parity == 0, e->P,
                                                    e->S, d_samples, pitch))
       n_fast = n & ~(size_t)15;
-    if (n_fast && e->use_split && demod_split_lds_bytes(e->P) <= 64 * 1024)
+    // (the split kernel's workgroups must all be resident: LDS per workgroup x workgroups per CU within 160 KB)
+    const size_t split_lds = demod_split_lds_bytes(e->P);
+    const size_t wgs_per_cu = (e->n_blocks + e->split_cus - 1) / e->split_cus;
+    if (n_fast && e->use_split && split_lds <= 64 * 1024 && (wgs_per_cu * split_lds <= 160 * 1024 || e->split_forced))
       HIP_TRY(launch_demod_split(wb, e->P, e->S, d_samples, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
     else if (n_fast)
       HIP_TRY(launch_demod_fast(wb, e->P, e->S, d_samples, n_fast, pitch, d_out, out_pitch, d_out_counts,
