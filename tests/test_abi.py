@@ -154,5 +154,9 @@ def test_fast_kernel_never_spills():
     for k, v in fast.items():
         if "ILb0E" in k:  # the plain (no write-back) variants are built for 4 waves per SIMD
             assert v["VGPRs"] <= 128, (k, v)
+    split = {k: v for k, v in res.items() if "demod_split_kernel" in k}
+    assert len(split) == 4
+    for name, v in split.items():
+        assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
     # the registers the asm prefetch lands in are never touched while a load may still be in flight
     assert check_isa.prefetch_register_hazards() == []
