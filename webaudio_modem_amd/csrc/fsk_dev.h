@@ -1,0 +1,86 @@
+// fsk_dev.h -- device helpers shared by the demodulator translation units (fsk_demod.hip: generic + r01 whole-tile
+// kernels; fsk_pipe.hip: the free-running front / ZIR-corrected back kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fsk_params.h"
+
+namespace fsk {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+static constexpr int kFastTile = 16;
+static constexpr uint32_t kStarted = 0xFFFFFFFFu;  // thr_eff while a frame is started (matched_min is <= 0xFFFFFFFE)
+
+__device__ inline uint32_t popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+__device__ inline uint32_t popc(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Low-pass biquad in "velocity" form.  With v = y[n-1] - y[n-2] kept as state,
+//   y[n] = y[n-1] + a2*v + (b0*(x + 2*x1 + x2) - delta*y[n-1]),   delta = 1 + a1 + a2
+// is algebraically the reference's Direct Form I (filters.ts:47-76) but the poles sit close to
+// z = 1 (cutoff = baud << fs), where DF-I in f32 amplifies both coefficient and state rounding by
+// 1/|A(1)| ~ 700 (300 baud); here the rounding of y is fed back only through delta ~ 1.5e-3.
+// State: y holds y[n-1], v holds the velocity.
+// GAIN = false is the variant whose input already carries the b0 gain (the I/Q filters).
+template <bool GAIN = true>
+__device__ inline float lp32(float b0, float a2, float delta, float &x1, float &x2, float &y, float &v, float x) {
+  float t = __builtin_fmaf(2.0f, x1, x) + x2;
+  float u = GAIN ? __builtin_fmaf(-delta, y, b0 * t) : __builtin_fmaf(-delta, y, t);
+  v = __builtin_fmaf(a2, v, u);
+  y = y + v;
+  x2 = x1; x1 = x;
+  return y;
+}
+
+// atan2 for the discriminator: |error| <= 1.5e-7 rad.  min/max ratio through v_rcp_f32, odd
+// minimax polynomial on [0,1] (coefficients fitted for this file), quadrant by compares.  -0 counts
+// as +0 for x (the reference's averages are never -0: its sums start at +0), atan2(0, 0) = 0.
+// Also returns the magnitude sqrt(x^2 + y^2) as max * sqrt(1 + (min/max)^2) -- same instruction count as squaring,
+// but it cannot underflow: in the exact-zero tail after a frame the I/Q averages decay through 1e-20 .. 1e-38, their
+// squares are zero in fp32 long before the values are, and a (false) sync detected there would set the silence
+// threshold to the mean of zeros where the reference's doubles still see the decaying amplitudes (found by
+// tools/soak.py: eod counts diverged).  Below fp32's own range (~1e-38) the paths still differ; see DESIGN.md.
+__device__ inline float atan2_amp_fast(float y, float x, float &amp) {
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+  const float a = mn * __builtin_amdgcn_rcpf(__builtin_fmaxf(mx, 1.0e-37f));
+  const float s = a * a;
+  amp = mx * __builtin_amdgcn_sqrtf(s + 1.0f);
+  float p = -4.355408570e-03f;
+  p = __builtin_fmaf(p, s, 2.304014596e-02f);
+  p = __builtin_fmaf(p, s, -5.777360382e-02f);
+  p = __builtin_fmaf(p, s, 9.794235514e-02f);
+  p = __builtin_fmaf(p, s, -1.397658244e-01f);
+  p = __builtin_fmaf(p, s, 1.996270403e-01f);
+  p = __builtin_fmaf(p, s, -3.333165903e-01f);
+  float r = __builtin_fmaf(a * s, p, a);
+  r = ay > ax ? 1.57079632679489662f - r : r;
+  r = x < 0.0f ? 3.14159265358979323846f - r : r;
+  return __builtin_copysignf(r, y);
+}
+
+// How the whole-tile kernels' rare paths reach the per-stream integer state in HBM: one buffer descriptor (SGPRs), the
+// field offset as the SGPR soffset, one VGPR lane offset (row*4, or out of range for lanes beyond the batch, whose
+// stores the bounds check then drops).
+struct FastMem {
+  __amdgpu_buffer_rsrc_t is_rsrc;    // integer state [IF_COUNT][n_streams]
+  uint32_t fld;                      // bytes per field
+  uint32_t voff;                     // row*4, or 0xFFFFFFF0 for lanes beyond the batch
+};
+__device__ inline uint32_t ist_load(const FastMem &M, uint32_t field) {
+  return __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, M.voff, field * M.fld, 0);
+}
+__device__ inline void ist_store(const FastMem &M, uint32_t field, uint32_t v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, M.is_rsrc, M.voff, field * M.fld, 0);
+}
+
+}  // namespace fsk
