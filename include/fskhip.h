@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FSKHIP_ABI_VERSION 1
+#define FSKHIP_ABI_VERSION 2
 #define FSKHIP_MAX_PATTERN_BYTES 16
 
 enum {
@@ -86,11 +86,14 @@ void fskhip_default_config(fskhip_config *cfg);
  * markFrequency / spaceFrequency / preFilterBandwidth; every other field must be equal across
  * streams -- BASELINE config #4).  `device` is the HIP device ordinal.  `precision` is
  * FSKHIP_PRECISION_*.
- * The modulator supports every configuration.  The demodulator does not implement: a fractional
- * sync-ring capacity (maxSyncBits*dsSPB*1.1 not an integer, e.g. 44.1 kHz; the reference's ring
- * stops working after one wrap there, fsk.ts:149 / utils.ts:38-48), more than 63 preamble+SFD
- * pattern bits, or dsSPB too large for LDS: create succeeds, fskhip_demod_supported() is 0 and
- * fskhip_demodulate_* return FSKHIP_E_UNSUPPORTED with the reason (loud, no fallback).
+ * The modulator supports every configuration.  The demodulator reproduces the reference's
+ * FRACTIONAL sync-ring capacities too (maxSyncBits*dsSPB*1.1 not an integer, fsk.ts:149: 44.1 kHz,
+ * or 48 kHz with parity / two stop bits / longer preambles; the reference's RingBuffer freezes
+ * after floor(capacity) pushes there, utils.ts:38-48, and so does this one).  Not implemented:
+ * capacities whose fractional write index turns integral again within 2^40 pushes (x.5 and the
+ * like), more than 63 preamble+SFD pattern bits, dsSPB too large for LDS: create succeeds,
+ * fskhip_demod_supported() is 0 and fskhip_demodulate_* return FSKHIP_E_UNSUPPORTED with the
+ * reason (loud, no fallback).
  * FSKHIP_E_UNSUPPORTED at create: per-stream configs that differ in a shared field.
  */
 int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams, int device,
@@ -98,6 +101,18 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
 int fskhip_destroy(fskhip_engine *e);
 
 uint32_t fskhip_n_streams(const fskhip_engine *e);
+
+/*
+ * Upper bound on the bytes ONE demodulate call of n_per_stream samples can return per stream (a byte
+ * takes bitsPerByte >= 8 bit times of samplesPerBit samples, fsk.ts:438-439): size out_pitch with it.
+ */
+size_t fskhip_max_bytes(const fskhip_engine *e, size_t n_per_stream);
+
+/*
+ * Name of the kernel the last fskhip_demodulate_device call launched for its whole 16-sample tiles
+ * ("" before the first call): measurement harnesses report it instead of guessing the dispatch.
+ */
+const char *fskhip_last_kernel(const fskhip_engine *e);
 
 /*
  * demodulateData(samples) (fsk.ts:190-222) for every stream: `samples` is [n_streams][pitch]

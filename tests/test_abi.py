@@ -45,7 +45,7 @@ def test_header_symbols_all_exported(lib):
 
 def test_abi_version_and_default_config(lib):
     L = lib.lib()
-    assert L.fskhip_abi_version() == 1
+    assert L.fskhip_abi_version() == 2
     c = lib.Config()
     L.fskhip_default_config(C.byref(c))
     # DEFAULT_FSK_CONFIG fsk.ts:19-33
@@ -137,9 +137,9 @@ def test_product_never_imports_oracle():
                 assert "oracle" not in src.lower(), os.path.join(dirpath, f)
 
 
-def test_fast_kernel_never_spills():
-    """tools/check_isa.py: the fast demod kernel's asm-issued prefetch is only safe without spills,
-    and its plain variant is built for 4 waves per SIMD (<= 128 VGPRs)."""
+def test_whole_tile_kernels_never_spill():
+    """tools/check_isa.py: the one-wave kernel's asm-issued prefetch is only safe without spills; it is built for 3 waves
+    per SIMD (<= 168 VGPRs), the two-wave kernel for 4 workgroups per CU (<= 128)."""
     import shutil
     import sys
     if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
@@ -147,16 +147,15 @@ def test_fast_kernel_never_spills():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_isa
     res = check_isa.kernel_resources()
-    fast = {k: v for k, v in res.items() if "demod_fast_kernel" in k}
-    assert len(fast) == 4  # <write-back, uniform-constants>
-    for name, v in fast.items():
+    fused = {k: v for k, v in res.items() if "demod_fused_kernel" in k}
+    assert len(fused) == 4  # <write-back, uniform-constants>
+    for name, v in fused.items():
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
-    for k, v in fast.items():
-        if "ILb0E" in k:  # the plain (no write-back) variants are built for 4 waves per SIMD
-            assert v["VGPRs"] <= 128, (k, v)
-    split = {k: v for k, v in res.items() if "demod_split_kernel" in k}
-    assert len(split) == 4
-    for name, v in split.items():
+        assert v["VGPRs"] <= 168, (name, v)
+    pipe = {k: v for k, v in res.items() if "demod_pipe_kernel" in k}
+    assert len(pipe) == 4
+    for name, v in pipe.items():
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
+        assert v["VGPRs"] <= 128, (name, v)
     # the registers the asm prefetch lands in are never touched while a load may still be in flight
     assert check_isa.prefetch_register_hazards() == []

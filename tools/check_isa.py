@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Static check of the compiled fast demod kernel (runs anywhere hipcc is installed, no GPU):
-its tile prefetch uses inline-asm loads whose results are only valid after a hand-placed s_waitcnt, so
+"""Static check of the compiled whole-tile demod kernels of fsk_pipe.hip (runs anywhere hipcc is installed, no GPU):
+the one-wave kernel's tile prefetch uses inline-asm loads whose results are only valid after a hand-placed s_waitcnt, so
 the register allocator must never spill inside that kernel (a spill store of an in-flight load result
-would save garbage), and the plain variant must fit 128 VGPRs (4 waves per SIMD)."""
+would save garbage); the one-wave kernel must fit 168 VGPRs (3 waves per SIMD), the two-wave kernel 128."""
 import os
 import re
 import subprocess
@@ -13,9 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_resources():
-    src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_demod.hip")
+    src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_pipe.hip")
     with tempfile.TemporaryDirectory() as tmp:
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
                "-c", src, "-o", os.path.join(tmp, "d.o"), "-Rpass-analysis=kernel-resource-usage"]
         out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
     res, cur = {}, None
@@ -36,10 +36,10 @@ def prefetch_register_hazards():
     destination VGPRs must not be touched.  Returns a list of violations found in the fast kernels' ISA:
     any instruction after the in-loop prefetch that uses those registers without an `s_waitcnt vmcnt(0)` (the
     epilogue) or the loop-top `s_waitcnt vmcnt(8)` + ds_write (the next iteration) in between."""
-    src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_demod.hip")
+    src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_pipe.hip")
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "d.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
                         "-S", "--cuda-device-only", "-o", asm, src], capture_output=True, text=True, check=True)
         text = open(asm).read()
 
@@ -52,9 +52,9 @@ def prefetch_register_hazards():
         return out
 
     problems = []
-    found = list(re.finditer(r"^(_ZN3fsk17demod_fast_kernel\w+):[^\n]*\n", text, re.M))
+    found = list(re.finditer(r"^(_ZN3fsk18demod_fused_kernel\w+):[^\n]*\n", text, re.M))
     if len(found) != 4:
-        problems.append(("demod_fast_kernel", "expected 4 kernel bodies in the ISA, found %d" % len(found)))
+        problems.append(("demod_fused_kernel", "expected 4 kernel bodies in the ISA, found %d" % len(found)))
     for m in found:
         body = text[m.end():text.index(".Lfunc_end", m.end())].split("\n")
         loads = [i for i, l in enumerate(body) if "buffer_load_dwordx4" in l]
@@ -110,7 +110,7 @@ if __name__ == "__main__":
     r = kernel_resources()
     bad = 0
     for name, v in r.items():
-        if "demod_fast_kernel" in name:
+        if "demod_fused_kernel" in name:
             print(name[:60], v)
             if v.get("ScratchSize [bytes/lane]", 0) or v.get("VGPRs Spill", 0):
                 bad += 1

@@ -165,6 +165,70 @@ KERNEL_BEGIN(k_dsread_fma_mix)
                  : "=&v"(v), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(addr), "v"(b), "v"(c) : "memory"); a7 += v.x; }
 KERNEL_END
 
+// ---- second batch: which encodings are FMA-class? -----------------------------------------------
+#define OP_K_LSHLREV(d) "v_lshlrev_b32 " d ", 1, " d "\n\t"
+KERNEL_BEGIN(k_lshlrev) asm volatile(IND32(OP_K_LSHLREV) S_REGS); KERNEL_END
+#define OP_K_LSHRREV(d) "v_lshrrev_b32 " d ", 31, " d "\n\t"
+KERNEL_BEGIN(k_lshrrev) asm volatile(IND32(OP_K_LSHRREV) S_REGS); KERNEL_END
+#define OP_K_ASHRREV(d) "v_ashrrev_i32 " d ", 31, " d "\n\t"
+KERNEL_BEGIN(k_ashrrev) asm volatile(IND32(OP_K_ASHRREV) S_REGS); KERNEL_END
+#define OP_K_XOR(d) "v_xor_b32 " d ", " d ", %8\n\t"
+KERNEL_BEGIN(k_xor) asm volatile(IND32(OP_K_XOR) S_REGS); KERNEL_END
+#define OP_K_OR(d) "v_or_b32 " d ", " d ", %8\n\t"
+KERNEL_BEGIN(k_or) asm volatile(IND32(OP_K_OR) S_REGS); KERNEL_END
+#define OP_K_SUBF(d) "v_sub_f32 " d ", " d ", %8\n\t"
+KERNEL_BEGIN(k_subf) asm volatile(IND32(OP_K_SUBF) S_REGS); KERNEL_END
+#define OP_K_ADDF(d) "v_add_f32 " d ", " d ", %8\n\t"
+KERNEL_BEGIN(k_addf) asm volatile(IND32(OP_K_ADDF) S_REGS); KERNEL_END
+#define OP_K_MOVV(d) "v_mov_b32 " d ", %8\n\t"
+KERNEL_BEGIN(k_movv) asm volatile(IND32(OP_K_MOVV) S_REGS); KERNEL_END
+#define OP_K_ANDOR(d) "v_and_or_b32 " d ", " d ", %8, %9\n\t"
+KERNEL_BEGIN(k_andor) asm volatile(IND32(OP_K_ANDOR) S_REGS); KERNEL_END
+#define OP_K_ADD3(d) "v_add3_u32 " d ", " d ", %8, %9\n\t"
+KERNEL_BEGIN(k_add3) asm volatile(IND32(OP_K_ADD3) S_REGS); KERNEL_END
+#define OP_K_LSHLADD(d) "v_lshl_add_u32 " d ", " d ", 1, %8\n\t"
+KERNEL_BEGIN(k_lshladd) asm volatile(IND32(OP_K_LSHLADD) S_REGS); KERNEL_END
+#define OP_K_ALIGNBIT(d) "v_alignbit_b32 " d ", " d ", %8, 31\n\t"
+KERNEL_BEGIN(k_alignbit) asm volatile(IND32(OP_K_ALIGNBIT) S_REGS); KERNEL_END
+#define OP_K_MINF(d) "v_min_f32 " d ", " d ", %8\n\t"
+KERNEL_BEGIN(k_minf) asm volatile(IND32(OP_K_MINF) S_REGS); KERNEL_END
+#define OP_K_SUBU(d) "v_sub_u32 " d ", " d ", %8\n\t"
+KERNEL_BEGIN(k_subu) asm volatile(IND32(OP_K_SUBU) S_REGS); KERNEL_END
+#define OP_K_SUBREV(d) "v_subrev_u32 " d ", " d ", %8\n\t"
+KERNEL_BEGIN(k_subrev) asm volatile(IND32(OP_K_SUBREV) S_REGS); KERNEL_END
+#define OP_K_MULLO(d) "v_mul_lo_u32 " d ", " d ", %8\n\t"
+KERNEL_BEGIN(k_mullo) asm volatile(IND32(OP_K_MULLO) S_REGS); KERNEL_END
+#define OP_K_MULU24(d) "v_mul_u32_u24 " d ", " d ", %8\n\t"
+KERNEL_BEGIN(k_mulu24) asm volatile(IND32(OP_K_MULU24) S_REGS); KERNEL_END
+#define OP_K_MADU24(d) "v_mad_u32_u24 " d ", " d ", %8, %9\n\t"
+KERNEL_BEGIN(k_madu24) asm volatile(IND32(OP_K_MADU24) S_REGS); KERNEL_END
+#define OP_K_BFE(d) "v_bfe_u32 " d ", " d ", 3, 5\n\t"
+KERNEL_BEGIN(k_bfe) asm volatile(IND32(OP_K_BFE) S_REGS); KERNEL_END
+#define OP_K_PERM(d) "v_perm_b32 " d ", " d ", %8, %9\n\t"
+KERNEL_BEGIN(k_perm) asm volatile(IND32(OP_K_PERM) S_REGS); KERNEL_END
+#define OP_K_MULLEGACY(d) "v_mul_legacy_f32 " d ", " d ", %8\n\t"
+KERNEL_BEGIN(k_mullegacy) asm volatile(IND32(OP_K_MULLEGACY) S_REGS); KERNEL_END
+#define OP_K_LDEXP(d) "v_ldexp_f32 " d ", " d ", 1\n\t"
+KERNEL_BEGIN(k_ldexp) asm volatile(IND32(OP_K_LDEXP) S_REGS); KERNEL_END
+#define OP_K_FLOOR(d) "v_floor_f32 " d ", " d "\n\t"
+KERNEL_BEGIN(k_floor) asm volatile(IND32(OP_K_FLOOR) S_REGS); KERNEL_END
+#define OP_K_FRACT(d) "v_fract_f32 " d ", " d "\n\t"
+KERNEL_BEGIN(k_fract) asm volatile(IND32(OP_K_FRACT) S_REGS); KERNEL_END
+#define OP_K_FMAC(d) "v_fmac_f32 " d ", %8, %9\n\t"
+KERNEL_BEGIN(k_fmac) asm volatile(IND32(OP_K_FMAC) S_REGS); KERNEL_END
+#define OP_K_MULCLAMP(d) "v_mul_f32_e64 " d ", " d ", %8 clamp\n\t"
+KERNEL_BEGIN(k_mulclamp) asm volatile(IND32(OP_K_MULCLAMP) S_REGS); KERNEL_END
+#define OP_K_FMACLAMP(d) "v_fma_f32 " d ", " d ", %8, %9 clamp\n\t"
+KERNEL_BEGIN(k_fmaclamp) asm volatile(IND32(OP_K_FMACLAMP) S_REGS); KERNEL_END
+#define OP_K_MAXU(d) "v_max_u32 " d ", " d ", %8\n\t"
+KERNEL_BEGIN(k_maxu) asm volatile(IND32(OP_K_MAXU) S_REGS); KERNEL_END
+#define OP_K_CMPCLASS(d) "v_cmp_class_f32 vcc, " d ", %8\n\t"
+KERNEL_BEGIN(k_cmpclass) asm volatile(IND32(OP_K_CMPCLASS) S_REGS : "vcc"); KERNEL_END
+#define OP_K_SAD(d) "v_sad_u8 " d ", " d ", %8, %9\n\t"
+KERNEL_BEGIN(k_sad) asm volatile(IND32(OP_K_SAD) S_REGS); KERNEL_END
+#define OP_K_DOT2(d) "v_dot2c_f32_f16 " d ", %8, %9\n\t"
+KERNEL_BEGIN(k_dot2) asm volatile(IND32(OP_K_DOT2) S_REGS); KERNEL_END
+
 // ---- scalar / nop ---------------------------------------------------------------------------------
 KERNEL_BEGIN(k_snop0) asm volatile(REP32("s_nop 0\n\t") S_REGS); KERNEL_END
 KERNEL_BEGIN(k_salu) asm volatile(REP32("s_add_u32 s20, s20, 1\n\t") S_REGS : "s20", "scc"); KERNEL_END
@@ -240,6 +304,37 @@ int main(int argc, char **argv) {
       {"ds_write_b128 x8 + wait", k_dswrite_b128, 8, "per ds_write (1 KiB/wave)"},
       {"ds_write_b32 x8 + wait", k_dswrite_b32, 8, "per ds_write"},
       {"ds_read_b128 + 24 v_fma + wait", k_dsread_fma_mix, 25, "per instruction"},
+      {"v_lshlrev_b32 v, 1, v", k_lshlrev, 32, ""},
+      {"v_lshrrev_b32 v, 31, v", k_lshrrev, 32, ""},
+      {"v_ashrrev_i32 v, 31, v", k_ashrrev, 32, ""},
+      {"v_xor_b32", k_xor, 32, ""},
+      {"v_or_b32", k_or, 32, ""},
+      {"v_sub_f32", k_subf, 32, ""},
+      {"v_add_f32", k_addf, 32, ""},
+      {"v_mov_b32 VGPR", k_movv, 32, ""},
+      {"v_and_or_b32", k_andor, 32, ""},
+      {"v_add3_u32", k_add3, 32, ""},
+      {"v_lshl_add_u32", k_lshladd, 32, ""},
+      {"v_alignbit_b32", k_alignbit, 32, ""},
+      {"v_min_f32", k_minf, 32, ""},
+      {"v_sub_u32", k_subu, 32, ""},
+      {"v_subrev_u32", k_subrev, 32, ""},
+      {"v_mul_lo_u32", k_mullo, 32, ""},
+      {"v_mul_u32_u24", k_mulu24, 32, ""},
+      {"v_mad_u32_u24", k_madu24, 32, ""},
+      {"v_bfe_u32", k_bfe, 32, ""},
+      {"v_perm_b32", k_perm, 32, ""},
+      {"v_mul_legacy_f32", k_mullegacy, 32, ""},
+      {"v_ldexp_f32", k_ldexp, 32, ""},
+      {"v_floor_f32", k_floor, 32, ""},
+      {"v_fract_f32", k_fract, 32, ""},
+      {"v_fmac_f32 (VOP2)", k_fmac, 32, ""},
+      {"v_mul_f32 clamp", k_mulclamp, 32, ""},
+      {"v_fma_f32 clamp", k_fmaclamp, 32, ""},
+      {"v_max_u32", k_maxu, 32, ""},
+      {"v_cmp_class_f32", k_cmpclass, 32, ""},
+      {"v_sad_u8", k_sad, 32, ""},
+      {"v_dot2c_f32_f16", k_dot2, 32, ""},
       {"s_nop 0", k_snop0, 32, ""},
       {"s_add_u32 dependent", k_salu, 32, ""},
       {"v_fma + s_add alternating", k_fma_salu, 32, "per instruction (16 VALU + 16 SALU)"},

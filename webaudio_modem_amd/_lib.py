@@ -59,6 +59,8 @@ _SYMBOLS = [
     ("fskhip_create", C.c_int, [C.POINTER(Config), C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(_P)]),
     ("fskhip_destroy", C.c_int, [_P]),
     ("fskhip_n_streams", C.c_uint32, [_P]),
+    ("fskhip_max_bytes", C.c_size_t, [_P, C.c_size_t]),
+    ("fskhip_last_kernel", C.c_char_p, [_P]),
     ("fskhip_demodulate_host", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P, _P, C.c_uint32]),
     ("fskhip_demodulate_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P, _P, C.c_uint32, _P]),
     ("fskhip_modulated_length", C.c_size_t, [_P, C.c_size_t]),

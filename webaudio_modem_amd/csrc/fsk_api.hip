@@ -21,13 +21,16 @@ hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, bool app
                         uint32_t *out_counts, uint32_t *eod_counts, hipStream_t stream);
 bool demod_fast_applicable(int precision, bool uniform_even, const DemodParams &P, const DemodState &S,
                            const float *samples, size_t pitch);
-hipError_t launch_demod_fast(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+// fsk_pipe.hip: free-running front / ZIR-corrected back kernels
+hipError_t launch_demod_pipe(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream);
-hipError_t launch_demod_split(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+hipError_t launch_demod_fused(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                               size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                               uint32_t *eod_counts, hipStream_t stream);
-size_t demod_split_lds_bytes(const DemodParams &P);
+size_t demod_pipe_lds_bytes(const DemodParams &P);
+size_t demod_fused_lds_bytes(const DemodParams &P);
+hipError_t set_pipe_lds_limit(size_t pipe_bytes);
 hipError_t set_demod_lds_limit(size_t lds_bytes);
 size_t demod_lds_bytes(const DemodParams &P);
 hipError_t launch_modulate(const ModParams &M, const double *coef, const uint8_t *payloads, const uint32_t *lens,
@@ -90,6 +93,7 @@ __global__ void init_kernel(DemodState S, uint32_t n, uint32_t matched_zero) {
   rs[(size_t)RF_sil_thr * n + s] = (Real)0.01;
   S.is[(size_t)IF_matched * n + s] = matched_zero;
   S.is[(size_t)IF_bit_wait * n + s] = kBigWait;
+  S.is[(size_t)IF_zr_dph * n + s] = 2u;
 }
 
 // reset() fsk.ts:464-469 = resetState() + syncSamplesBuffer.clear() (+ host-side counters).
@@ -105,7 +109,25 @@ __global__ void reset_kernel(DemodState S, uint32_t n, int64_t stream) {
   for (int f : rz) rs[(size_t)f * n + s] = (Real)0;
   const int iz[] = {IF_nco_lo, IF_nco_hi, IF_ds_cnt, IF_gsc, IF_cad_ctr, IF_sil_cnt, IF_started, IF_bit_acc,
                     IF_bit_reload, IF_byte_cur, IF_bit_pos, IF_ring_len, IF_sync_det};
-  for (int f : iz) S.is[(size_t)f * n + s] = 0u;
+  if (sizeof(Real) == 4) {
+    // fp32 engines (free-running frame, fsk_params.h): the NCO restarts at 0, so the frame offset becomes minus the
+    // frame's own phase, and lastPhase = 0 is that phase in the frame; filters and correction start from zero
+    const uint64_t acc = ((uint64_t)S.is[(size_t)IF_nco_hi * n + s] << 32) | S.is[(size_t)IF_nco_lo * n + s];
+    const uint64_t off = ((uint64_t)S.is[(size_t)IF_fr_hi * n + s] << 32) | S.is[(size_t)IF_fr_lo * n + s];
+    const uint64_t fr0 = acc - off, noff = 0ull - fr0;
+    S.is[(size_t)IF_fr_lo * n + s] = (uint32_t)noff;
+    S.is[(size_t)IF_fr_hi * n + s] = (uint32_t)(noff >> 32);
+    const int zz[] = {RF_zq_ai, RF_zq_aq, RF_zq_bi, RF_zq_bq, RF_zq_0i, RF_zq_0q, RF_zd_ix1, RF_zd_ix2, RF_zd_iy, RF_zd_iv,
+                      RF_zd_qx1, RF_zd_qx2, RF_zd_qy, RF_zd_qv};
+    for (int f : zz) rs[(size_t)f * n + s] = (Real)0;
+    S.is[(size_t)IF_zr_dph * n + s] = 2u;
+    double r = (double)fr0 * 5.42101086242752217e-20 * 6.283185307179586476925;
+    r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
+    for (int f : iz) S.is[(size_t)f * n + s] = 0u;
+    rs[(size_t)RF_last_phase * n + s] = (Real)r;
+  } else {
+    for (int f : iz) S.is[(size_t)f * n + s] = 0u;
+  }
   S.is[(size_t)IF_bit_wait * n + s] = kBigWait;
 }
 
@@ -133,6 +155,7 @@ struct fskhip_engine {
   bool use_split = false;        // two waves per 64-stream group (demod_split_kernel): batches of fewer than two waves per SIMD
   uint32_t split_cus = 256;
   bool split_forced = false;     // FSKHIP_SPLIT was set: skip the residency check too
+  const char *last_kernel = "";  // what the last fskhip_demodulate_device call launched for its whole tiles
   bool demod_ok = true;          // false: configuration the demodulator kernels do not implement
   std::string demod_why;
   uint32_t trace_cap = 0;
@@ -463,6 +486,27 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     const uint64_t inc2 = inc[0] << 1, inc16 = inc[0] << 4;
     P.u_inc2_lo = (uint32_t)inc2; P.u_inc2_hi = (uint32_t)(inc2 >> 32);
     P.u_inc16_lo = (uint32_t)inc16; P.u_inc16_hi = (uint32_t)(inc16 >> 32);
+    P.u_inc_lo = (uint32_t)inc[0]; P.u_inc_hi = (uint32_t)(inc[0] >> 32);
+  }
+  {
+    // fsk_pipe.hip: zero-input response of the I/Q low-pass (y[n] = -a1 y[n-1] - a2 y[n-2]) as pair sums
+    // q[m] = Z[2m] + Z[2m+1]:  q[m+2] = (a1^2 - 2 a2) q[m+1] - a2^2 q[m]  (the squared poles), and the map from the next
+    // two pair sums back to the filter state (Z[n-1], Z[n-1] - Z[n-2]) at an even n (tools/zir_model.py)
+    const double a1 = P.lp_a1, a2 = P.lp_a2;
+    P.z_c1 = (float)(a1 * a1 - 2 * a2);
+    P.z_c2 = (float)(a2 * a2);
+    auto q_of = [&](double z1, double z2, double &q0, double &q1) {
+      double Z[6] = {z2, z1, 0, 0, 0, 0};
+      for (int i = 2; i < 6; i++) Z[i] = -a1 * Z[i - 1] - a2 * Z[i - 2];
+      q0 = Z[2] + Z[3]; q1 = Z[4] + Z[5];
+    };
+    double l00, l10, l01, l11;           // q = L (zeta1, zeta2)
+    q_of(1, 0, l00, l10);
+    q_of(0, 1, l01, l11);
+    const double det = l00 * l11 - l01 * l10;
+    const double i00 = l11 / det, i01 = -l01 / det, i10 = -l10 / det, i11 = l00 / det;   // (zeta1, zeta2) = Linv (q0, q1)
+    P.z_ya = (float)i00; P.z_yb = (float)i01;
+    P.z_va = (float)(i00 - i10); P.z_vb = (float)(i01 - i11);
   }
 
 #define CREATE_TRY(expr)                                                                          \
@@ -505,6 +549,8 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     CREATE_TRY(hipDeviceSynchronize());
   }
   if (e->demod_ok && e->lds_bytes > 48 * 1024) CREATE_TRY(set_demod_lds_limit(e->lds_bytes));
+  if (e->demod_ok && !P.wide && !P.frac && precision == FSKHIP_PRECISION_F32 && demod_pipe_lds_bytes(P) <= 160 * 1024)
+    CREATE_TRY(set_pipe_lds_limit(demod_pipe_lds_bytes(P)));
   e->S.trace_stream = 0xFFFFFFFFu;
 #undef CREATE_TRY
   e->base_calls.assign(n_streams, 0);
@@ -514,6 +560,8 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
 }
 
 uint32_t fskhip_n_streams(const fskhip_engine *e) { return e ? e->n_streams : 0; }
+size_t fskhip_max_bytes(const fskhip_engine *e, size_t n_per_stream) { return e ? engine_max_bytes(e, n_per_stream) : 0; }
+const char *fskhip_last_kernel(const fskhip_engine *e) { return e ? e->last_kernel : ""; }
 
 int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_t pitch, uint8_t *d_out,
                              size_t out_pitch, uint32_t *d_out_counts, uint32_t *d_eod_counts, uint32_t flags,
@@ -544,14 +592,21 @@ int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_
     if (!e->force_generic && demod_fast_applicable(e->precision, e->ds_uniform && e->ds_parity == 0, e->P,
                                                    e->S, d_samples, pitch))
       n_fast = n & ~(size_t)15;
-    // (the split kernel's workgroups must all be resident: LDS per workgroup x workgroups per CU within 160 KB)
-    const size_t split_lds = demod_split_lds_bytes(e->P);
+    // whole tiles: two waves per 64-stream group while the batch gives the SIMDs fewer than two waves each and all
+    // workgroups' LDS rings fit on the CUs at once (LDS per workgroup x workgroups per CU within 160 KB), else one
     const size_t wgs_per_cu = (e->n_blocks + e->split_cus - 1) / e->split_cus;
-    if (n_fast && e->use_split && split_lds <= 64 * 1024 && (wgs_per_cu * split_lds <= 160 * 1024 || e->split_forced))
-      HIP_TRY(launch_demod_split(wb, e->P, e->S, d_samples, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
-    else if (n_fast)
-      HIP_TRY(launch_demod_fast(wb, e->P, e->S, d_samples, n_fast, pitch, d_out, out_pitch, d_out_counts,
-                                d_eod_counts, st));
+    const size_t pipe_lds = demod_pipe_lds_bytes(e->P);
+    e->last_kernel = "";
+    if (n_fast && e->use_split && pipe_lds <= 160 * 1024 && (wgs_per_cu * pipe_lds <= 160 * 1024 || e->split_forced)) {
+      HIP_TRY(launch_demod_pipe(wb, e->P, e->S, d_samples, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+      e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_pipe_kernel<true, true>" : "fsk::demod_pipe_kernel<true, false>")
+                          : (e->P.uni_cfg ? "fsk::demod_pipe_kernel<false, true>" : "fsk::demod_pipe_kernel<false, false>");
+    } else if (n_fast) {
+      HIP_TRY(launch_demod_fused(wb, e->P, e->S, d_samples, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+      e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_fused_kernel<true, true>" : "fsk::demod_fused_kernel<true, false>")
+                          : (e->P.uni_cfg ? "fsk::demod_fused_kernel<false, true>" : "fsk::demod_fused_kernel<false, false>");
+    }
+    if (!n_fast) e->last_kernel = e->precision == FSKHIP_PRECISION_F64 ? "fsk::demod_kernel<double, ...>" : "fsk::demod_kernel<float, ...>";
     if (n_fast < n || n == 0)
       HIP_TRY(launch_demod(e->precision, e->ds_uniform, wb, n_fast != 0, e->P, e->S, d_samples + n_fast, n - n_fast,
                            pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));

@@ -20,6 +20,12 @@ namespace fsk {
   X(last_phase)                         /* iqState.lastPhase fsk.ts:102 */                  \
   X(nco_phase)                          /* iqState.localOscPhase (f64 path only) */         \
   X(sil_thr)                            /* silence.threshold fsk.ts:128 */
+// fp32 engines keep the I/Q low-pass in a FREE-RUNNING frame (fsk_pipe.hip): li_*, lq_*, last_phase are that frame's;
+// what resetState() would have zeroed is carried as a zero-input response (pair sums zq_*), or, for the two decimated
+// samples after a reset (zr_dph = 0, 1), as a zero-started direct instance zd_*.  (Not part of the generic kernel's Lane.)
+#define FSK_REAL_FIELDS_PIPE(X)                                                             \
+  X(zq_ai) X(zq_aq) X(zq_bi) X(zq_bq) X(zq_0i) X(zq_0q)                                     \
+  X(zd_ix1) X(zd_ix2) X(zd_iy) X(zd_iv) X(zd_qx1) X(zd_qx2) X(zd_qy) X(zd_qv)
 
 // ---- integer per-stream state ----------------------------------------------------------------
 #define FSK_INT_FIELDS(X)                                                                   \
@@ -41,16 +47,22 @@ namespace fsk {
   X(amp_pos) X(amp_len) /* syncAmplitudeBuffer write index / length */                      \
   X(sync_det)           /* debug.syncDetections */                                          \
   X(eod_total)          /* 'eod' events since create */
+#define FSK_INT_FIELDS_PIPE(X)                                                              \
+  X(fr_lo) X(fr_hi)     /* fp32: NCO phase minus the free-running frame's phase (64-bit turns); */ \
+                        /* changes only at resetState()                                     */      \
+  X(zr_dph)             /* fp32: 2 = zq_* valid; 0, 1 = decimated samples done by the direct instance */
 
 enum RealField {
 #define X(n) RF_##n,
   FSK_REAL_FIELDS(X)
+  FSK_REAL_FIELDS_PIPE(X)
 #undef X
   RF_COUNT
 };
 enum IntField {
 #define X(n) IF_##n,
   FSK_INT_FIELDS(X)
+  FSK_INT_FIELDS_PIPE(X)
 #undef X
   IF_COUNT
 };
@@ -102,6 +114,10 @@ struct DemodParams {
   float u_w2_re, u_w2_im;          // e^{2 j omega}
   uint32_t u_inc2_lo, u_inc2_hi;   // 2 NCO steps (turns * 2^64)
   uint32_t u_inc16_lo, u_inc16_hi; // 16 NCO steps = one tile
+  // fsk_pipe.hip (free-running front, ZIR-corrected back)
+  uint32_t u_inc_lo, u_inc_hi;     // one NCO step (turns * 2^64), uniform configuration
+  float z_c1, z_c2;                // zero-input response of the I/Q low-pass as pair sums: q[m+2] = c1 q[m+1] - c2 q[m]
+  float z_ya, z_yb, z_va, z_vb;    // (y, v) of that response at an even sample from the next two pair sums (q[m], q[m+1])
 };
 
 struct DemodState {

@@ -1,0 +1,940 @@
+// fsk_pipe.hip -- round-2 whole-tile fp32 demodulator kernels for gfx950 (MI355X): a FREE-RUNNING front end and a
+// back end that repairs resetState() by linearity, so that the two can run as a decoupled wave pipeline.
+//
+// Why.  valu_probe (tools/, profiles/r02_valu_probe.txt): one wave issues a vector instruction every ~4 cycles, a SIMD
+// retires one every ~2 once two or more waves interleave, packed fp32 costs twice a plain op and transcendentals four
+// times.  At 65 536 streams (BASELINE config #3 on one GPU) one lane per stream gives each SIMD ONE wave, so the r01
+// kernels ran at half the SIMD's rate whatever their instruction count.  Splitting a 64-stream group over two waves
+// needs a cut with no feedback across it -- and the reference has one: processDownsampledBit -> resetState()
+// (fsk.ts:175-188, 288-291, 352-355) zeroes the NCO phase and the I/Q low-pass state from inside the frame logic.
+//
+// How.  The I/Q branch is linear, so the front wave never resets anything:
+//   front (per input sample):  AGC (fsk.ts:52-76) -> pre-filter (filters.ts:47-87) -> mix with the NCO of a frame that
+//                              started at phase 0 when the launch did -> I/Q low-pass -> pair sums U[m]  (fsk.ts:228-248)
+//   back (per decimated sample): w[m] = U[m] - q[m], discriminator, post filter, slicer (fsk.ts:251-264) and the whole
+//                              frame state machine (fsk.ts:278-375).
+// q[m] is the zero-input response of the free-running filters' state at the last reset, as a pair sum: with Z[n] the
+// response of  y[n] = -a1 y[n-1] - a2 y[n-2]  it obeys  q[m+2] = (a1^2 - 2 a2) q[m+1] - a2^2 q[m].  Its first two values
+// come from computing the two pairs after a reset directly (a second, zero-started filter instance fed with the same
+// pre-filter outputs): q = U - W_direct.  What the reference's restarted NCO changes on top of that is a constant
+// rotation e^{-j w n0} of the I/Q plane, which the amplitude does not see and the phase DIFFERENCE only sees once:
+// lastPhase = 0 in the reference's frame is w*n0 in the free-running one.  tools/zir_model.py checks the algebra
+// against a sample-serial model (f64: 7e-14; f32: 1e-7 of the signal peak, i.e. the rounding the fp32 path has anyway).
+//
+// Because the front's frame is uniform over the batch when all streams share one configuration, its NCO is not per-lane
+// arithmetic: sixteen lanes evaluate e^{j w n} for the sixteen samples of a tile (v_cos / v_sin of the exact 64-bit turn
+// accumulator, as in round 1), park them in LDS, and every lane reads them back as broadcasts -- VGPR operands for
+// the mixer (an operand from an SGPR would make every multiply a half-rate instruction, profiles/r02_valu_probe_summary.md).
+//
+// State.  fp32 engines keep this representation in HBM between launches (fsk_params.h: li_*/lq_*/last_phase are the
+// free-running frame's, fr_* the frame offset, zq_*/zd_*/zr_dph the correction), so a stream cut into launches at any
+// whole-tile boundaries computes bit for bit what one launch computes; the generic kernel (fsk_demod.hip), which runs
+// ragged tails and the uncommon configurations with real resets, converts on load and store (pipe_to_actual /
+// actual_to_pipe in fsk_dev.h, f64 rotation).
+//
+// Kernels:
+//   demod_pipe_kernel   two waves per 64-stream group: wave 0 front, wave 1 back, hand-off through an LDS ring of
+//                       16-sample tiles with producer/consumer counters (no barrier in the loop).  For batches
+//                       that give a SIMD fewer than ~3 waves (BASELINE configs #2, #3, #5).
+//   demod_fused_kernel  the same two halves called back to back by one wave, pair by pair through registers, for
+//                       batches large enough to fill the SIMDs with one wave per group.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fsk_params.h"
+#include "fsk_dev.h"
+
+namespace fsk {
+
+static constexpr uint32_t kPipeSlots = 3;          // tiles in the LDS ring between the two waves
+static constexpr uint32_t kSlotV4 = 8 * 64;        // v4f per ring slot: y[16] and U[8 pairs x (I,Q)] per lane
+
+// ---- front: everything before the decimator, free-running --------------------------------------------------------
+struct FrontLane {
+  float g, bx1, bx2, by1, by2;   // AGC gain; pre-filter history (outputs carry the low-pass gain b0/2)
+  float ix1, ix2, iy, iv;        // I low-pass: x[n-1], x[n-2], y[n-1], velocity      (launch frame)
+  float qx1, qx2, qy, qv;        // Q low-pass
+};
+struct FrontK {                   // all in VGPRs: an SGPR operand halves a vector instruction's rate (valu_probe)
+  float att_m_rel, rel;          // AGC: attack - release, release
+  float step_k, step_b;          // 2^40, -2^39: clamp(level*2^40 - 2^39) = [level > 0.5]
+  float g_lo, g_hi;              // 0.1, 10
+  float bp_b0, bp_na1, bp_na2;   // pre-filter: y = b0*(x - x2) - a2*y2 - a1*y1
+  float lp_a2, lp_nd;            // low-pass a2, -(1 + a1 + a2)
+};
+
+// one input sample: returns the AGC'd sample (write-back), the pre-filter output and the I/Q low-pass outputs
+__device__ inline void front_sample(FrontLane &F, const FrontK &K, float xin, float c, float s, float &xs, float &y,
+                                    float &oi, float &oq) {
+  // AGC (fsk.ts:52-76); exact zero holds the gain.  The attack/release choice is arithmetic (a clamped fma is an
+  // FMA-class instruction, compare + select are two half-rate ones): exact for every level, since
+  // (level - 0.5) * 2^40 >= 2^16 for the smallest level above 0.5.
+  const float xv = xin * F.g;
+  xs = xv;
+  const float level = __builtin_fabsf(xv);
+  const float t = __builtin_fmaf(0.5f, __builtin_amdgcn_rcpf(level), -F.g);
+  float st;
+  asm("v_fma_f32 %0, |%1|, %2, %3 clamp" : "=v"(st) : "v"(xv), "v"(K.step_k), "v"(K.step_b));
+  const float rate = __builtin_fmaf(st, K.att_m_rel, K.rel);
+  float gn = __builtin_fmaf(t, rate, F.g);
+  gn = level > 0.0f ? gn : F.g;
+  F.g = __builtin_amdgcn_fmed3f(gn, K.g_lo, K.g_hi);
+  // pre-filter (filters.ts:47-87), b1 = 0, b2 = -b0
+  float v = K.bp_b0 * (xv - F.bx2);
+  v = __builtin_fmaf(K.bp_na2, F.by2, v);
+  v = __builtin_fmaf(K.bp_na1, F.by1, v);
+  F.bx2 = F.bx1; F.bx1 = xv;
+  F.by2 = F.by1; F.by1 = v;
+  y = v;
+  // mix + I/Q low-pass (fsk.ts:229-238), velocity form, gain already on v
+  const float mi = v * c, mq = v * s;
+  const float ti = __builtin_fmaf(2.0f, F.ix1, mi) + F.ix2;
+  const float tq = __builtin_fmaf(2.0f, F.qx1, mq) + F.qx2;
+  F.iv = __builtin_fmaf(K.lp_a2, F.iv, __builtin_fmaf(K.lp_nd, F.iy, ti));
+  F.qv = __builtin_fmaf(K.lp_a2, F.qv, __builtin_fmaf(K.lp_nd, F.qy, tq));
+  F.iy += F.iv; F.qy += F.qv;
+  F.ix2 = F.ix1; F.ix1 = mi;
+  F.qx2 = F.qx1; F.qx1 = mq;
+  oi = F.iy; oq = F.qy;
+}
+
+// Discriminator front half (fsk.ts:251-252): phase and magnitude of one decimated I/Q pair sum, with FMA-class
+// instructions only besides the two transcendentals (no min/max, compare or select: those issue at half rate).
+//   atan(|y|/|x|) = pi/4 + atan(u),  u = (|y| - |x|) / (|y| + |x|) in [-1, 1]      (no octant swap)
+//   |(x, y)| = (|x| + |y|) * sqrt((1 + u^2) / 2)                                     (cannot underflow: see fsk_dev.h)
+//   quadrant: pi/2 + ((atan(u) - pi/4) XOR signbit(x)), then OR signbit(y)
+// |x| carries +1e-37 so that (0, 0) gives u = -1, i.e. angle 0 like Math.atan2(0, 0), without a guard instruction.
+// Same odd minimax polynomial as fsk_dev.h's atan2_amp_fast (|error| <= 1.5e-7 rad on [-1, 1]).
+// tiny = 1e-37f and sgn = 0x80000000 arrive in VGPRs: as literals they would be hoisted into SGPRs (VOP3 cannot
+// encode a literal), and an SGPR operand halves the instruction's rate.
+__device__ inline float atan2_amp_fma(float y, float x, float &amp, float tiny, uint32_t sgn) {
+  x = x + 0.0f;                                        // -0 counts as +0 (the reference's averages are never -0)
+  const float axp = __builtin_fabsf(x) + tiny;
+  const float ay = __builtin_fabsf(y);
+  const float sm = ay + axp;
+  const float u = (ay - axp) * __builtin_amdgcn_rcpf(sm);
+  const float s = u * u;
+  amp = sm * __builtin_amdgcn_sqrtf(__builtin_fmaf(s, 0.5f, 0.5f));
+  float p = -4.355408570e-03f;
+  p = __builtin_fmaf(p, s, 2.304014596e-02f);
+  p = __builtin_fmaf(p, s, -5.777360382e-02f);
+  p = __builtin_fmaf(p, s, 9.794235514e-02f);
+  p = __builtin_fmaf(p, s, -1.397658244e-01f);
+  p = __builtin_fmaf(p, s, 1.996270403e-01f);
+  p = __builtin_fmaf(p, s, -3.333165903e-01f);
+  const float r = __builtin_fmaf(u * s, p, u);         // atan(u)
+  const float phi = r - 0.78539816339744831f;          // in [-pi/2, 0]
+  const uint32_t sx = __builtin_bit_cast(uint32_t, x) & sgn;
+  const float th = 1.57079632679489662f + __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, phi) ^ sx);
+  return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, th) | (__builtin_bit_cast(uint32_t, y) & sgn));
+}
+
+// all ones iff v < 0.  Right shifts, add/sub and the bit ops are FMA-class instructions on gfx950 while v_cmp, v_cndmask,
+// v_addc and the left shifts issue at half rate (profiles/r02_valu_probe*.txt), so per-sample flags are computed as sign
+// bits.  The empty asm keeps hipcc from folding the mask back into a compare + select.
+__device__ inline uint32_t neg_mask(uint32_t v) {
+  uint32_t m = (uint32_t)((int32_t)v >> 31);
+  asm("" : "+v"(m));
+  return m;
+}
+__device__ inline uint32_t sign_bit(uint32_t v) {
+  uint32_t m = v >> 31;
+  asm("" : "+v"(m));
+  return m;
+}
+
+// ---- back: decimated rate ----------------------------------------------------------------------------------------
+struct BackLane {
+  float qai, qaq, qbi, qbq;      // ZIR pair sums of the upcoming two decimated samples
+  float px1, px2, py, pv;        // post filter (velocity form)
+  float last_phase, thr;         // lastPhase in the launch frame; silence threshold
+  // the two pairs after a reset are computed directly by a zero-started filter instance (dph = 0, 1; 2 = steady)
+  uint32_t dph;
+  float dix1, dix2, diy, dvi, dqx1, dqx2, dqy, dqv, q0i, q0q;
+  // frame state machine, as absolute push counts of this launch (k = pushes so far, wave-uniform):
+  uint32_t matched, thr_eff;     // sync correlator count; matched_min while searching, kStarted while a frame is started
+  uint32_t rho;                  // globalSampleCounter % cadence == 0  <=>  k % cadence == rho
+  uint32_t ls;                   // silence.sampleCount = k - ls
+  uint32_t acc, T, tlast;        // bit vote; nextBitSampleIndex - bitSampleCounter = T - k; bitAccumCount = k - tlast
+  uint32_t sreg;                 // byteState as a shift register under a sentinel bit: 1 = waiting for the start bit,
+                                 // 1 s d7..d0 (bit 9 set) = all data bits in, the next decision is the stop (or parity) bit
+  uint32_t out_cnt;
+};
+struct BackK {                    // VGPRs, like FrontK
+  float c1, c2;                  // ZIR pair-sum recurrence
+  float lp_b0, lp_a2, lp_nd;     // post filter: b0, a2, -(1 + a1 + a2)
+  uint32_t qn, mask;             // ~pattern, window mask (bits 1 .. nBits-1)
+  uint32_t d;                    // downsampledSamplesPerBit
+  float tiny; uint32_t sgn;      // 1e-37f, 0x80000000 (atan2_amp_fma)
+  uint32_t edge_min;             // (1 << stop_pos) - 2: sreg - 2 >= edge_min (unsigned) <=> start or stop position
+  uint32_t eod_m1;               // samplesForEOD - 1
+};
+struct BackU {                   // wave-uniform context of one decimated sample
+  uint32_t k;                    // pushes of this launch including this one
+  uint32_t kv;                   // the same in a VGPR (operand of the per-lane selects and differences)
+  uint32_t kappa;                // k % cadence
+  uint32_t phase;                // polyphase slot of this push
+  uint32_t amp_soff;             // byte offset of the amplitude-ring row
+  uint32_t direct;               // decimated samples for which some lane still runs the direct instance (after a reset)
+  uint64_t free0;                // free-running frame: NCO phase (turns * 2^64) at the first sample of the launch
+};
+
+// resetState() fsk.ts:175-188 at the end of push k: the next input sample is n0 = 2k of this launch.
+template <bool UNI>
+__device__ inline void back_reset(BackLane &B, const DemodParams &P, const FastMem &M, const BackU &X, uint64_t inc) {
+  // the reference's NCO restarts at 0: from here on its phase is the free-running frame's minus that frame's phase at
+  // n0, and its lastPhase = 0 is that phase in the free frame
+  const uint64_t fr0 = X.free0 + inc * (uint64_t)(2u * X.k);
+  const uint64_t off = 0ull - fr0;
+  ist_store(M, IF_fr_lo, (uint32_t)off);
+  ist_store(M, IF_fr_hi, (uint32_t)(off >> 32));
+  {
+    double r = (double)fr0 * 5.42101086242752217e-20 * 6.283185307179586476925;   // 2^-64 turns -> radians
+    r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
+    B.last_phase = (float)r;
+  }
+  B.dph = 0;
+  B.dix1 = B.dix2 = B.diy = B.dvi = 0.f;
+  B.dqx1 = B.dqx2 = B.dqy = B.dqv = 0.f;
+  B.px1 = B.px2 = B.py = B.pv = 0.f;
+  ist_store(M, IF_gsc, 0u - X.k);
+  B.rho = X.kappa;
+  B.ls = X.k;
+  B.acc = 0; B.T = X.k + kBigWait; B.tlast = B.T;
+  B.sreg = 1u;
+  B.thr_eff = M.voff < 0xFFFFFFF0u ? P.matched_min : 0xFFFFFFFEu;  // lanes beyond the batch stay parked
+}
+
+// e^{j 2 pi acc / 2^64}: the hardware's sin/cos take turns
+__device__ inline void nco_phasor(uint64_t acc, float &c, float &s) {
+  const float turns = (float)(uint32_t)(acc >> 32) * 2.3283064365386963e-10f;  // 2^-32
+  c = __builtin_amdgcn_cosf(turns);
+  s = __builtin_amdgcn_sinf(turns);
+}
+
+// One decimated sample: ZIR correction, discriminator (fsk.ts:245-264), processDownsampledBit (fsk.ts:278-344),
+// processByte (346-375).  ypair: LDS address of this pair's two pre-filter outputs (read by the direct instance only).
+template <bool UNI>
+__device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams &P, const DemodState &S, const FastMem &M,
+                                 uint32_t *poly, uint32_t lane, __amdgpu_buffer_rsrc_t amp_rsrc, uint8_t *out,
+                                 uint32_t out_pitch, uint32_t *eod_counts, BackU &X, float Ui, float Uq,
+                                 const float *ypair, uint32_t r_old, uint64_t inc) {
+  // ---- ZIR correction: w = U - q, q advances by its two-term recurrence
+  float wi = Ui - B.qai, wq = Uq - B.qaq;
+  {
+    const float ni = __builtin_fmaf(K.c1, B.qbi, -(K.c2 * B.qai));
+    const float nq = __builtin_fmaf(K.c1, B.qbq, -(K.c2 * B.qaq));
+    B.qai = B.qbi; B.qaq = B.qbq; B.qbi = ni; B.qbq = nq;
+  }
+  // (opaque: otherwise hipcc sinks this straight-line code into the else side of the rare branch below)
+  asm volatile("" : "+v"(wi), "+v"(wq), "+v"(B.qai), "+v"(B.qaq), "+v"(B.qbi), "+v"(B.qbq));
+  // ---- rare: the two pairs after a reset come from the zero-started instance, which also yields q's start values
+  if (X.direct) {
+    X.direct--;
+    if (B.dph < 2u) {
+      const float y0 = ypair[0], y1 = ypair[1];
+      const uint32_t n0 = 2u * (X.k - 1u);
+      // the front's phasors of these two samples, evaluated the same way (nco_phasor)
+      float c0, s0, c1, s1;
+      nco_phasor(X.free0 + inc * (uint64_t)n0, c0, s0);
+      nco_phasor(X.free0 + inc * (uint64_t)(n0 + 1u), c1, s1);
+      float di, dq;
+      {
+        const float mi = y0 * c0, mq = y0 * s0;
+        const float ti = __builtin_fmaf(2.0f, B.dix1, mi) + B.dix2, tq = __builtin_fmaf(2.0f, B.dqx1, mq) + B.dqx2;
+        B.dvi = __builtin_fmaf(K.lp_a2, B.dvi, __builtin_fmaf(K.lp_nd, B.diy, ti));
+        B.dqv = __builtin_fmaf(K.lp_a2, B.dqv, __builtin_fmaf(K.lp_nd, B.dqy, tq));
+        B.diy += B.dvi; B.dqy += B.dqv;
+        B.dix2 = B.dix1; B.dix1 = mi; B.dqx2 = B.dqx1; B.dqx1 = mq;
+        di = B.diy; dq = B.dqy;
+      }
+      {
+        const float mi = y1 * c1, mq = y1 * s1;
+        const float ti = __builtin_fmaf(2.0f, B.dix1, mi) + B.dix2, tq = __builtin_fmaf(2.0f, B.dqx1, mq) + B.dqx2;
+        B.dvi = __builtin_fmaf(K.lp_a2, B.dvi, __builtin_fmaf(K.lp_nd, B.diy, ti));
+        B.dqv = __builtin_fmaf(K.lp_a2, B.dqv, __builtin_fmaf(K.lp_nd, B.dqy, tq));
+        B.diy += B.dvi; B.dqy += B.dqv;
+        B.dix2 = B.dix1; B.dix1 = mi; B.dqx2 = B.dqx1; B.dqx1 = mq;
+        di += B.diy; dq += B.dqy;
+      }
+      wi = di; wq = dq;
+      if (B.dph == 0u) {
+        B.q0i = Ui - di; B.q0q = Uq - dq;
+      } else {
+        const float q1i = Ui - di, q1q = Uq - dq;
+        B.qai = __builtin_fmaf(K.c1, q1i, -(K.c2 * B.q0i));
+        B.qaq = __builtin_fmaf(K.c1, q1q, -(K.c2 * B.q0q));
+        B.qbi = __builtin_fmaf(K.c1, B.qai, -(K.c2 * q1i));
+        B.qbq = __builtin_fmaf(K.c1, B.qaq, -(K.c2 * q1q));
+      }
+      B.dph += 1u;
+    }
+  }
+  // ---- discriminator (fsk.ts:251-264)
+  float amp;
+  const float ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
+  float dphi = ph - B.last_phase;
+  {
+    // wrap into (-pi, pi] (fsk.ts:255-257): |dphi| < 2 pi, so one rounded quotient does both branches; rounding to
+    // nearest-even by adding and subtracting 1.5 * 2^23 (v_rndne_f32 is a half-rate instruction)
+    float tq = __builtin_fmaf(dphi, 0.15915494309189535f, 12582912.0f);
+    tq -= 12582912.0f;
+    dphi = __builtin_fmaf(-6.283185307179586f, tq, dphi);
+  }
+  B.last_phase = ph;
+  // post filter (fsk.ts:261), velocity form as fsk_dev.h's lp32
+  float f;
+  {
+    const float tt = __builtin_fmaf(2.0f, B.px1, dphi) + B.px2;
+    B.pv = __builtin_fmaf(K.lp_a2, B.pv, __builtin_fmaf(K.lp_nd, B.py, K.lp_b0 * tt));
+    B.py += B.pv;
+    B.px2 = B.px1; B.px1 = dphi;
+    f = B.py;
+  }
+  // slicer (fsk.ts:264): f > 0  <=>  sign bit of 0 - f  (f = +-0 gives +0, i.e. bit 0)
+  const uint32_t bit = sign_bit(__builtin_bit_cast(uint32_t, 0.0f - f));
+
+  // ---- processDownsampledBit (fsk.ts:278-344)
+  const uint32_t qn = K.qn, mask = K.mask;
+  const uint32_t r = r_old + r_old + bit;                      // syncSamplesBuffer.put(bit)
+  poly[X.phase * 64u + lane] = r;
+  B.matched += (uint32_t)__builtin_popcount((r ^ qn) & mask);
+  B.matched -= (uint32_t)__builtin_popcount((r_old ^ qn) & mask);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, M.voff, X.amp_soff, 0);  // syncAmplitudeBuffer.put
+  const bool hit = B.rho == X.kappa;                           // globalSampleCounter % round(dsSPB/4) == 0
+  {
+    const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, amp - B.thr));   // amp < threshold (fsk.ts:285)
+    B.ls = (B.ls & silent) | (X.kv & ~silent);                 // silence run = k - ls (fsk.ts:285-295)
+  }
+  const uint32_t e1 = K.eod_m1 - (X.kv - B.ls);                // negative <=> silence.sampleCount >= samplesForEOD
+  const bool eod = (int32_t)e1 < 0;
+  B.acc += bit;                                                // bit clock, ungated
+  // nextBitSampleIndex reached (only frames that are started get here: T is parked otherwise), and no 'eod' in this step
+  const uint32_t dm = ~(neg_mask(X.kv - B.T) | neg_mask(e1));
+  const bool cand = hit & (B.matched >= B.thr_eff);
+
+  bool did_reset = false;
+  if (__builtin_amdgcn_ballot_w64(eod) | __builtin_amdgcn_ballot_w64(cand)) {
+    if (eod) {                                                 // fsk.ts:288-291
+      ist_store(M, IF_eod_total, ist_load(M, IF_eod_total) + 1u);
+      if (eod_counts && M.voff < 0xFFFFFFF0u) eod_counts[M.voff >> 2] += 1u;
+      back_reset<UNI>(B, P, M, X, inc);
+      did_reset = true;
+    }
+    // ring length >= preamble window? (fsk.ts:302); ring_len / amp_len in HBM hold the launch-start values
+    bool sync_now = false;
+    uint32_t slen = 0;
+    if (cand & !eod) {
+      const uint32_t ring_base = ist_load(M, IF_ring_len);
+      sync_now = (ring_base + X.k >= P.sample_count) & (M.voff < 0xFFFFFFF0u);
+      const uint32_t pushes = ist_load(M, IF_amp_len) + X.k;
+      slen = pushes < P.amp_cap ? pushes : P.amp_cap;
+    }
+    uint64_t m = __builtin_amdgcn_ballot_w64(sync_now);
+    if (m) {
+      if (sync_now) {                                          // fsk.ts:315-319
+        B.thr_eff = kStarted;
+        B.sreg = 1u;
+        B.acc = 0; B.T = X.k; B.tlast = X.k;
+        ist_store(M, IF_sync_det, ist_load(M, IF_sync_det) + 1u);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's ring stores have reached L2
+      while (m) {
+        const int src = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t srow = (uint32_t)__builtin_amdgcn_readlane((int)M.voff, src) >> 2;
+        const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slen, src);
+        double part = 0.0;
+        for (uint32_t i = lane; i < sl; i += 64) {
+          const float *p = S.amp_ring + (size_t)i * P.n_streams + srow;
+          part += (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const double sum = wave_sum(part);
+        if ((int)lane == src) B.thr = (float)((sum / (double)sl) * 0.1);   // fsk.ts:321-326
+      }
+    }
+  }
+
+  // ---- bit decision (fsk.ts:335-341) + processByte (346-375).  Some lane decides at nearly every step, so the common
+  // part -- vote, clock advance, shifting the bit in -- runs for all lanes as masked arithmetic (one mask, bit ops) instead
+  // of a divergent block per step; only start and stop positions (two in ten decisions) branch.
+  const uint32_t s0 = B.sreg;
+  const uint32_t b = sign_bit((X.kv - B.tlast) - B.acc - B.acc);   // 2 * bitAccumulator > bitAccumCount (fsk.ts:336)
+  B.sreg = (s0 & ~dm) | ((s0 + s0 + b) & dm);
+  B.acc &= ~dm;
+  B.T += K.d & dm;                                             // nextBitSampleIndex += dsSPB
+  B.tlast = (B.tlast & ~dm) | (X.kv & dm);
+  const bool edge = ((s0 - 2u >= K.edge_min) ? dm : 0u) != 0u;
+  if (__builtin_amdgcn_ballot_w64(edge)) {
+    bool bad_start = false;
+    if (edge) {
+      if (s0 == 1u) {
+        bad_start = b != 0;                                    // fsk.ts:352-355
+      } else if (b) {                                          // stop bit: fsk.ts:367-368
+        if (M.voff < 0xFFFFFFF0u && B.out_cnt < out_pitch)
+          out[(size_t)(M.voff >> 2) * out_pitch + B.out_cnt] = (uint8_t)(s0 >> (P.stop_pos - 9u));
+        B.out_cnt++;
+        B.sreg = 1u;
+      } else {                                                 // bad stop bit: fsk.ts:363-366 -- started = false, byteState stays
+        const uint32_t reload = B.T - B.tlast;
+        B.T = X.k + kBigWait; B.tlast = B.T - reload;
+        B.thr_eff = P.matched_min;
+        B.sreg = s0;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(bad_start)) {
+      if (bad_start) back_reset<UNI>(B, P, M, X, inc);
+      did_reset = true;
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(did_reset)) X.direct = 2u;
+}
+
+// ---- state arrays <-> registers ------------------------------------------------------------------------------
+#define PIPE_RLOAD(f) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rsrc, row4, (uint32_t)RF_##f * fld, 0))
+#define PIPE_ILOAD(f) __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, row4, (uint32_t)IF_##f * fld, 0)
+#define PIPE_RSTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)(v)), rs_rsrc, M.voff, (uint32_t)RF_##f * fld, 0)
+#define PIPE_ISTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(v), M.is_rsrc, M.voff, (uint32_t)IF_##f * fld, 0)
+#define PIPE_CLOAD(f) (__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cf_rsrc, row4 * 2u, (uint32_t)(f) * fld * 2u, 0)))
+
+struct PipeCtx {   // descriptors and offsets both halves use
+  __amdgpu_buffer_rsrc_t rs_rsrc, cf_rsrc;
+  FastMem M;
+  uint32_t fld, row4;
+  bool valid;
+};
+__device__ inline PipeCtx pipe_ctx(const DemodParams &P, const DemodState &S, uint32_t stream) {
+  PipeCtx C;
+  C.valid = stream < P.n_streams;
+  const uint32_t row = C.valid ? stream : P.n_streams - 1;
+  C.fld = P.n_streams * 4u;
+  C.rs_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.rs, 0, (int)(C.fld * RF_COUNT), 0x00020000);
+  C.cf_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)S.coef, 0, (int)(2u * C.fld * CF_COUNT), 0x00020000);
+  C.M.is_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.is, 0, (int)(C.fld * IF_COUNT), 0x00020000);
+  C.M.fld = C.fld;
+  C.M.voff = C.valid ? row * 4u : 0xFFFFFFF0u;
+  C.row4 = row * 4u;
+  return C;
+}
+
+// NCO phase of the free-running frame at the first sample of the launch = the stream's NCO phase minus its frame offset.
+// Uniform configuration: every stream of the batch shares the frame, so this is a wave-uniform value (SGPRs).
+template <bool UNI>
+__device__ inline uint64_t pipe_free0(const PipeCtx &C) {
+  const FastMem &M = C.M;
+  const uint32_t fld = C.fld, row4 = C.row4;
+  const uint64_t acc = ((uint64_t)PIPE_ILOAD(nco_hi) << 32) | PIPE_ILOAD(nco_lo);
+  const uint64_t off = ((uint64_t)PIPE_ILOAD(fr_hi) << 32) | PIPE_ILOAD(fr_lo);
+  const uint64_t f = acc - off;
+  if (!UNI) return f;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)f);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(f >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// front state (AGC, pre-filter, free-running I/Q low-pass)
+template <bool UNI>
+__device__ inline void front_load(FrontLane &F, FrontK &K, const DemodParams &P, const DemodState &S, const PipeCtx &C) {
+  const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc, cf_rsrc = C.cf_rsrc;
+  const uint32_t fld = C.fld, row4 = C.row4;
+  F.g = PIPE_RLOAD(agc_gain);
+  F.bx1 = PIPE_RLOAD(bp_x1); F.bx2 = PIPE_RLOAD(bp_x2); F.by1 = PIPE_RLOAD(bp_y1); F.by2 = PIPE_RLOAD(bp_y2);
+  F.ix1 = PIPE_RLOAD(li_x1); F.ix2 = PIPE_RLOAD(li_x2); F.iy = PIPE_RLOAD(li_y1); F.iv = PIPE_RLOAD(li_y2);
+  F.qx1 = PIPE_RLOAD(lq_x1); F.qx2 = PIPE_RLOAD(lq_x2); F.qy = PIPE_RLOAD(lq_y1); F.qv = PIPE_RLOAD(lq_y2);
+  K.att_m_rel = P.f_agc_att - P.f_agc_rel; K.rel = P.f_agc_rel;
+  K.step_k = 1099511627776.0f; K.step_b = -549755813888.0f;
+  K.g_lo = 0.1f; K.g_hi = 10.0f;
+  if (UNI) {
+    K.bp_b0 = P.u_bp_b0h; K.bp_na1 = P.u_bp_na1; K.bp_na2 = P.u_bp_na2;
+  } else {
+    K.bp_b0 = (float)(PIPE_CLOAD(CF_bp_b0) * (0.5 * P.lp_b0));
+    K.bp_na1 = -(float)PIPE_CLOAD(CF_bp_a1); K.bp_na2 = -(float)PIPE_CLOAD(CF_bp_a2);
+  }
+  K.lp_a2 = P.f_lp_a2; K.lp_nd = -P.f_lp_delta;
+  asm volatile("" : "+v"(K.att_m_rel), "+v"(K.rel), "+v"(K.step_k), "+v"(K.step_b), "+v"(K.g_lo), "+v"(K.g_hi));
+  asm volatile("" : "+v"(K.bp_b0), "+v"(K.bp_na1), "+v"(K.bp_na2), "+v"(K.lp_a2), "+v"(K.lp_nd));
+}
+
+template <bool UNI>
+__device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, const DemodState &S, const PipeCtx &C,
+                                 uint32_t stream, uint32_t *eod_counts) {
+  const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
+  const FastMem &M = C.M;
+  const uint32_t fld = C.fld, row4 = C.row4;
+  B.qai = PIPE_RLOAD(zq_ai); B.qaq = PIPE_RLOAD(zq_aq); B.qbi = PIPE_RLOAD(zq_bi); B.qbq = PIPE_RLOAD(zq_bq);
+  B.q0i = PIPE_RLOAD(zq_0i); B.q0q = PIPE_RLOAD(zq_0q);
+  B.px1 = PIPE_RLOAD(po_x1); B.px2 = PIPE_RLOAD(po_x2); B.py = PIPE_RLOAD(po_y1); B.pv = PIPE_RLOAD(po_y2);
+  B.last_phase = PIPE_RLOAD(last_phase);
+  B.thr = PIPE_RLOAD(sil_thr);
+  B.dph = PIPE_ILOAD(zr_dph);
+  B.dix1 = PIPE_RLOAD(zd_ix1); B.dix2 = PIPE_RLOAD(zd_ix2); B.diy = PIPE_RLOAD(zd_iy); B.dvi = PIPE_RLOAD(zd_iv);
+  B.dqx1 = PIPE_RLOAD(zd_qx1); B.dqx2 = PIPE_RLOAD(zd_qx2); B.dqy = PIPE_RLOAD(zd_qy); B.dqv = PIPE_RLOAD(zd_qv);
+  B.matched = PIPE_ILOAD(matched);
+  B.thr_eff = PIPE_ILOAD(started) ? kStarted : P.matched_min;
+  {
+    const uint32_t cc = PIPE_ILOAD(cad_ctr);
+    B.rho = cc ? P.cadence - cc : 0u;
+  }
+  B.ls = 0u - PIPE_ILOAD(sil_cnt);
+  B.acc = PIPE_ILOAD(bit_acc);
+  B.T = PIPE_ILOAD(bit_wait);
+  B.tlast = B.T - PIPE_ILOAD(bit_reload);
+  {
+    // byteState (fsk.ts:125) -> shift register: position p, bits received so far under a sentinel at bit p
+    const uint32_t pos = PIPE_ILOAD(bit_pos), bc = PIPE_ILOAD(byte_cur);
+    B.sreg = pos <= 9u ? (1u << pos) | ((bc & 0x1FFu) >> (9u - pos)) : (1u << 10) | ((bc & 0x1FFu) << 1) | (bc >> 31);
+  }
+  if (B.thr_eff != kStarted) { B.T = kBigWait; B.tlast = B.T - PIPE_ILOAD(bit_reload); }  // (re)park: decisions imply a started frame
+  B.out_cnt = 0;
+  if (C.valid && eod_counts) eod_counts[stream] = 0;  // incremented in memory by the (rare) EOD path
+  if (!C.valid) {
+    // Lanes beyond the batch run on zeros with a copy of the last stream's state.  Park them: no sync candidate (a
+    // threshold `matched` cannot reach), no silence run (nothing is below a negative threshold), no bit clock -- so
+    // they never enter a rare path, where their out-of-range row index would be used as an address.
+    B.thr_eff = 0xFFFFFFFEu; B.thr = -1.0f; B.T = kBigWait; B.tlast = B.T;
+  }
+  K.c1 = P.z_c1; K.c2 = P.z_c2;
+  K.lp_b0 = P.f_lp_b0; K.lp_a2 = P.f_lp_a2; K.lp_nd = -P.f_lp_delta;
+  K.qn = ~(uint32_t)P.pat_q; K.mask = (uint32_t)P.pat_mask; K.d = P.d;
+  K.tiny = 1.0e-37f; K.sgn = 0x80000000u; K.edge_min = (1u << P.stop_pos) - 2u; K.eod_m1 = P.eod_min - 1u;
+  asm volatile("" : "+v"(K.edge_min), "+v"(K.eod_m1));
+  asm volatile("" : "+v"(K.c1), "+v"(K.c2), "+v"(K.lp_b0), "+v"(K.lp_a2), "+v"(K.lp_nd), "+v"(K.qn), "+v"(K.mask), "+v"(K.d));
+  asm volatile("" : "+v"(K.tiny), "+v"(K.sgn));
+}
+
+// everything back to the state arrays.  F: the front's final state, n: samples of the launch, k: decimated samples,
+// kappa = k % cadence, free0: the free-running frame's NCO phase at the first sample of the launch.
+template <bool UNI>
+__device__ inline void pipe_store(const FrontLane &F, bool store_front, const BackLane &B, const DemodParams &P,
+                                  const PipeCtx &C, uint32_t stream, uint32_t *out_counts, size_t n, uint32_t k,
+                                  uint32_t kappa, uint32_t phase, uint32_t amp_pos, uint64_t inc, uint64_t free0) {
+  const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
+  const FastMem &M = C.M;
+  const uint32_t fld = C.fld, row4 = C.row4;
+  if (store_front) {
+    PIPE_RSTORE(agc_gain, F.g);
+    PIPE_RSTORE(bp_x1, F.bx1); PIPE_RSTORE(bp_x2, F.bx2); PIPE_RSTORE(bp_y1, F.by1); PIPE_RSTORE(bp_y2, F.by2);
+  }
+  // free-running I/Q low-pass, the correction, lastPhase in the free frame; NCO phase = free phase + frame offset
+  PIPE_RSTORE(li_x1, F.ix1); PIPE_RSTORE(li_x2, F.ix2); PIPE_RSTORE(li_y1, F.iy); PIPE_RSTORE(li_y2, F.iv);
+  PIPE_RSTORE(lq_x1, F.qx1); PIPE_RSTORE(lq_x2, F.qx2); PIPE_RSTORE(lq_y1, F.qy); PIPE_RSTORE(lq_y2, F.qv);
+  PIPE_RSTORE(zq_ai, B.qai); PIPE_RSTORE(zq_aq, B.qaq); PIPE_RSTORE(zq_bi, B.qbi); PIPE_RSTORE(zq_bq, B.qbq);
+  PIPE_RSTORE(zq_0i, B.q0i); PIPE_RSTORE(zq_0q, B.q0q);
+  PIPE_ISTORE(zr_dph, B.dph);
+  PIPE_RSTORE(zd_ix1, B.dix1); PIPE_RSTORE(zd_ix2, B.dix2); PIPE_RSTORE(zd_iy, B.diy); PIPE_RSTORE(zd_iv, B.dvi);
+  PIPE_RSTORE(zd_qx1, B.dqx1); PIPE_RSTORE(zd_qx2, B.dqx2); PIPE_RSTORE(zd_qy, B.dqy); PIPE_RSTORE(zd_qv, B.dqv);
+  PIPE_RSTORE(last_phase, B.last_phase);
+  {
+    const uint64_t off = ((uint64_t)PIPE_ILOAD(fr_hi) << 32) | PIPE_ILOAD(fr_lo);
+    const uint64_t acc = free0 + inc * (uint64_t)n + off;
+    PIPE_ISTORE(nco_lo, (uint32_t)acc); PIPE_ISTORE(nco_hi, (uint32_t)(acc >> 32));
+  }
+  PIPE_RSTORE(po_x1, B.px1); PIPE_RSTORE(po_x2, B.px2); PIPE_RSTORE(po_y1, B.py); PIPE_RSTORE(po_y2, B.pv);
+  PIPE_RSTORE(sil_thr, B.thr);
+  {
+    const uint32_t cc = kappa + P.cadence - B.rho;
+    PIPE_ISTORE(cad_ctr, cc >= P.cadence ? cc - P.cadence : cc);
+  }
+  PIPE_ISTORE(sil_cnt, k - B.ls);
+  PIPE_ISTORE(bit_acc, B.acc); PIPE_ISTORE(bit_wait, B.T - k); PIPE_ISTORE(bit_reload, B.T - B.tlast);
+  {
+    const uint32_t pos = 31u - (uint32_t)__builtin_clz(B.sreg | 1u);
+    const uint32_t bc = pos <= 9u ? (B.sreg & ((1u << pos) - 1u)) << (9u - pos) : ((B.sreg >> 1) & 0x1FFu) | ((B.sreg & 1u) << 31);
+    PIPE_ISTORE(byte_cur, bc); PIPE_ISTORE(bit_pos, pos);
+  }
+  PIPE_ISTORE(started, B.thr_eff == kStarted ? 1u : 0u); PIPE_ISTORE(matched, B.matched);
+  PIPE_ISTORE(gsc, k + PIPE_ILOAD(gsc));              // the gsc word held the offset during the launch
+  const uint32_t rl = PIPE_ILOAD(ring_len) + k, al = PIPE_ILOAD(amp_len) + k;
+  PIPE_ISTORE(ring_len, rl < P.ring_cap ? rl : P.ring_cap);
+  PIPE_ISTORE(amp_len, al < P.amp_cap ? al : P.amp_cap);
+  PIPE_ISTORE(poly_phase, phase);
+  PIPE_ISTORE(amp_pos, amp_pos);
+  if (C.valid) out_counts[stream] = B.out_cnt;
+}
+
+// wave-uniform LDS word, polled by the other wave of the workgroup
+__device__ inline uint32_t lds_peek(const uint32_t *p) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ inline void lds_post(uint32_t *p, uint32_t v) {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" : : "v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
+}
+
+// ================================================================================================================
+// Two waves per 64-stream group.
+// LDS: stage [4][65] v4f | ring [kPipeSlots][8][64] v4f | fin [2][64] v4f | zt [2][8] v4f | poly [d][64] u32 | counters
+// ================================================================================================================
+template <bool WB, bool UNI>
+__global__ __launch_bounds__(128) void demod_pipe_kernel(
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch,
+    uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
+    uint32_t *__restrict__ eod_counts) {
+  extern __shared__ float4 lds[];
+  v4f *stage = reinterpret_cast<v4f *>(lds);
+  v4f *ring = stage + 4 * kSlotStride;
+  v4f *fin = ring + kPipeSlots * kSlotV4;
+  v4f *zt = fin + 2 * 64;                                 // NCO phasors of two tiles: [2][16 samples] x (cos, sin)
+  uint32_t *poly = reinterpret_cast<uint32_t *>(zt + 2 * 8);
+  uint32_t *ctr = poly + 64u * P.d;                       // [0] tiles produced, [1] tiles consumed
+  uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
+
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t stream = blockIdx.x * 64u + lane;
+  const PipeCtx C = pipe_ctx(P, S, stream);
+  const size_t n_tiles = n / kFastTile;
+  const uint64_t inc = UNI ? (((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo) : S.nco_inc[C.row4 >> 2];
+  const uint64_t free0 = pipe_free0<UNI>(C);
+
+  if (threadIdx.x == 0) { ctr[0] = 0; ctr[1] = 0; }
+  __syncthreads();
+
+  if (wave == 0) {
+    // ---------------------------------------------------------------------------------------------- front
+    FrontLane F;
+    FrontK K;
+    front_load<UNI>(F, K, P, S, C);
+    // per-lane NCO (per-stream tone pairs): phasor recurrence, re-seeded from the exact accumulator at every tile
+    float wre = 1.f, wim = 0.f;
+    if (!UNI) {
+      const __amdgpu_buffer_rsrc_t cf_rsrc = C.cf_rsrc;
+      const uint32_t fld = C.fld, row4 = C.row4;
+      wre = (float)PIPE_CLOAD(CF_w1_re); wim = (float)PIPE_CLOAD(CF_w1_im);
+    }
+    const uint32_t sub_row = lane >> 2, chunk = lane & 3;
+    const uint32_t rows_here = P.n_streams - blockIdx.x * 64u < 64u ? P.n_streams - blockIdx.x * 64u : 64u;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        samples + (size_t)blockIdx.x * 64u * pitch, 0, (int)(uint32_t)(rows_here * pitch * 4u), 0x00020000);
+    const uint32_t in_voff = (uint32_t)((sub_row * pitch + 4u * chunk) * 4u);
+    const uint32_t in_row16 = (uint32_t)(16u * pitch * 4u);
+    const uint32_t st_slot = chunk * kSlotStride + sub_row;
+    // three tiles in flight (rows beyond the batch read as 0: the row step rides in the bounds-checked VGPR offset)
+    auto load_tile = [&](size_t t, v4f &a, v4f &b, v4f &c, v4f &d) {
+      const uint32_t tn = (uint32_t)((t < n_tiles ? t : n_tiles - 1) * kFastTile * 4u);
+      a = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff, tn, 0));
+      b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff + in_row16, tn, 0));
+      c = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff + 2u * in_row16, tn, 0));
+      d = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff + 3u * in_row16, tn, 0));
+    };
+    v4f a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+    load_tile(0, a0, a1, a2, a3);
+    load_tile(1, b0, b1, b2, b3);
+    load_tile(2, c0, c1, c2, c3);
+    // NCO phasors (uniform configuration): lane j & 15 evaluates sample j of the tile from the exact accumulator, the
+    // sixteen (cos, sin) pairs are parked in LDS and read back as broadcasts
+    const uint64_t zoff = inc * (uint64_t)(lane & 15u);
+    uint32_t consumed = 0;
+    for (size_t t = 0; t < n_tiles; t++) {
+      while (t - consumed >= kPipeSlots) {                  // ring full: wait for the back wave
+        consumed = lds_peek(&ctr[1]);
+        if (t - consumed >= kPipeSlots) __builtin_amdgcn_s_sleep(1);
+      }
+      stage[st_slot] = a0; stage[st_slot + 16] = a1; stage[st_slot + 32] = a2; stage[st_slot + 48] = a3;
+      a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+      b0 = c0; b1 = c1; b2 = c2; b3 = c3;
+      const v4f *ztile = zt + (t & 1) * 8u;
+      float zr = 1.f, zi = 0.f;
+      if (UNI) {
+        float pc, ps;
+        nco_phasor(free0 + inc * (uint64_t)(t * kFastTile) + zoff, pc, ps);
+        reinterpret_cast<f2 *>(zt + (t & 1) * 8u)[lane & 15u] = (f2){pc, ps};
+      } else {
+        nco_phasor(free0 + inc * (uint64_t)(t * kFastTile), zr, zi);
+      }
+      load_tile(t + 3, c0, c1, c2, c3);
+      v4f *slot = ring + (uint32_t)(t % kPipeSlots) * kSlotV4;
+#pragma unroll 1
+      for (uint32_t c = 0; c < 4; c++) {
+        const v4f x4 = stage[c * kSlotStride + lane];       // written by this wave: a wave's ds ops are ordered
+        float zc[4], zs[4];
+        if (UNI) {
+          const v4f z01 = ztile[c * 2u], z23 = ztile[c * 2u + 1u];   // same address in every lane: LDS broadcast
+          zc[0] = z01.x; zs[0] = z01.y; zc[1] = z01.z; zs[1] = z01.w;
+          zc[2] = z23.x; zs[2] = z23.y; zc[3] = z23.z; zs[3] = z23.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            zc[j] = zr; zs[j] = zi;
+            const float nr = __builtin_fmaf(-zi, wim, zr * wre), ni = __builtin_fmaf(zi, wre, zr * wim);
+            zr = nr; zi = ni;
+          }
+        }
+        const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
+        float xs[4], y[4], oi[4], oq[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) front_sample(F, K, xin[j], zc[j], zs[j], xs[j], y[j], oi[j], oq[j]);
+        slot[c * 64u + lane] = (v4f){y[0], y[1], y[2], y[3]};
+        slot[(4u + c) * 64u + lane] = (v4f){oi[0] + oi[1], oq[0] + oq[1], oi[2] + oi[3], oq[2] + oq[3]};
+        if (WB) {
+          if (C.valid)
+            *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + t * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
+        }
+      }
+      lds_post(&ctr[0], (uint32_t)t + 1u);                  // this wave's ring writes are done (lgkmcnt(0) inside)
+    }
+    // hand the final I/Q filter state to the back wave, which owns the epilogue
+    fin[lane] = (v4f){F.ix1, F.ix2, F.iy, F.iv};
+    fin[64u + lane] = (v4f){F.qx1, F.qx2, F.qy, F.qv};
+    lds_post(&ctr[0], (uint32_t)n_tiles + 1u);
+    {
+      const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
+      const FastMem &M = C.M;
+      const uint32_t fld = C.fld;
+      PIPE_RSTORE(agc_gain, F.g);
+      PIPE_RSTORE(bp_x1, F.bx1); PIPE_RSTORE(bp_x2, F.bx2); PIPE_RSTORE(bp_y1, F.by1); PIPE_RSTORE(bp_y2, F.by2);
+    }
+  } else {
+    // ---------------------------------------------------------------------------------------------- back
+    BackLane B;
+    BackK K;
+    back_load<UNI>(B, K, P, S, C, stream, eod_counts);
+    const FastMem &M = C.M;
+    const uint32_t fld = C.fld, row4 = C.row4;
+    for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
+    BackU X;
+    X.k = 0; X.kappa = 0; X.kv = 0; X.free0 = free0;
+    X.direct = __builtin_amdgcn_ballot_w64(B.dph < 2u) ? 2u : 0u;
+    asm volatile("" : "+v"(X.kv));
+    X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
+    const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
+    const uint32_t amp_row_bytes = P.n_streams * 4u;
+    X.amp_soff = amp_pos0 * amp_row_bytes;
+    const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
+    const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
+    uint32_t produced = 0;
+    for (size_t t = 0; t < n_tiles; t++) {
+      while (produced <= t) {
+        produced = lds_peek(&ctr[0]);
+        if (produced <= t) __builtin_amdgcn_s_sleep(1);
+      }
+      const v4f *slot = ring + (uint32_t)(t % kPipeSlots) * kSlotV4;
+#pragma unroll 1
+      for (uint32_t c = 0; c < 4; c++) {
+        const v4f u4 = slot[(4u + c) * 64u + lane];
+        const uint32_t ph0 = X.phase, ph1 = (X.phase + 1 == P.d) ? 0u : X.phase + 1;
+        const uint32_t r0 = poly[ph0 * 64u + lane];
+        const uint32_t r1 = poly[ph1 * 64u + lane];
+        const float *yp = reinterpret_cast<const float *>(&slot[c * 64u + lane]);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          X.k++;
+          X.kv += 1u;
+          X.kappa = (X.kappa + 1 == P.cadence) ? 0u : X.kappa + 1;
+          X.phase = h ? ph1 : ph0;
+          back_pair<UNI>(B, K, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, h ? u4.z : u4.x,
+                         h ? u4.w : u4.y, yp + 2 * h, h ? r1 : r0, inc);
+          X.amp_soff += amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
+        }
+        X.phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
+      }
+      lds_post(&ctr[1], (uint32_t)t + 1u);                  // slot free (this wave's reads of it are complete)
+    }
+    while (produced <= n_tiles) {
+      produced = lds_peek(&ctr[0]);
+      if (produced <= n_tiles) __builtin_amdgcn_s_sleep(1);
+    }
+    FrontLane F;
+    {
+      const v4f fi = fin[lane], fq = fin[64u + lane];
+      F.ix1 = fi.x; F.ix2 = fi.y; F.iy = fi.z; F.iv = fi.w;
+      F.qx1 = fq.x; F.qx2 = fq.y; F.qy = fq.z; F.qv = fq.w;
+      F.g = F.bx1 = F.bx2 = F.by1 = F.by2 = 0.f;
+    }
+    for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
+    pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.kappa, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
+  }
+}
+
+// ================================================================================================================
+// One wave per 64-stream group: the same two halves, pair by pair through registers.
+// LDS: stage [4][65] v4f | zt [2][8] v4f | poly [d][64] u32
+// ================================================================================================================
+template <bool WB, bool UNI>
+__global__ __launch_bounds__(64, 3) void demod_fused_kernel(
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch,
+    uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
+    uint32_t *__restrict__ eod_counts) {
+  extern __shared__ float4 lds[];
+  v4f *stage = reinterpret_cast<v4f *>(lds);
+  v4f *zt = stage + 4 * kSlotStride;
+  uint32_t *poly = reinterpret_cast<uint32_t *>(zt + 2 * 8);
+  uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t stream = blockIdx.x * 64u + lane;
+  const PipeCtx C = pipe_ctx(P, S, stream);
+  const FastMem &M = C.M;
+  const uint32_t fld = C.fld, row4 = C.row4;
+  const uint64_t inc = UNI ? (((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo) : S.nco_inc[C.row4 >> 2];
+  const uint64_t free0 = pipe_free0<UNI>(C);
+
+  FrontLane F;
+  FrontK FK;
+  front_load<UNI>(F, FK, P, S, C);
+  BackLane B;
+  BackK BK;
+  back_load<UNI>(B, BK, P, S, C, stream, eod_counts);
+  float wre = 1.f, wim = 0.f;
+  if (!UNI) {
+    const __amdgpu_buffer_rsrc_t cf_rsrc = C.cf_rsrc;
+    wre = (float)PIPE_CLOAD(CF_w1_re); wim = (float)PIPE_CLOAD(CF_w1_im);
+  }
+  for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
+  BackU X;
+  X.k = 0; X.kappa = 0; X.kv = 0; X.free0 = free0;
+  X.direct = __builtin_amdgcn_ballot_w64(B.dph < 2u) ? 2u : 0u;
+  asm volatile("" : "+v"(X.kv));
+  X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
+  const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
+  const uint32_t amp_row_bytes = P.n_streams * 4u;
+  X.amp_soff = amp_pos0 * amp_row_bytes;
+  const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
+  const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
+
+  // tile prefetch as in the r01 kernel: inline-asm loads with a hand-counted vmcnt (each tile issues at least 8
+  // VMEM operations after its prefetch -- the unconditional ring stores -- so vmcnt(8) retires exactly the loads)
+  const uint32_t sub_row = lane >> 2, chunk = lane & 3;
+  const uint32_t rows_here = P.n_streams - blockIdx.x * 64u < 64u ? P.n_streams - blockIdx.x * 64u : 64u;
+  v4i in_rsrc;
+  {
+    const uint64_t base = reinterpret_cast<uint64_t>(samples + (size_t)blockIdx.x * 64u * pitch);
+    in_rsrc.x = (int)(uint32_t)base;
+    in_rsrc.y = (int)(uint32_t)(base >> 32);
+    in_rsrc.z = (int)(uint32_t)(rows_here * pitch * 4u);
+    in_rsrc.w = 0x00020000;
+  }
+  const uint32_t in_voff = (uint32_t)((sub_row * pitch + 4u * chunk) * 4u);
+  const uint32_t in_row16 = (uint32_t)(16u * pitch * 4u);
+  v4f pre0, pre1, pre2, pre3;
+#define FSK_BLOAD4(dst, rows16, soff)                                                                      \
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(in_voff + (rows16) * in_row16), \
+               "s"(in_rsrc), "s"(soff) : "memory")
+  {
+    const uint32_t s0 = 0u;
+    FSK_BLOAD4(pre0, 0u, s0); FSK_BLOAD4(pre1, 1u, s0); FSK_BLOAD4(pre2, 2u, s0); FSK_BLOAD4(pre3, 3u, s0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): state, constants and the first tile are complete
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre0), "+v"(pre1), "+v"(pre2), "+v"(pre3) : : "memory");
+  const uint32_t st_slot = chunk * kSlotStride + sub_row;
+  // NCO phasors: see demod_pipe_kernel
+  const uint64_t zoff = inc * (uint64_t)(lane & 15u);
+
+  for (size_t t0 = 0; t0 < n; t0 += kFastTile) {
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(8)" : "+v"(pre0), "+v"(pre1), "+v"(pre2), "+v"(pre3) : : "memory");
+    stage[st_slot] = pre0;
+    stage[st_slot + 16] = pre1;
+    stage[st_slot + 32] = pre2;
+    stage[st_slot + 48] = pre3;
+    const v4f *ztile = zt + ((t0 >> 4) & 1) * 8u;
+    float zr = 1.f, zi = 0.f;
+    if (UNI) {
+      float pc, ps;
+      nco_phasor(free0 + inc * (uint64_t)t0 + zoff, pc, ps);
+      reinterpret_cast<f2 *>(zt + ((t0 >> 4) & 1) * 8u)[lane & 15u] = (f2){pc, ps};
+    } else {
+      nco_phasor(free0 + inc * (uint64_t)t0, zr, zi);
+    }
+    __syncthreads();
+    {
+      const uint32_t tn = (uint32_t)((t0 + kFastTile < n ? t0 + kFastTile : t0) * 4u);
+      FSK_BLOAD4(pre0, 0u, tn); FSK_BLOAD4(pre1, 1u, tn); FSK_BLOAD4(pre2, 2u, tn); FSK_BLOAD4(pre3, 3u, tn);
+    }
+#pragma unroll 1
+    for (uint32_t c = 0; c < 4; c++) {
+      const v4f x4 = stage[c * kSlotStride + lane];
+      const uint32_t ph0 = X.phase, ph1 = (X.phase + 1 == P.d) ? 0u : X.phase + 1;
+      const uint32_t r0 = poly[ph0 * 64u + lane];
+      const uint32_t r1 = poly[ph1 * 64u + lane];
+      float zc[4], zs[4];
+      if (UNI) {
+        const v4f z01 = ztile[c * 2u], z23 = ztile[c * 2u + 1u];
+        zc[0] = z01.x; zs[0] = z01.y; zc[1] = z01.z; zs[1] = z01.w;
+        zc[2] = z23.x; zs[2] = z23.y; zc[3] = z23.z; zs[3] = z23.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          zc[j] = zr; zs[j] = zi;
+          const float nr = __builtin_fmaf(-zi, wim, zr * wre), ni = __builtin_fmaf(zi, wre, zr * wim);
+          zr = nr; zi = ni;
+        }
+      }
+      const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
+      float xs[4];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        float y0, y1, oi0, oq0, oi1, oq1;
+        front_sample(F, FK, xin[2 * h], zc[2 * h], zs[2 * h], xs[2 * h], y0, oi0, oq0);
+        front_sample(F, FK, xin[2 * h + 1], zc[2 * h + 1], zs[2 * h + 1], xs[2 * h + 1], y1, oi1, oq1);
+        X.k++;
+        X.kv += 1u;
+        X.kappa = (X.kappa + 1 == P.cadence) ? 0u : X.kappa + 1;
+        X.phase = h ? ph1 : ph0;
+        const float ypr[2] = {y0, y1};
+        back_pair<UNI>(B, BK, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, oi0 + oi1, oq0 + oq1,
+                       ypr, h ? r1 : r0, inc);
+        X.amp_soff += amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
+      }
+      X.phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
+      if (WB) {
+        if (C.valid)
+          *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + t0 + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
+      }
+    }
+  }
+  // the last prefetch is still in flight and its registers are dead to the compiler: keep them until it has landed
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre0), "+v"(pre1), "+v"(pre2), "+v"(pre3) : : "memory");
+#undef FSK_BLOAD4
+  for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
+  pipe_store<UNI>(F, true, B, P, C, stream, out_counts, n, X.k, X.kappa, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+size_t demod_pipe_lds_bytes(const DemodParams &P) {
+  return sizeof(float4) * (4 * kSlotStride + kPipeSlots * kSlotV4 + 2 * 64 + 2 * 8) + sizeof(uint32_t) * (64u * P.d + 4u);
+}
+size_t demod_fused_lds_bytes(const DemodParams &P) { return sizeof(float4) * (4 * kSlotStride + 2 * 8) + sizeof(uint32_t) * 64u * P.d; }
+
+hipError_t set_pipe_lds_limit(size_t pipe_bytes) {
+  hipError_t e = hipSuccess;
+#define FSK_ATTR(WBV, UNIV)                                                                                      \
+  if (e == hipSuccess)                                                                                           \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_pipe_kernel<WBV, UNIV>),                       \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_bytes);
+  FSK_ATTR(false, false) FSK_ATTR(false, true) FSK_ATTR(true, false) FSK_ATTR(true, true)
+#undef FSK_ATTR
+  return e;
+}
+
+hipError_t launch_demod_pipe(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+                             size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
+                             uint32_t *eod_counts, hipStream_t stream) {
+  const uint32_t blocks = (P.n_streams + 63u) / 64u;
+  const size_t lds = demod_pipe_lds_bytes(P);
+#define FSK_LAUNCH_PIPE(WBV, UNIV)                                                                          \
+  hipLaunchKernelGGL((demod_pipe_kernel<WBV, UNIV>), dim3(blocks), dim3(128), lds, stream, P, S, samples, n, pitch, \
+                     out, out_pitch, out_counts, eod_counts)
+  const bool uni = P.uni_cfg != 0;
+  if (writeback) { if (uni) FSK_LAUNCH_PIPE(true, true); else FSK_LAUNCH_PIPE(true, false); }
+  else { if (uni) FSK_LAUNCH_PIPE(false, true); else FSK_LAUNCH_PIPE(false, false); }
+#undef FSK_LAUNCH_PIPE
+  return hipGetLastError();
+}
+
+hipError_t launch_demod_fused(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
+                              uint32_t *eod_counts, hipStream_t stream) {
+  const uint32_t blocks = (P.n_streams + 63u) / 64u;
+  const size_t lds = demod_fused_lds_bytes(P);
+#define FSK_LAUNCH_FUSED(WBV, UNIV)                                                                          \
+  hipLaunchKernelGGL((demod_fused_kernel<WBV, UNIV>), dim3(blocks), dim3(64), lds, stream, P, S, samples, n, pitch, \
+                     out, out_pitch, out_counts, eod_counts)
+  const bool uni = P.uni_cfg != 0;
+  if (writeback) { if (uni) FSK_LAUNCH_FUSED(true, true); else FSK_LAUNCH_FUSED(true, false); }
+  else { if (uni) FSK_LAUNCH_FUSED(false, true); else FSK_LAUNCH_FUSED(false, false); }
+#undef FSK_LAUNCH_FUSED
+  return hipGetLastError();
+}
+
+}  // namespace fsk

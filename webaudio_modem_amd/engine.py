@@ -102,9 +102,12 @@ class FSKEngine:
 
     # ---- demodulateData (fsk.ts:190-222) -------------------------------------------------------
     def max_bytes(self, n_per_stream):
-        """Upper bound on bytes one call can produce per stream (one byte needs >= 9 bit times)."""
-        spb = int(self.config["sampleRate"] // self.config["baudRate"])
-        return int(n_per_stream // max(1, 4 * spb)) + 8
+        """Upper bound on bytes one call can produce per stream (fskhip_max_bytes: size out_pitch with it)."""
+        return int(self._L.fskhip_max_bytes(self._h, int(n_per_stream)))
+
+    def last_kernel(self):
+        """Name of the kernel the last demodulate_device call launched for its whole tiles (fskhip_last_kernel)."""
+        return (self._L.fskhip_last_kernel(self._h) or b"").decode()
 
     def demodulate_data(self, samples, writeback_agc=False, out_pitch=None):
         """samples: float32 [S, N] (host).  Returns (list of bytes per stream, eod counts ndarray).
