@@ -139,7 +139,7 @@ def test_product_never_imports_oracle():
 
 def test_whole_tile_kernels_never_spill():
     """tools/check_isa.py: the one-wave kernel's asm-issued prefetch is only safe without spills; it is built for 3 waves
-    per SIMD (<= 168 VGPRs), the two-wave kernel for 4 workgroups per CU (<= 128)."""
+    per SIMD (<= 168 VGPRs), the two-wave kernel for 4 workgroups = 8 waves per CU, 2 per SIMD (<= 256)."""
     import shutil
     import sys
     if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
@@ -156,6 +156,7 @@ def test_whole_tile_kernels_never_spill():
     assert len(pipe) == 4
     for name, v in pipe.items():
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
-        assert v["VGPRs"] <= 128, (name, v)
+        assert v["VGPRs"] <= 256, (name, v)
     # the registers the asm prefetch lands in are never touched while a load may still be in flight
     assert check_isa.prefetch_register_hazards() == []
+    assert check_isa.pipe_prefetch_hazards() == []

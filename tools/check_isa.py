@@ -103,8 +103,67 @@ def prefetch_register_hazards():
     return problems
 
 
+def pipe_prefetch_hazards():
+    """The two-wave kernel's front wave keeps three register sets of asm-issued tile loads in flight (unrolled by three).
+    In its tile loop (everything after the prologue's `s_waitcnt vmcnt(0)` up to the epilogue's) a register of a set may
+    only be read after the `s_waitcnt vmcnt(N)` placed in front of that set's ds_write_b128 staging, and only by it."""
+    src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_pipe.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        asm = os.path.join(tmp, "d.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+                        "-S", "--cuda-device-only", "-o", asm, src], capture_output=True, text=True, check=True)
+        text = open(asm).read()
+
+    def regs_of(line):
+        out = set()
+        for m in re.finditer(r"v\[(\d+):(\d+)\]", line):
+            out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bv(\d+)\b", line):
+            out.add(int(m.group(1)))
+        return out
+
+    problems = []
+    found = list(re.finditer(r"^(_ZN3fsk17demod_pipe_kernel\w+):[^\n]*\n", text, re.M))
+    if len(found) != 4:
+        problems.append(("demod_pipe_kernel", "expected 4 kernel bodies in the ISA, found %d" % len(found)))
+    for m in found:
+        body = [l for l in text[m.end():text.index(".Lfunc_end", m.end())].split("\n")]
+        loads = [i for i, l in enumerate(body) if "buffer_load_dwordx4" in l]
+        if len(loads) != 24:
+            problems.append((m.group(1), "expected 12 prologue + 12 loop prefetch loads, found %d" % len(loads)))
+            continue
+        loop_loads = loads[12:]
+        first, last = loop_loads[0], loop_loads[-1]
+        # walk the loop region: from the first staging wait before the first loop load to the last loop load
+        start = max(i for i in range(loads[11], first) if "s_waitcnt vmcnt(" in body[i] and "ASMSTART" in body[i - 1])
+        pending = {}   # register -> index of the load that targets it
+        for i in range(start, len(body)):
+            line = body[i].strip()
+            if not line or line.startswith(";") or line.startswith("."):
+                continue
+            if "buffer_load_dwordx4" in line:
+                for r in regs_of(line.split(",")[0]):
+                    pending[r] = i
+                continue
+            if line.startswith("s_waitcnt") and "vmcnt(" in line:
+                n = int(re.search(r"vmcnt\((\d+)\)", line).group(1))
+                # in issue order: all but the n youngest VMEM operations are complete; count loads only (stores of the
+                # write-back variant make the real wait stricter, never looser)
+                order = sorted(set(pending.values()))
+                done = set(order[:max(0, len(order) - (n + 3) // 4 * 4)]) if n else set(order)
+                pending = {r: j for r, j in pending.items() if j not in done}
+                continue
+            if "s_endpgm" in line:
+                break
+            touched = regs_of(line) & set(pending)
+            if touched and i <= last + 400:
+                problems.append((m.group(1), "register of an in-flight tile load touched: " + line))
+                break
+    return problems
+
+
 if __name__ == "__main__":
-    for name, what in prefetch_register_hazards():
+    for name, what in prefetch_register_hazards() + pipe_prefetch_hazards():
         print("HAZARD", name[:50], what)
         sys.exit(2)
     r = kernel_resources()

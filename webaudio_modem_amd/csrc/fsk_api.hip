@@ -22,12 +22,15 @@ hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, bool app
 bool demod_fast_applicable(int precision, bool uniform_even, const DemodParams &P, const DemodState &S,
                            const float *samples, size_t pitch);
 // fsk_pipe.hip: free-running front / ZIR-corrected back kernels
-hipError_t launch_demod_pipe(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+hipError_t launch_demod_pipe(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream);
-hipError_t launch_demod_fused(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+hipError_t launch_demod_fused(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                               size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                               uint32_t *eod_counts, hipStream_t stream);
+hipError_t launch_demod_tail(bool writeback, bool append, int parity0, const DemodParams &P, const DemodState &S,
+                             float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
+                             uint32_t *eod_counts, hipStream_t stream);
 size_t demod_pipe_lds_bytes(const DemodParams &P);
 size_t demod_fused_lds_bytes(const DemodParams &P);
 hipError_t set_pipe_lds_limit(size_t pipe_bytes);
@@ -155,6 +158,8 @@ struct fskhip_engine {
   bool use_split = false;        // two waves per 64-stream group (demod_split_kernel): batches of fewer than two waves per SIMD
   uint32_t split_cus = 256;
   bool split_forced = false;     // FSKHIP_SPLIT was set: skip the residency check too
+  bool gen_odd = false;          // fp32: the last generic-kernel launch left a decimator pair open (its partial sums are in
+                                 // the reference's frame, the whole-tile kernels' in the free-running one)
   const char *last_kernel = "";  // what the last fskhip_demodulate_device call launched for its whole tiles
   bool demod_ok = true;          // false: configuration the demodulator kernels do not implement
   std::string demod_why;
@@ -186,7 +191,7 @@ size_t engine_max_bytes(const fskhip_engine *e, size_t n_per_stream) {
 // everything fskhip_demodulate_device's choice of launches depends on besides its arguments
 uint32_t engine_launch_key(const fskhip_engine *e) {
   return (e->ds_uniform ? 1u : 0u) | (e->ds_parity << 1) | (e->force_generic ? 4u : 0u) | (e->timing ? 8u : 0u) |
-         (e->use_split ? 32u : 0u) |
+         (e->use_split ? 32u : 0u) | (e->gen_odd ? 64u : 0u) |
          (e->S.trace_stream != 0xFFFFFFFFu ? 16u : 0u);
 }
 void engine_note_replayed_call(fskhip_engine *e, size_t n) {
@@ -586,30 +591,55 @@ int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_
   }
   {
     const bool wb = (flags & FSKHIP_DEMOD_WRITEBACK_AGC) != 0;
-    // whole 16-sample tiles of lock-step fp32 streams go through the fast kernel, the rest (and every
-    // other configuration) through the generic one
-    size_t n_fast = 0;
-    if (!e->force_generic && demod_fast_applicable(e->precision, e->ds_uniform && e->ds_parity == 0, e->P,
-                                                   e->S, d_samples, pitch))
-      n_fast = n & ~(size_t)15;
-    // whole tiles: two waves per 64-stream group while the batch gives the SIMDs fewer than two waves each and all
-    // workgroups' LDS rings fit on the CUs at once (LDS per workgroup x workgroups per CU within 160 KB), else one
-    const size_t wgs_per_cu = (e->n_blocks + e->split_cus - 1) / e->split_cus;
-    const size_t pipe_lds = demod_pipe_lds_bytes(e->P);
+    // Lock-step fp32 batches with narrow integer-capacity rings never leave fsk_pipe.hip's arithmetic: a head of
+    // single samples up to an even decimator parity and a 16-byte boundary, whole 16-sample tiles, a tail of single
+    // samples -- so cutting a stream into calls of any lengths changes nothing, bit for bit.  Everything else (fp64,
+    // wide / fractional rings, traces, streams out of lock step) is the generic kernel's.
     e->last_kernel = "";
-    if (n_fast && e->use_split && pipe_lds <= 160 * 1024 && (wgs_per_cu * pipe_lds <= 160 * 1024 || e->split_forced)) {
-      HIP_TRY(launch_demod_pipe(wb, e->P, e->S, d_samples, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
-      e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_pipe_kernel<true, true>" : "fsk::demod_pipe_kernel<true, false>")
-                          : (e->P.uni_cfg ? "fsk::demod_pipe_kernel<false, true>" : "fsk::demod_pipe_kernel<false, false>");
-    } else if (n_fast) {
-      HIP_TRY(launch_demod_fused(wb, e->P, e->S, d_samples, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
-      e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_fused_kernel<true, true>" : "fsk::demod_fused_kernel<true, false>")
-                          : (e->P.uni_cfg ? "fsk::demod_fused_kernel<false, true>" : "fsk::demod_fused_kernel<false, false>");
+    if (n > 0 && !e->force_generic && !e->gen_odd && demod_fast_applicable(e->precision, e->ds_uniform, e->P, e->S, d_samples, pitch)) {
+      const size_t wgs_per_cu = (e->n_blocks + e->split_cus - 1) / e->split_cus;
+      const size_t pipe_lds = demod_pipe_lds_bytes(e->P);
+      const bool two_wave = e->use_split && pipe_lds <= 160 * 1024 && (wgs_per_cu * pipe_lds <= 160 * 1024 || e->split_forced);
+      const uint32_t p0 = e->ds_parity;
+      size_t head = 0, n_fast = 0;
+      bool tiles = (pitch % 4 == 0) && (uint64_t)pitch * 4u * 64u < 0x7FFFFFF0ull;
+      if (tiles) {
+        // smallest head with (p0 + head) even and (d_samples + head) 16-byte aligned; none if the two disagree in parity
+        const size_t a = (size_t)((16u - (reinterpret_cast<uintptr_t>(d_samples) & 15u)) & 15u);
+        if ((a & 3u) != 0 || ((a >> 2) & 1u) != p0) tiles = false;
+        else head = a >> 2;
+      }
+      if (tiles && head < n) n_fast = (n - head) & ~(size_t)15;
+      if (!n_fast) head = n;   // all of it sample by sample
+      bool app = false;
+      if (head) {
+        HIP_TRY(launch_demod_tail(wb, false, (int)p0, e->P, e->S, d_samples, head, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+        e->last_kernel = "fsk::demod_tail_kernel";
+        app = true;
+      }
+      if (n_fast) {
+        if (two_wave) {
+          HIP_TRY(launch_demod_pipe(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+          e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_pipe_kernel<true, true>" : "fsk::demod_pipe_kernel<true, false>")
+                              : (e->P.uni_cfg ? "fsk::demod_pipe_kernel<false, true>" : "fsk::demod_pipe_kernel<false, false>");
+        } else {
+          HIP_TRY(launch_demod_fused(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+          e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_fused_kernel<true, true>" : "fsk::demod_fused_kernel<true, false>")
+                              : (e->P.uni_cfg ? "fsk::demod_fused_kernel<false, true>" : "fsk::demod_fused_kernel<false, false>");
+        }
+        app = true;
+        const size_t done = head + n_fast;
+        if (done < n)
+          HIP_TRY(launch_demod_tail(wb, true, 0, e->P, e->S, d_samples + done, n - done, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+      }
+    } else {
+      HIP_TRY(launch_demod(e->precision, e->ds_uniform, wb, false, e->P, e->S, d_samples, n, pitch, d_out, out_pitch,
+                           d_out_counts, d_eod_counts, st));
+      e->last_kernel = e->precision == FSKHIP_PRECISION_F64 ? "fsk::demod_kernel<double, ...>" : "fsk::demod_kernel<float, ...>";
+      // the generic kernel keeps an open decimator pair's partial sums in the reference's own frame: stay with it
+      // until the pair is closed
+      if (n > 0) e->gen_odd = e->precision == FSKHIP_PRECISION_F32 && ((e->ds_parity + (uint32_t)(n & 1)) & 1u) != 0;
     }
-    if (!n_fast) e->last_kernel = e->precision == FSKHIP_PRECISION_F64 ? "fsk::demod_kernel<double, ...>" : "fsk::demod_kernel<float, ...>";
-    if (n_fast < n || n == 0)
-      HIP_TRY(launch_demod(e->precision, e->ds_uniform, wb, n_fast != 0, e->P, e->S, d_samples + n_fast, n - n_fast,
-                           pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
   }
   if (timed) {
     HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], st));

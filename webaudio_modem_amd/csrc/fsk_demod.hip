@@ -755,12 +755,12 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
 // fsk_pipe.hip's demod_fused_kernel / demod_pipe_kernel.)
 
 // The whole-tile kernels (fsk_pipe.hip) apply to fp32 engines with narrow integer-capacity rings whose streams are in lock
-// step at a pair boundary; n must be a multiple of 16, the buffer 16-B aligned with pitch % 4 == 0.
-bool demod_fast_applicable(int precision, bool uniform_even, const DemodParams &P, const DemodState &S,
+// step (any decimator parity, any alignment: fskhip_demodulate_device cuts a call into head / whole tiles / tail).
+bool demod_fast_applicable(int precision, bool uniform, const DemodParams &P, const DemodState &S,
                            const float *samples, size_t pitch) {
-  return precision == 0 && uniform_even && !P.wide && !P.frac && P.d >= 2 && S.trace_stream == 0xFFFFFFFFu &&
-         (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(samples) & 15u) == 0) &&
-         sizeof(float4) * 4 * kSlotStride + sizeof(uint32_t) * 64u * P.d <= 56 * 1024 && (uint64_t)P.amp_cap * P.n_streams * 4u < 0xFFFFFFF0ull &&
+  (void)samples;
+  return precision == 0 && uniform && !P.wide && !P.frac && P.d >= 2 && S.trace_stream == 0xFFFFFFFFu &&
+         sizeof(float4) * (4 * kSlotStride + 16) + sizeof(uint32_t) * 64u * P.d <= 48 * 1024 && (uint64_t)P.amp_cap * P.n_streams * 4u < 0xFFFFFFF0ull &&
          (uint64_t)pitch * 4u * 64u < 0x7FFFFFF0ull;  // per-wave input descriptor and offsets fit 31 bits
 }
 size_t demod_lds_bytes(const DemodParams &P) {

@@ -457,7 +457,7 @@ __device__ inline void front_load(FrontLane &F, FrontK &K, const DemodParams &P,
 
 template <bool UNI>
 __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, const DemodState &S, const PipeCtx &C,
-                                 uint32_t stream, uint32_t *eod_counts) {
+                                 uint32_t stream, uint32_t *out_counts, uint32_t *eod_counts, int append) {
   const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
   const FastMem &M = C.M;
   const uint32_t fld = C.fld, row4 = C.row4;
@@ -485,8 +485,9 @@ __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, co
     B.sreg = pos <= 9u ? (1u << pos) | ((bc & 0x1FFu) >> (9u - pos)) : (1u << 10) | ((bc & 0x1FFu) << 1) | (bc >> 31);
   }
   if (B.thr_eff != kStarted) { B.T = kBigWait; B.tlast = B.T - PIPE_ILOAD(bit_reload); }  // (re)park: decisions imply a started frame
-  B.out_cnt = 0;
-  if (C.valid && eod_counts) eod_counts[stream] = 0;  // incremented in memory by the (rare) EOD path
+  // append: a preceding launch of the same call (head samples up to a pair / 16-byte boundary) has produced output already
+  B.out_cnt = (append && C.valid) ? out_counts[stream] : 0u;
+  if (!append && C.valid && eod_counts) eod_counts[stream] = 0;  // incremented in memory by the (rare) EOD path
   if (!C.valid) {
     // Lanes beyond the batch run on zeros with a copy of the last stream's state.  Park them: no sync candidate (a
     // threshold `matched` cannot reach), no silence run (nothing is below a negative threshold), no bit clock -- so
@@ -568,7 +569,7 @@ __device__ inline void lds_post(uint32_t *p, uint32_t v) {
 // ================================================================================================================
 template <bool WB, bool UNI>
 __global__ __launch_bounds__(128) void demod_pipe_kernel(
-    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch,
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch, int append,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
     uint32_t *__restrict__ eod_counts) {
   extern __shared__ float4 lds[];
@@ -605,46 +606,67 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
     }
     const uint32_t sub_row = lane >> 2, chunk = lane & 3;
     const uint32_t rows_here = P.n_streams - blockIdx.x * 64u < 64u ? P.n_streams - blockIdx.x * 64u : 64u;
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        samples + (size_t)blockIdx.x * 64u * pitch, 0, (int)(uint32_t)(rows_here * pitch * 4u), 0x00020000);
+    v4i in_rsrc;
+    {
+      const uint64_t base = reinterpret_cast<uint64_t>(samples + (size_t)blockIdx.x * 64u * pitch);
+      in_rsrc.x = (int)(uint32_t)base;
+      in_rsrc.y = (int)(uint32_t)(base >> 32);
+      in_rsrc.z = (int)(uint32_t)(rows_here * pitch * 4u);
+      in_rsrc.w = 0x00020000;
+    }
     const uint32_t in_voff = (uint32_t)((sub_row * pitch + 4u * chunk) * 4u);
     const uint32_t in_row16 = (uint32_t)(16u * pitch * 4u);
     const uint32_t st_slot = chunk * kSlotStride + sub_row;
-    // three tiles in flight (rows beyond the batch read as 0: the row step rides in the bounds-checked VGPR offset)
+    // Three tiles in flight, in three register sets used in turn (the loop is unrolled by three so that no set is ever
+    // copied).  The loads are inline asm with hand-counted waits, as in demod_fused_kernel: vmcnt counts in issue order
+    // and hipcc, which cannot see across the loop's back edge, would drain everything (vmcnt(0)) at the top of every
+    // iteration.  When a set is staged, the two sets issued after it (8 loads) may still be in flight, plus this wave's
+    // write-back stores of the two tiles in between (4 each) in the write-back variant.
+    // (rows beyond the batch read as 0: the row step rides in the bounds-checked VGPR offset)
+#define PIPE_BLOAD4(dst, rows16, soff)                                                                      \
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(in_voff + (rows16) * in_row16), \
+               "s"(in_rsrc), "s"(soff) : "memory")
     auto load_tile = [&](size_t t, v4f &a, v4f &b, v4f &c, v4f &d) {
       const uint32_t tn = (uint32_t)((t < n_tiles ? t : n_tiles - 1) * kFastTile * 4u);
-      a = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff, tn, 0));
-      b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff + in_row16, tn, 0));
-      c = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff + 2u * in_row16, tn, 0));
-      d = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_voff + 3u * in_row16, tn, 0));
+      PIPE_BLOAD4(a, 0u, tn); PIPE_BLOAD4(b, 1u, tn); PIPE_BLOAD4(c, 2u, tn); PIPE_BLOAD4(d, 3u, tn);
     };
     v4f a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the state loads above are complete, the count starts clean
     load_tile(0, a0, a1, a2, a3);
     load_tile(1, b0, b1, b2, b3);
     load_tile(2, c0, c1, c2, c3);
+    // the loop may receive the three sets in other registers than these loads were issued into: any such copy must see
+    // landed data (inside the loop tools/check_isa.py proves that nothing touches a set between issue and its wait)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+                 "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
     // NCO phasors (uniform configuration): lane j & 15 evaluates sample j of the tile from the exact accumulator, the
     // sixteen (cos, sin) pairs are parked in LDS and read back as broadcasts
-    const uint64_t zoff = inc * (uint64_t)(lane & 15u);
-    uint32_t consumed = 0;
-    for (size_t t = 0; t < n_tiles; t++) {
+    uint64_t zacc = free0 + inc * (uint64_t)(lane & 15u);     // this lane's sample of the current tile (UNI)
+    uint64_t tacc = free0;                                     // first sample of the current tile (per-stream tones)
+    const uint64_t inc16 = inc * 16u;
+    uint32_t consumed = 0, slot_i = 0;
+    auto do_tile = [&](uint32_t t, v4f &r0, v4f &r1, v4f &r2, v4f &r3) {
       while (t - consumed >= kPipeSlots) {                  // ring full: wait for the back wave
         consumed = lds_peek(&ctr[1]);
         if (t - consumed >= kPipeSlots) __builtin_amdgcn_s_sleep(1);
       }
-      stage[st_slot] = a0; stage[st_slot + 16] = a1; stage[st_slot + 32] = a2; stage[st_slot + 48] = a3;
-      a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-      b0 = c0; b1 = c1; b2 = c2; b3 = c3;
-      const v4f *ztile = zt + (t & 1) * 8u;
+      if (WB) asm volatile("s_waitcnt vmcnt(16)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+      stage[st_slot] = r0; stage[st_slot + 16] = r1; stage[st_slot + 32] = r2; stage[st_slot + 48] = r3;
+      load_tile((size_t)t + 3, r0, r1, r2, r3);
+      const v4f *ztile = zt + (t & 1u) * 8u;
       float zr = 1.f, zi = 0.f;
       if (UNI) {
         float pc, ps;
-        nco_phasor(free0 + inc * (uint64_t)(t * kFastTile) + zoff, pc, ps);
-        reinterpret_cast<f2 *>(zt + (t & 1) * 8u)[lane & 15u] = (f2){pc, ps};
+        nco_phasor(zacc, pc, ps);
+        reinterpret_cast<f2 *>(zt + (t & 1u) * 8u)[lane & 15u] = (f2){pc, ps};
+        zacc += inc16;
       } else {
-        nco_phasor(free0 + inc * (uint64_t)(t * kFastTile), zr, zi);
+        nco_phasor(tacc, zr, zi);
+        tacc += inc16;
       }
-      load_tile(t + 3, c0, c1, c2, c3);
-      v4f *slot = ring + (uint32_t)(t % kPipeSlots) * kSlotV4;
+      v4f *slot = ring + slot_i * kSlotV4;
+      slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
 #pragma unroll 1
       for (uint32_t c = 0; c < 4; c++) {
         const v4f x4 = stage[c * kSlotStride + lane];       // written by this wave: a wave's ds ops are ordered
@@ -669,15 +691,25 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
         slot[(4u + c) * 64u + lane] = (v4f){oi[0] + oi[1], oq[0] + oq[1], oi[2] + oi[3], oq[2] + oq[3]};
         if (WB) {
           if (C.valid)
-            *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + t * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
+            *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + (size_t)t * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
         }
       }
-      lds_post(&ctr[0], (uint32_t)t + 1u);                  // this wave's ring writes are done (lgkmcnt(0) inside)
+      lds_post(&ctr[0], t + 1u);                            // this wave's ring writes are done (lgkmcnt(0) inside)
+    };
+    const uint32_t nt = (uint32_t)n_tiles;
+    for (uint32_t t = 0; t < nt; t += 3) {
+      do_tile(t, a0, a1, a2, a3);
+      if (t + 1 < nt) do_tile(t + 1, b0, b1, b2, b3);
+      if (t + 2 < nt) do_tile(t + 2, c0, c1, c2, c3);
     }
+    // the last prefetches are still in flight and their registers are dead to the compiler: keep them until they land
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+                 "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
+#undef PIPE_BLOAD4
     // hand the final I/Q filter state to the back wave, which owns the epilogue
     fin[lane] = (v4f){F.ix1, F.ix2, F.iy, F.iv};
     fin[64u + lane] = (v4f){F.qx1, F.qx2, F.qy, F.qv};
-    lds_post(&ctr[0], (uint32_t)n_tiles + 1u);
+    lds_post(&ctr[0], nt + 1u);
     {
       const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
       const FastMem &M = C.M;
@@ -689,7 +721,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
     // ---------------------------------------------------------------------------------------------- back
     BackLane B;
     BackK K;
-    back_load<UNI>(B, K, P, S, C, stream, eod_counts);
+    back_load<UNI>(B, K, P, S, C, stream, out_counts, eod_counts, append);
     const FastMem &M = C.M;
     const uint32_t fld = C.fld, row4 = C.row4;
     for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
@@ -703,13 +735,15 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
     X.amp_soff = amp_pos0 * amp_row_bytes;
     const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
     const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
-    uint32_t produced = 0;
-    for (size_t t = 0; t < n_tiles; t++) {
+    uint32_t produced = 0, slot_i = 0;
+    const uint32_t nt = (uint32_t)n_tiles;
+    for (uint32_t t = 0; t < nt; t++) {
       while (produced <= t) {
         produced = lds_peek(&ctr[0]);
         if (produced <= t) __builtin_amdgcn_s_sleep(1);
       }
-      const v4f *slot = ring + (uint32_t)(t % kPipeSlots) * kSlotV4;
+      const v4f *slot = ring + slot_i * kSlotV4;
+      slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
 #pragma unroll 1
       for (uint32_t c = 0; c < 4; c++) {
         const v4f u4 = slot[(4u + c) * 64u + lane];
@@ -729,11 +763,11 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
         }
         X.phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
       }
-      lds_post(&ctr[1], (uint32_t)t + 1u);                  // slot free (this wave's reads of it are complete)
+      lds_post(&ctr[1], t + 1u);                            // slot free (this wave's reads of it are complete)
     }
-    while (produced <= n_tiles) {
+    while (produced <= nt) {
       produced = lds_peek(&ctr[0]);
-      if (produced <= n_tiles) __builtin_amdgcn_s_sleep(1);
+      if (produced <= nt) __builtin_amdgcn_s_sleep(1);
     }
     FrontLane F;
     {
@@ -753,7 +787,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
 // ================================================================================================================
 template <bool WB, bool UNI>
 __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
-    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch,
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch, int append,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
     uint32_t *__restrict__ eod_counts) {
   extern __shared__ float4 lds[];
@@ -774,7 +808,7 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
   front_load<UNI>(F, FK, P, S, C);
   BackLane B;
   BackK BK;
-  back_load<UNI>(B, BK, P, S, C, stream, eod_counts);
+  back_load<UNI>(B, BK, P, S, C, stream, out_counts, eod_counts, append);
   float wre = 1.f, wim = 0.f;
   if (!UNI) {
     const __amdgpu_buffer_rsrc_t cf_rsrc = C.cf_rsrc;
@@ -890,6 +924,84 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
   pipe_store<UNI>(F, true, B, P, C, stream, out_counts, n, X.k, X.kappa, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
 }
 
+// ================================================================================================================
+// The same arithmetic one sample at a time, for what is not whole 16-sample tiles of a lock-step batch: the odd sample
+// that completes a decimator pair left open by the previous call, the samples up to the next 16-byte boundary, the
+// tail of a call, buffers without 16-byte alignment.  One wave per 64-stream group, strided loads -- slow, but a
+// stream cut into calls of ANY lengths then computes bit for bit what one call computes (the reference is a streaming
+// state machine: fsk-demodulation.node.test.ts:363-398, 668-753), with the generic kernel left to the fp64 path, wide
+// or fractional rings, traces and batches that are not in lock step.
+// parity0: downsample.counter at the first sample (fsk.ts:106); the open pair's first low-pass outputs are acc_i / acc_q.
+// LDS: poly [d][64] u32
+// ================================================================================================================
+template <bool WB, bool UNI>
+__global__ __launch_bounds__(64, 2) void demod_tail_kernel(
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch, int parity0, int append,
+    uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
+    uint32_t *__restrict__ eod_counts) {
+  extern __shared__ float4 lds[];
+  uint32_t *poly = reinterpret_cast<uint32_t *>(lds);
+  uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t stream = blockIdx.x * 64u + lane;
+  const PipeCtx C = pipe_ctx(P, S, stream);
+  const FastMem &M = C.M;
+  const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
+  const uint32_t fld = C.fld, row4 = C.row4;
+  const uint64_t inc = UNI ? (((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo) : S.nco_inc[C.row4 >> 2];
+  const uint64_t free0 = pipe_free0<UNI>(C);
+
+  FrontLane F;
+  FrontK FK;
+  front_load<UNI>(F, FK, P, S, C);
+  BackLane B;
+  BackK BK;
+  back_load<UNI>(B, BK, P, S, C, stream, out_counts, eod_counts, append);
+  for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
+  BackU X;
+  X.k = 0; X.kappa = 0; X.kv = 0;
+  X.free0 = free0 - (parity0 ? inc : 0ull);             // decimated sample 0 of this launch starts one sample early then
+  X.direct = __builtin_amdgcn_ballot_w64(B.dph < 2u) ? 2u : 0u;
+  asm volatile("" : "+v"(X.kv));
+  X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
+  const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
+  const uint32_t amp_row_bytes = P.n_streams * 4u;
+  X.amp_soff = amp_pos0 * amp_row_bytes;
+  const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
+  const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
+  float acc_i = parity0 ? PIPE_RLOAD(acc_i) : 0.f, acc_q = parity0 ? PIPE_RLOAD(acc_q) : 0.f;
+  float *xrow = samples + (size_t)(C.row4 >> 2) * pitch;
+
+  uint32_t par = (uint32_t)parity0;
+  for (size_t t = 0; t < n; t++) {
+    const float xin = C.valid ? xrow[t] : 0.f;
+    float zc, zs, xs, y, oi, oq;
+    nco_phasor(free0 + inc * (uint64_t)t, zc, zs);
+    front_sample(F, FK, xin, zc, zs, xs, y, oi, oq);
+    if (WB) { if (C.valid) xrow[t] = xs; }
+    if (par == 0) {
+      acc_i = oi; acc_q = oq;
+      par = 1;
+    } else {
+      par = 0;
+      X.k++;
+      X.kv += 1u;
+      X.kappa = (X.kappa + 1 == P.cadence) ? 0u : X.kappa + 1;
+      const uint32_t r_old = poly[X.phase * 64u + lane];
+      const float ypr[2] = {F.by2, F.by1};               // the pair's two pre-filter outputs
+      back_pair<UNI>(B, BK, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, acc_i + oi, acc_q + oq,
+                     ypr, r_old, inc);
+      X.amp_soff += amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
+      X.phase = (X.phase + 1 == P.d) ? 0u : X.phase + 1;
+      acc_i = 0.f; acc_q = 0.f;
+    }
+  }
+  for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
+  pipe_store<UNI>(F, true, B, P, C, stream, out_counts, n, X.k, X.kappa, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
+  PIPE_RSTORE(acc_i, acc_i); PIPE_RSTORE(acc_q, acc_q);
+  PIPE_ISTORE(ds_cnt, par);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 size_t demod_pipe_lds_bytes(const DemodParams &P) {
   return sizeof(float4) * (4 * kSlotStride + kPipeSlots * kSlotV4 + 2 * 64 + 2 * 8) + sizeof(uint32_t) * (64u * P.d + 4u);
@@ -907,14 +1019,14 @@ hipError_t set_pipe_lds_limit(size_t pipe_bytes) {
   return e;
 }
 
-hipError_t launch_demod_pipe(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+hipError_t launch_demod_pipe(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream) {
   const uint32_t blocks = (P.n_streams + 63u) / 64u;
   const size_t lds = demod_pipe_lds_bytes(P);
 #define FSK_LAUNCH_PIPE(WBV, UNIV)                                                                          \
   hipLaunchKernelGGL((demod_pipe_kernel<WBV, UNIV>), dim3(blocks), dim3(128), lds, stream, P, S, samples, n, pitch, \
-                     out, out_pitch, out_counts, eod_counts)
+                     append ? 1 : 0, out, out_pitch, out_counts, eod_counts)
   const bool uni = P.uni_cfg != 0;
   if (writeback) { if (uni) FSK_LAUNCH_PIPE(true, true); else FSK_LAUNCH_PIPE(true, false); }
   else { if (uni) FSK_LAUNCH_PIPE(false, true); else FSK_LAUNCH_PIPE(false, false); }
@@ -922,18 +1034,33 @@ hipError_t launch_demod_pipe(bool writeback, const DemodParams &P, const DemodSt
   return hipGetLastError();
 }
 
-hipError_t launch_demod_fused(bool writeback, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+hipError_t launch_demod_fused(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                               size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                               uint32_t *eod_counts, hipStream_t stream) {
   const uint32_t blocks = (P.n_streams + 63u) / 64u;
   const size_t lds = demod_fused_lds_bytes(P);
 #define FSK_LAUNCH_FUSED(WBV, UNIV)                                                                          \
   hipLaunchKernelGGL((demod_fused_kernel<WBV, UNIV>), dim3(blocks), dim3(64), lds, stream, P, S, samples, n, pitch, \
-                     out, out_pitch, out_counts, eod_counts)
+                     append ? 1 : 0, out, out_pitch, out_counts, eod_counts)
   const bool uni = P.uni_cfg != 0;
   if (writeback) { if (uni) FSK_LAUNCH_FUSED(true, true); else FSK_LAUNCH_FUSED(true, false); }
   else { if (uni) FSK_LAUNCH_FUSED(false, true); else FSK_LAUNCH_FUSED(false, false); }
 #undef FSK_LAUNCH_FUSED
+  return hipGetLastError();
+}
+
+hipError_t launch_demod_tail(bool writeback, bool append, int parity0, const DemodParams &P, const DemodState &S,
+                             float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
+                             uint32_t *eod_counts, hipStream_t stream) {
+  const uint32_t blocks = (P.n_streams + 63u) / 64u;
+  const size_t lds = sizeof(uint32_t) * 64u * P.d;
+#define FSK_LAUNCH_TAIL(WBV, UNIV)                                                                          \
+  hipLaunchKernelGGL((demod_tail_kernel<WBV, UNIV>), dim3(blocks), dim3(64), lds, stream, P, S, samples, n, pitch, \
+                     parity0, append ? 1 : 0, out, out_pitch, out_counts, eod_counts)
+  const bool uni = P.uni_cfg != 0;
+  if (writeback) { if (uni) FSK_LAUNCH_TAIL(true, true); else FSK_LAUNCH_TAIL(true, false); }
+  else { if (uni) FSK_LAUNCH_TAIL(false, true); else FSK_LAUNCH_TAIL(false, false); }
+#undef FSK_LAUNCH_TAIL
   return hipGetLastError();
 }
 
