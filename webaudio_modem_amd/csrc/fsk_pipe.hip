@@ -46,8 +46,8 @@
 
 namespace fsk {
 
-static constexpr uint32_t kPipeSlots = 3;          // tiles in the LDS ring between the two waves
-static constexpr uint32_t kSlotV4 = 8 * 64;        // v4f per ring slot: y[16] and U[8 pairs x (I,Q)] per lane
+static constexpr uint32_t kPipeSlots = 4;          // half tiles (8 samples) in the LDS ring between the two waves
+static constexpr uint32_t kSlotV4 = 6 * 64;        // v4f per ring slot and lane: y[8] | U[4 pairs x (I, Q)] | (phase, magnitude)[4 pairs]
 
 // ---- front: everything before the decimator, free-running --------------------------------------------------------
 struct FrontLane {
@@ -61,6 +61,7 @@ struct FrontK {                   // all in VGPRs: an SGPR operand halves a vect
   float g_lo, g_hi;              // 0.1, 10
   float bp_b0, bp_na1, bp_na2;   // pre-filter: y = b0*(x - x2) - a2*y2 - a1*y1
   float lp_a2, lp_nd;            // low-pass a2, -(1 + a1 + a2)
+  float tiny; uint32_t sgn;      // 1e-37f, 0x80000000 (atan2_amp_fma)
 };
 
 // one input sample: returns the AGC'd sample (write-back), the pre-filter output and the I/Q low-pass outputs
@@ -214,11 +215,15 @@ __device__ inline void nco_phasor(uint64_t acc, float &c, float &s) {
 
 // One decimated sample: ZIR correction, discriminator (fsk.ts:245-264), processDownsampledBit (fsk.ts:278-344),
 // processByte (346-375).  ypair: LDS address of this pair's two pre-filter outputs (read by the direct instance only).
-template <bool UNI>
+// PA: the front wave has evaluated the discriminator's phase / magnitude on U already (ph_u, amp_u); they stand unless the
+// correction changed a bit of U in some lane (w == U bit for bit wherever q has decayed below half an ulp of U, i.e. from
+// ~40 decimated samples after a reset on), in which case the wave re-evaluates -- same function, same inputs where
+// nothing changed, so the result does not depend on which wave computed it.
+template <bool UNI, bool PA = false>
 __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams &P, const DemodState &S, const FastMem &M,
                                  uint32_t *poly, uint32_t lane, __amdgpu_buffer_rsrc_t amp_rsrc, uint8_t *out,
                                  uint32_t out_pitch, uint32_t *eod_counts, BackU &X, float Ui, float Uq,
-                                 const float *ypair, uint32_t r_old, uint64_t inc) {
+                                 const float *ypair, uint32_t r_old, uint64_t inc, float ph_u = 0.f, float amp_u = 0.f) {
   // ---- ZIR correction: w = U - q, q advances by its two-term recurrence
   float wi = Ui - B.qai, wq = Uq - B.qaq;
   {
@@ -271,8 +276,15 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
     }
   }
   // ---- discriminator (fsk.ts:251-264)
-  float amp;
-  const float ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
+  float amp, ph;
+  if (PA) {
+    ph = ph_u; amp = amp_u;
+    const uint32_t changed = (__builtin_bit_cast(uint32_t, wi) ^ __builtin_bit_cast(uint32_t, Ui)) |
+                             (__builtin_bit_cast(uint32_t, wq) ^ __builtin_bit_cast(uint32_t, Uq));
+    if (__builtin_amdgcn_ballot_w64(changed != 0u)) ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
+  } else {
+    ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
+  }
   float dphi = ph - B.last_phase;
   {
     // wrap into (-pi, pi] (fsk.ts:255-257): |dphi| < 2 pi, so one rounded quotient does both branches; rounding to
@@ -451,6 +463,8 @@ __device__ inline void front_load(FrontLane &F, FrontK &K, const DemodParams &P,
     K.bp_na1 = -(float)PIPE_CLOAD(CF_bp_a1); K.bp_na2 = -(float)PIPE_CLOAD(CF_bp_a2);
   }
   K.lp_a2 = P.f_lp_a2; K.lp_nd = -P.f_lp_delta;
+  K.tiny = 1.0e-37f; K.sgn = 0x80000000u;
+  asm volatile("" : "+v"(K.tiny), "+v"(K.sgn));
   asm volatile("" : "+v"(K.att_m_rel), "+v"(K.rel), "+v"(K.step_k), "+v"(K.step_b), "+v"(K.g_lo), "+v"(K.g_hi));
   asm volatile("" : "+v"(K.bp_b0), "+v"(K.bp_na1), "+v"(K.bp_na2), "+v"(K.lp_a2), "+v"(K.lp_nd));
 }
@@ -565,7 +579,7 @@ __device__ inline void lds_post(uint32_t *p, uint32_t v) {
 
 // ================================================================================================================
 // Two waves per 64-stream group.
-// LDS: stage [4][65] v4f | ring [kPipeSlots][8][64] v4f | fin [2][64] v4f | zt [2][8] v4f | poly [d][64] u32 | counters
+// LDS: stage [4][65] v4f | ring [kPipeSlots][6][64] v4f | fin [2][64] v4f | zt [2][8] v4f | poly [d][64] u32 | counters
 // ================================================================================================================
 template <bool WB, bool UNI>
 __global__ __launch_bounds__(128) void demod_pipe_kernel(
@@ -646,10 +660,6 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
     const uint64_t inc16 = inc * 16u;
     uint32_t consumed = 0, slot_i = 0;
     auto do_tile = [&](uint32_t t, v4f &r0, v4f &r1, v4f &r2, v4f &r3) {
-      while (t - consumed >= kPipeSlots) {                  // ring full: wait for the back wave
-        consumed = lds_peek(&ctr[1]);
-        if (t - consumed >= kPipeSlots) __builtin_amdgcn_s_sleep(1);
-      }
       if (WB) asm volatile("s_waitcnt vmcnt(16)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
       else asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
       stage[st_slot] = r0; stage[st_slot + 16] = r1; stage[st_slot + 32] = r2; stage[st_slot + 48] = r3;
@@ -665,36 +675,51 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
         nco_phasor(tacc, zr, zi);
         tacc += inc16;
       }
-      v4f *slot = ring + slot_i * kSlotV4;
-      slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
 #pragma unroll 1
-      for (uint32_t c = 0; c < 4; c++) {
-        const v4f x4 = stage[c * kSlotStride + lane];       // written by this wave: a wave's ds ops are ordered
-        float zc[4], zs[4];
-        if (UNI) {
-          const v4f z01 = ztile[c * 2u], z23 = ztile[c * 2u + 1u];   // same address in every lane: LDS broadcast
-          zc[0] = z01.x; zs[0] = z01.y; zc[1] = z01.z; zs[1] = z01.w;
-          zc[2] = z23.x; zs[2] = z23.y; zc[3] = z23.z; zs[3] = z23.w;
-        } else {
+      for (uint32_t hf = 0; hf < 2; hf++) {
+        const uint32_t hidx = 2u * t + hf;                  // half tiles produced so far
+        while (hidx - consumed >= kPipeSlots) {             // ring full: wait for the back wave
+          consumed = lds_peek(&ctr[1]);
+          if (hidx - consumed >= kPipeSlots) __builtin_amdgcn_s_sleep(1);
+        }
+        v4f *slot = ring + slot_i * kSlotV4;
+        slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
+#pragma unroll 1
+        for (uint32_t cc = 0; cc < 2; cc++) {
+          const uint32_t c = 2u * hf + cc;
+          const v4f x4 = stage[c * kSlotStride + lane];     // written by this wave: a wave's ds ops are ordered
+          float zc[4], zs[4];
+          if (UNI) {
+            const v4f z01 = ztile[c * 2u], z23 = ztile[c * 2u + 1u];   // same address in every lane: LDS broadcast
+            zc[0] = z01.x; zs[0] = z01.y; zc[1] = z01.z; zs[1] = z01.w;
+            zc[2] = z23.x; zs[2] = z23.y; zc[3] = z23.z; zs[3] = z23.w;
+          } else {
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            zc[j] = zr; zs[j] = zi;
-            const float nr = __builtin_fmaf(-zi, wim, zr * wre), ni = __builtin_fmaf(zi, wre, zr * wim);
-            zr = nr; zi = ni;
+            for (int j = 0; j < 4; j++) {
+              zc[j] = zr; zs[j] = zi;
+              const float nr = __builtin_fmaf(-zi, wim, zr * wre), ni = __builtin_fmaf(zi, wre, zr * wim);
+              zr = nr; zi = ni;
+            }
+          }
+          const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
+          float xs[4], y[4], oi[4], oq[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) front_sample(F, K, xin[j], zc[j], zs[j], xs[j], y[j], oi[j], oq[j]);
+          const float u0i = oi[0] + oi[1], u0q = oq[0] + oq[1], u1i = oi[2] + oi[3], u1q = oq[2] + oq[3];
+          // the discriminator's phase / magnitude of the uncorrected pair sums, speculatively (see back_pair)
+          float am0, am1;
+          const float p0 = atan2_amp_fma(u0q, u0i, am0, K.tiny, K.sgn);
+          const float p1 = atan2_amp_fma(u1q, u1i, am1, K.tiny, K.sgn);
+          slot[cc * 64u + lane] = (v4f){y[0], y[1], y[2], y[3]};
+          slot[(2u + cc) * 64u + lane] = (v4f){u0i, u0q, u1i, u1q};
+          slot[(4u + cc) * 64u + lane] = (v4f){p0, am0, p1, am1};
+          if (WB) {
+            if (C.valid)
+              *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + (size_t)t * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
           }
         }
-        const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
-        float xs[4], y[4], oi[4], oq[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) front_sample(F, K, xin[j], zc[j], zs[j], xs[j], y[j], oi[j], oq[j]);
-        slot[c * 64u + lane] = (v4f){y[0], y[1], y[2], y[3]};
-        slot[(4u + c) * 64u + lane] = (v4f){oi[0] + oi[1], oq[0] + oq[1], oi[2] + oi[3], oq[2] + oq[3]};
-        if (WB) {
-          if (C.valid)
-            *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + (size_t)t * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
-        }
+        lds_post(&ctr[0], hidx + 1u);                       // this wave's ring writes are done (lgkmcnt(0) inside)
       }
-      lds_post(&ctr[0], t + 1u);                            // this wave's ring writes are done (lgkmcnt(0) inside)
     };
     const uint32_t nt = (uint32_t)n_tiles;
     for (uint32_t t = 0; t < nt; t += 3) {
@@ -709,7 +734,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
     // hand the final I/Q filter state to the back wave, which owns the epilogue
     fin[lane] = (v4f){F.ix1, F.ix2, F.iy, F.iv};
     fin[64u + lane] = (v4f){F.qx1, F.qx2, F.qy, F.qv};
-    lds_post(&ctr[0], nt + 1u);
+    lds_post(&ctr[0], 2u * nt + 1u);
     {
       const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
       const FastMem &M = C.M;
@@ -736,8 +761,8 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
     const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
     const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
     uint32_t produced = 0, slot_i = 0;
-    const uint32_t nt = (uint32_t)n_tiles;
-    for (uint32_t t = 0; t < nt; t++) {
+    const uint32_t nh = 2u * (uint32_t)n_tiles;             // half tiles
+    for (uint32_t t = 0; t < nh; t++) {
       while (produced <= t) {
         produced = lds_peek(&ctr[0]);
         if (produced <= t) __builtin_amdgcn_s_sleep(1);
@@ -745,8 +770,9 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
       const v4f *slot = ring + slot_i * kSlotV4;
       slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
 #pragma unroll 1
-      for (uint32_t c = 0; c < 4; c++) {
-        const v4f u4 = slot[(4u + c) * 64u + lane];
+      for (uint32_t c = 0; c < 2; c++) {
+        const v4f u4 = slot[(2u + c) * 64u + lane];
+        const v4f pa = slot[(4u + c) * 64u + lane];
         const uint32_t ph0 = X.phase, ph1 = (X.phase + 1 == P.d) ? 0u : X.phase + 1;
         const uint32_t r0 = poly[ph0 * 64u + lane];
         const uint32_t r1 = poly[ph1 * 64u + lane];
@@ -757,17 +783,17 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
           X.kv += 1u;
           X.kappa = (X.kappa + 1 == P.cadence) ? 0u : X.kappa + 1;
           X.phase = h ? ph1 : ph0;
-          back_pair<UNI>(B, K, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, h ? u4.z : u4.x,
-                         h ? u4.w : u4.y, yp + 2 * h, h ? r1 : r0, inc);
+          back_pair<UNI, true>(B, K, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, h ? u4.z : u4.x,
+                               h ? u4.w : u4.y, yp + 2 * h, h ? r1 : r0, inc, h ? pa.z : pa.x, h ? pa.w : pa.y);
           X.amp_soff += amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
         }
         X.phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
       }
       lds_post(&ctr[1], t + 1u);                            // slot free (this wave's reads of it are complete)
     }
-    while (produced <= nt) {
+    while (produced <= nh) {
       produced = lds_peek(&ctr[0]);
-      if (produced <= nt) __builtin_amdgcn_s_sleep(1);
+      if (produced <= nh) __builtin_amdgcn_s_sleep(1);
     }
     FrontLane F;
     {
