@@ -47,6 +47,7 @@
 namespace fsk {
 
 static constexpr uint32_t kPipeSlots = 4;          // half tiles (8 samples) in the LDS ring between the two waves
+static constexpr uint32_t kStartedP = 0x7FFFFFFFu;  // thr_eff while a frame is started, in these kernels: matched - thr_eff stays negative
 static constexpr uint32_t kSlotV4 = 6 * 64;        // v4f per ring slot and lane: y[8] | U[4 pairs x (I, Q)] | (phase, magnitude)[4 pairs]
 
 // ---- front: everything before the decimator, free-running --------------------------------------------------------
@@ -153,7 +154,7 @@ struct BackLane {
   uint32_t dph;
   float dix1, dix2, diy, dvi, dqx1, dqx2, dqy, dqv, q0i, q0q;
   // frame state machine, as absolute push counts of this launch (k = pushes so far, wave-uniform):
-  uint32_t matched, thr_eff;     // sync correlator count; matched_min while searching, kStarted while a frame is started
+  uint32_t matched, thr_eff;     // sync correlator count; matched_min while searching, kStartedP while a frame is started
   uint32_t rho;                  // globalSampleCounter % cadence == 0  <=>  k % cadence == rho
   uint32_t ls;                   // silence.sampleCount = k - ls
   uint32_t acc, T, tlast;        // bit vote; nextBitSampleIndex - bitSampleCounter = T - k; bitAccumCount = k - tlast
@@ -173,10 +174,10 @@ struct BackK {                    // VGPRs, like FrontK
 struct BackU {                   // wave-uniform context of one decimated sample
   uint32_t k;                    // pushes of this launch including this one
   uint32_t kv;                   // the same in a VGPR (operand of the per-lane selects and differences)
-  uint32_t kappa;                // k % cadence
   uint32_t phase;                // polyphase slot of this push
   uint32_t amp_soff;             // byte offset of the amplitude-ring row
   uint32_t direct;               // decimated samples for which some lane still runs the direct instance (after a reset)
+  uint32_t zlive;                // some lane carries a non-zero correction (or runs the direct instance)
   uint64_t free0;                // free-running frame: NCO phase (turns * 2^64) at the first sample of the launch
 };
 
@@ -199,11 +200,11 @@ __device__ inline void back_reset(BackLane &B, const DemodParams &P, const FastM
   B.dqx1 = B.dqx2 = B.dqy = B.dqv = 0.f;
   B.px1 = B.px2 = B.py = B.pv = 0.f;
   ist_store(M, IF_gsc, 0u - X.k);
-  B.rho = X.kappa;
+  B.rho = X.k % P.cadence;
   B.ls = X.k;
   B.acc = 0; B.T = X.k + kBigWait; B.tlast = B.T;
   B.sreg = 1u;
-  B.thr_eff = M.voff < 0xFFFFFFF0u ? P.matched_min : 0xFFFFFFFEu;  // lanes beyond the batch stay parked
+  B.thr_eff = M.voff < 0xFFFFFFF0u ? P.matched_min : 0x7FFFFFFEu;  // lanes beyond the batch stay parked
 }
 
 // e^{j 2 pi acc / 2^64}: the hardware's sin/cos take turns
@@ -224,67 +225,81 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
                                  uint32_t *poly, uint32_t lane, __amdgpu_buffer_rsrc_t amp_rsrc, uint8_t *out,
                                  uint32_t out_pitch, uint32_t *eod_counts, BackU &X, float Ui, float Uq,
                                  const float *ypair, uint32_t r_old, uint64_t inc, float ph_u = 0.f, float amp_u = 0.f) {
-  // ---- ZIR correction: w = U - q, q advances by its two-term recurrence
-  float wi = Ui - B.qai, wq = Uq - B.qaq;
-  {
-    const float ni = __builtin_fmaf(K.c1, B.qbi, -(K.c2 * B.qai));
-    const float nq = __builtin_fmaf(K.c1, B.qbq, -(K.c2 * B.qaq));
-    B.qai = B.qbi; B.qaq = B.qbq; B.qbi = ni; B.qbq = nq;
-  }
-  // (opaque: otherwise hipcc sinks this straight-line code into the else side of the rare branch below)
-  asm volatile("" : "+v"(wi), "+v"(wq), "+v"(B.qai), "+v"(B.qaq), "+v"(B.qbi), "+v"(B.qbq));
-  // ---- rare: the two pairs after a reset come from the zero-started instance, which also yields q's start values
-  if (X.direct) {
-    X.direct--;
-    if (B.dph < 2u) {
-      const float y0 = ypair[0], y1 = ypair[1];
-      const uint32_t n0 = 2u * (X.k - 1u);
-      // the front's phasors of these two samples, evaluated the same way (nco_phasor)
-      float c0, s0, c1, s1;
-      nco_phasor(X.free0 + inc * (uint64_t)n0, c0, s0);
-      nco_phasor(X.free0 + inc * (uint64_t)(n0 + 1u), c1, s1);
-      float di, dq;
-      {
-        const float mi = y0 * c0, mq = y0 * s0;
-        const float ti = __builtin_fmaf(2.0f, B.dix1, mi) + B.dix2, tq = __builtin_fmaf(2.0f, B.dqx1, mq) + B.dqx2;
-        B.dvi = __builtin_fmaf(K.lp_a2, B.dvi, __builtin_fmaf(K.lp_nd, B.diy, ti));
-        B.dqv = __builtin_fmaf(K.lp_a2, B.dqv, __builtin_fmaf(K.lp_nd, B.dqy, tq));
-        B.diy += B.dvi; B.dqy += B.dqv;
-        B.dix2 = B.dix1; B.dix1 = mi; B.dqx2 = B.dqx1; B.dqx1 = mq;
-        di = B.diy; dq = B.dqy;
-      }
-      {
-        const float mi = y1 * c1, mq = y1 * s1;
-        const float ti = __builtin_fmaf(2.0f, B.dix1, mi) + B.dix2, tq = __builtin_fmaf(2.0f, B.dqx1, mq) + B.dqx2;
-        B.dvi = __builtin_fmaf(K.lp_a2, B.dvi, __builtin_fmaf(K.lp_nd, B.diy, ti));
-        B.dqv = __builtin_fmaf(K.lp_a2, B.dqv, __builtin_fmaf(K.lp_nd, B.dqy, tq));
-        B.diy += B.dvi; B.dqy += B.dqv;
-        B.dix2 = B.dix1; B.dix1 = mi; B.dqx2 = B.dqx1; B.dqx1 = mq;
-        di += B.diy; dq += B.dqy;
-      }
-      wi = di; wq = dq;
-      if (B.dph == 0u) {
-        B.q0i = Ui - di; B.q0q = Uq - dq;
-      } else {
-        const float q1i = Ui - di, q1q = Uq - dq;
-        B.qai = __builtin_fmaf(K.c1, q1i, -(K.c2 * B.q0i));
-        B.qaq = __builtin_fmaf(K.c1, q1q, -(K.c2 * B.q0q));
-        B.qbi = __builtin_fmaf(K.c1, B.qai, -(K.c2 * q1i));
-        B.qbq = __builtin_fmaf(K.c1, B.qaq, -(K.c2 * q1q));
-      }
-      B.dph += 1u;
-    }
-  }
-  // ---- discriminator (fsk.ts:251-264)
+  // ---- ZIR correction: w = U - q, q advances by its two-term recurrence.  Skipped (exactly: U - 0 = U) while no lane of
+  // the wave carries a correction; a correction whose four values are all below 1e-20 is retired to exactly zero (a rule
+  // of the stream's own history only, so every kernel and every chunking retires it at the same decimated sample).
+  float wi = Ui, wq = Uq;
   float amp, ph;
-  if (PA) {
+  if (X.zlive) {
+    wi = Ui - B.qai; wq = Uq - B.qaq;
+    {
+      const float ni = __builtin_fmaf(K.c1, B.qbi, -(K.c2 * B.qai));
+      const float nq = __builtin_fmaf(K.c1, B.qbq, -(K.c2 * B.qaq));
+      B.qai = B.qbi; B.qaq = B.qbq; B.qbi = ni; B.qbq = nq;
+    }
+    // ---- rare: the two pairs after a reset come from the zero-started instance, which also yields q's start values
+    if (X.direct) {
+      X.direct--;
+      if (B.dph < 2u) {
+        const float y0 = ypair[0], y1 = ypair[1];
+        const uint32_t n0 = 2u * (X.k - 1u);
+        // the front's phasors of these two samples, evaluated the same way (nco_phasor)
+        float c0, s0, c1, s1;
+        nco_phasor(X.free0 + inc * (uint64_t)n0, c0, s0);
+        nco_phasor(X.free0 + inc * (uint64_t)(n0 + 1u), c1, s1);
+        float di, dq;
+        {
+          const float mi = y0 * c0, mq = y0 * s0;
+          const float ti = __builtin_fmaf(2.0f, B.dix1, mi) + B.dix2, tq = __builtin_fmaf(2.0f, B.dqx1, mq) + B.dqx2;
+          B.dvi = __builtin_fmaf(K.lp_a2, B.dvi, __builtin_fmaf(K.lp_nd, B.diy, ti));
+          B.dqv = __builtin_fmaf(K.lp_a2, B.dqv, __builtin_fmaf(K.lp_nd, B.dqy, tq));
+          B.diy += B.dvi; B.dqy += B.dqv;
+          B.dix2 = B.dix1; B.dix1 = mi; B.dqx2 = B.dqx1; B.dqx1 = mq;
+          di = B.diy; dq = B.dqy;
+        }
+        {
+          const float mi = y1 * c1, mq = y1 * s1;
+          const float ti = __builtin_fmaf(2.0f, B.dix1, mi) + B.dix2, tq = __builtin_fmaf(2.0f, B.dqx1, mq) + B.dqx2;
+          B.dvi = __builtin_fmaf(K.lp_a2, B.dvi, __builtin_fmaf(K.lp_nd, B.diy, ti));
+          B.dqv = __builtin_fmaf(K.lp_a2, B.dqv, __builtin_fmaf(K.lp_nd, B.dqy, tq));
+          B.diy += B.dvi; B.dqy += B.dqv;
+          B.dix2 = B.dix1; B.dix1 = mi; B.dqx2 = B.dqx1; B.dqx1 = mq;
+          di += B.diy; dq += B.dqy;
+        }
+        wi = di; wq = dq;
+        if (B.dph == 0u) {
+          B.q0i = Ui - di; B.q0q = Uq - dq;
+        } else {
+          const float q1i = Ui - di, q1q = Uq - dq;
+          B.qai = __builtin_fmaf(K.c1, q1i, -(K.c2 * B.q0i));
+          B.qaq = __builtin_fmaf(K.c1, q1q, -(K.c2 * B.q0q));
+          B.qbi = __builtin_fmaf(K.c1, B.qai, -(K.c2 * q1i));
+          B.qbq = __builtin_fmaf(K.c1, B.qaq, -(K.c2 * q1q));
+        }
+        B.dph += 1u;
+      }
+    }
+    {
+      const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(B.qai), __builtin_fabsf(B.qaq)),
+                                        __builtin_fmaxf(__builtin_fabsf(B.qbi), __builtin_fabsf(B.qbq)));
+      const bool steady = B.dph >= 2u;
+      if (steady & (big < 1.0e-20f)) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }
+      X.zlive = __builtin_amdgcn_ballot_w64(!steady | (big >= 1.0e-20f)) ? 1u : 0u;
+    }
+    if (PA) {
+      ph = ph_u; amp = amp_u;
+      const uint32_t changed = (__builtin_bit_cast(uint32_t, wi) ^ __builtin_bit_cast(uint32_t, Ui)) |
+                               (__builtin_bit_cast(uint32_t, wq) ^ __builtin_bit_cast(uint32_t, Uq));
+      if (__builtin_amdgcn_ballot_w64(changed != 0u)) ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
+    } else {
+      ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
+    }
+  } else if (PA) {
     ph = ph_u; amp = amp_u;
-    const uint32_t changed = (__builtin_bit_cast(uint32_t, wi) ^ __builtin_bit_cast(uint32_t, Ui)) |
-                             (__builtin_bit_cast(uint32_t, wq) ^ __builtin_bit_cast(uint32_t, Uq));
-    if (__builtin_amdgcn_ballot_w64(changed != 0u)) ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
   } else {
     ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
   }
+  // ---- discriminator (fsk.ts:251-264)
   float dphi = ph - B.last_phase;
   {
     // wrap into (-pi, pi] (fsk.ts:255-257): |dphi| < 2 pi, so one rounded quotient does both branches; rounding to
@@ -313,20 +328,22 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   B.matched += (uint32_t)__builtin_popcount((r ^ qn) & mask);
   B.matched -= (uint32_t)__builtin_popcount((r_old ^ qn) & mask);
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, M.voff, X.amp_soff, 0);  // syncAmplitudeBuffer.put
-  const bool hit = B.rho == X.kappa;                           // globalSampleCounter % round(dsSPB/4) == 0
   {
     const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, amp - B.thr));   // amp < threshold (fsk.ts:285)
     B.ls = (B.ls & silent) | (X.kv & ~silent);                 // silence run = k - ls (fsk.ts:285-295)
   }
   const uint32_t e1 = K.eod_m1 - (X.kv - B.ls);                // negative <=> silence.sampleCount >= samplesForEOD
-  const bool eod = (int32_t)e1 < 0;
   B.acc += bit;                                                // bit clock, ungated
   // nextBitSampleIndex reached (only frames that are started get here: T is parked otherwise), and no 'eod' in this step
   const uint32_t dm = ~(neg_mask(X.kv - B.T) | neg_mask(e1));
-  const bool cand = hit & (B.matched >= B.thr_eff);
+  // one test for both rare events: 'eod', or a sync candidate (matched >= threshold while searching; whether this step
+  // is on the search cadence is only looked at inside)
+  const uint32_t m1 = B.matched - B.thr_eff;                   // >= 0 (as int32) <=> matched >= thr_eff
 
   bool did_reset = false;
-  if (__builtin_amdgcn_ballot_w64(eod) | __builtin_amdgcn_ballot_w64(cand)) {
+  if (__builtin_amdgcn_ballot_w64((int32_t)(e1 | ~m1) < 0)) {
+    const bool eod = (int32_t)e1 < 0;
+    const bool cand = ((int32_t)m1 >= 0) & (B.rho == X.k % P.cadence);   // globalSampleCounter % round(dsSPB/4) == 0
     if (eod) {                                                 // fsk.ts:288-291
       ist_store(M, IF_eod_total, ist_load(M, IF_eod_total) + 1u);
       if (eod_counts && M.voff < 0xFFFFFFF0u) eod_counts[M.voff >> 2] += 1u;
@@ -345,7 +362,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
     uint64_t m = __builtin_amdgcn_ballot_w64(sync_now);
     if (m) {
       if (sync_now) {                                          // fsk.ts:315-319
-        B.thr_eff = kStarted;
+        B.thr_eff = kStartedP;
         B.sreg = 1u;
         B.acc = 0; B.T = X.k; B.tlast = X.k;
         ist_store(M, IF_sync_det, ist_load(M, IF_sync_det) + 1u);
@@ -399,7 +416,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
       did_reset = true;
     }
   }
-  if (__builtin_amdgcn_ballot_w64(did_reset)) X.direct = 2u;
+  if (__builtin_amdgcn_ballot_w64(did_reset)) { X.direct = 2u; X.zlive = 1u; }
 }
 
 // ---- state arrays <-> registers ------------------------------------------------------------------------------
@@ -484,7 +501,7 @@ __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, co
   B.dix1 = PIPE_RLOAD(zd_ix1); B.dix2 = PIPE_RLOAD(zd_ix2); B.diy = PIPE_RLOAD(zd_iy); B.dvi = PIPE_RLOAD(zd_iv);
   B.dqx1 = PIPE_RLOAD(zd_qx1); B.dqx2 = PIPE_RLOAD(zd_qx2); B.dqy = PIPE_RLOAD(zd_qy); B.dqv = PIPE_RLOAD(zd_qv);
   B.matched = PIPE_ILOAD(matched);
-  B.thr_eff = PIPE_ILOAD(started) ? kStarted : P.matched_min;
+  B.thr_eff = PIPE_ILOAD(started) ? kStartedP : P.matched_min;
   {
     const uint32_t cc = PIPE_ILOAD(cad_ctr);
     B.rho = cc ? P.cadence - cc : 0u;
@@ -498,7 +515,7 @@ __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, co
     const uint32_t pos = PIPE_ILOAD(bit_pos), bc = PIPE_ILOAD(byte_cur);
     B.sreg = pos <= 9u ? (1u << pos) | ((bc & 0x1FFu) >> (9u - pos)) : (1u << 10) | ((bc & 0x1FFu) << 1) | (bc >> 31);
   }
-  if (B.thr_eff != kStarted) { B.T = kBigWait; B.tlast = B.T - PIPE_ILOAD(bit_reload); }  // (re)park: decisions imply a started frame
+  if (B.thr_eff != kStartedP) { B.T = kBigWait; B.tlast = B.T - PIPE_ILOAD(bit_reload); }  // (re)park: decisions imply a started frame
   // append: a preceding launch of the same call (head samples up to a pair / 16-byte boundary) has produced output already
   B.out_cnt = (append && C.valid) ? out_counts[stream] : 0u;
   if (!append && C.valid && eod_counts) eod_counts[stream] = 0;  // incremented in memory by the (rare) EOD path
@@ -506,7 +523,7 @@ __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, co
     // Lanes beyond the batch run on zeros with a copy of the last stream's state.  Park them: no sync candidate (a
     // threshold `matched` cannot reach), no silence run (nothing is below a negative threshold), no bit clock -- so
     // they never enter a rare path, where their out-of-range row index would be used as an address.
-    B.thr_eff = 0xFFFFFFFEu; B.thr = -1.0f; B.T = kBigWait; B.tlast = B.T;
+    B.thr_eff = 0x7FFFFFFEu; B.thr = -1.0f; B.T = kBigWait; B.tlast = B.T;
   }
   K.c1 = P.z_c1; K.c2 = P.z_c2;
   K.lp_b0 = P.f_lp_b0; K.lp_a2 = P.f_lp_a2; K.lp_nd = -P.f_lp_delta;
@@ -557,7 +574,7 @@ __device__ inline void pipe_store(const FrontLane &F, bool store_front, const Ba
     const uint32_t bc = pos <= 9u ? (B.sreg & ((1u << pos) - 1u)) << (9u - pos) : ((B.sreg >> 1) & 0x1FFu) | ((B.sreg & 1u) << 31);
     PIPE_ISTORE(byte_cur, bc); PIPE_ISTORE(bit_pos, pos);
   }
-  PIPE_ISTORE(started, B.thr_eff == kStarted ? 1u : 0u); PIPE_ISTORE(matched, B.matched);
+  PIPE_ISTORE(started, B.thr_eff == kStartedP ? 1u : 0u); PIPE_ISTORE(matched, B.matched);
   PIPE_ISTORE(gsc, k + PIPE_ILOAD(gsc));              // the gsc word held the offset during the launch
   const uint32_t rl = PIPE_ILOAD(ring_len) + k, al = PIPE_ILOAD(amp_len) + k;
   PIPE_ISTORE(ring_len, rl < P.ring_cap ? rl : P.ring_cap);
@@ -751,8 +768,10 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
     const uint32_t fld = C.fld, row4 = C.row4;
     for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
     BackU X;
-    X.k = 0; X.kappa = 0; X.kv = 0; X.free0 = free0;
+    X.k = 0; X.kv = 0; X.free0 = free0;
     X.direct = __builtin_amdgcn_ballot_w64(B.dph < 2u) ? 2u : 0u;
+  X.zlive = __builtin_amdgcn_ballot_w64((B.dph < 2u) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
+    X.zlive = __builtin_amdgcn_ballot_w64((B.dph < 2u) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
     asm volatile("" : "+v"(X.kv));
     X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
     const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
@@ -769,7 +788,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
       }
       const v4f *slot = ring + slot_i * kSlotV4;
       slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
-#pragma unroll 1
+#pragma unroll
       for (uint32_t c = 0; c < 2; c++) {
         const v4f u4 = slot[(2u + c) * 64u + lane];
         const v4f pa = slot[(4u + c) * 64u + lane];
@@ -781,7 +800,6 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
         for (int h = 0; h < 2; h++) {
           X.k++;
           X.kv += 1u;
-          X.kappa = (X.kappa + 1 == P.cadence) ? 0u : X.kappa + 1;
           X.phase = h ? ph1 : ph0;
           back_pair<UNI, true>(B, K, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, h ? u4.z : u4.x,
                                h ? u4.w : u4.y, yp + 2 * h, h ? r1 : r0, inc, h ? pa.z : pa.x, h ? pa.w : pa.y);
@@ -803,7 +821,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
       F.g = F.bx1 = F.bx2 = F.by1 = F.by2 = 0.f;
     }
     for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
-    pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.kappa, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
+    pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
   }
 }
 
@@ -842,8 +860,9 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
   }
   for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
   BackU X;
-  X.k = 0; X.kappa = 0; X.kv = 0; X.free0 = free0;
+  X.k = 0; X.kv = 0; X.free0 = free0;
   X.direct = __builtin_amdgcn_ballot_w64(B.dph < 2u) ? 2u : 0u;
+  X.zlive = __builtin_amdgcn_ballot_w64((B.dph < 2u) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
   asm volatile("" : "+v"(X.kv));
   X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
   const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
@@ -929,7 +948,6 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
         front_sample(F, FK, xin[2 * h + 1], zc[2 * h + 1], zs[2 * h + 1], xs[2 * h + 1], y1, oi1, oq1);
         X.k++;
         X.kv += 1u;
-        X.kappa = (X.kappa + 1 == P.cadence) ? 0u : X.kappa + 1;
         X.phase = h ? ph1 : ph0;
         const float ypr[2] = {y0, y1};
         back_pair<UNI>(B, BK, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, oi0 + oi1, oq0 + oq1,
@@ -947,7 +965,7 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre0), "+v"(pre1), "+v"(pre2), "+v"(pre3) : : "memory");
 #undef FSK_BLOAD4
   for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
-  pipe_store<UNI>(F, true, B, P, C, stream, out_counts, n, X.k, X.kappa, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
+  pipe_store<UNI>(F, true, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
 }
 
 // ================================================================================================================
@@ -985,9 +1003,10 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
   back_load<UNI>(B, BK, P, S, C, stream, out_counts, eod_counts, append);
   for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
   BackU X;
-  X.k = 0; X.kappa = 0; X.kv = 0;
+  X.k = 0; X.kv = 0;
   X.free0 = free0 - (parity0 ? inc : 0ull);             // decimated sample 0 of this launch starts one sample early then
   X.direct = __builtin_amdgcn_ballot_w64(B.dph < 2u) ? 2u : 0u;
+  X.zlive = __builtin_amdgcn_ballot_w64((B.dph < 2u) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
   asm volatile("" : "+v"(X.kv));
   X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
   const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
@@ -1012,7 +1031,6 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
       par = 0;
       X.k++;
       X.kv += 1u;
-      X.kappa = (X.kappa + 1 == P.cadence) ? 0u : X.kappa + 1;
       const uint32_t r_old = poly[X.phase * 64u + lane];
       const float ypr[2] = {F.by2, F.by1};               // the pair's two pre-filter outputs
       back_pair<UNI>(B, BK, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, acc_i + oi, acc_q + oq,
@@ -1023,7 +1041,7 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
     }
   }
   for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
-  pipe_store<UNI>(F, true, B, P, C, stream, out_counts, n, X.k, X.kappa, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
+  pipe_store<UNI>(F, true, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
   PIPE_RSTORE(acc_i, acc_i); PIPE_RSTORE(acc_q, acc_q);
   PIPE_ISTORE(ds_cnt, par);
 }
