@@ -8,6 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfskhip.so")
+# measurement builds only (tools/stage_times.py loads the FSK_ABLATE build of the same sources)
+if os.environ.get("FSKHIP_LIB_OVERRIDE"):
+    LIB_PATH = os.environ["FSKHIP_LIB_OVERRIDE"]
 
 MAX_PATTERN_BYTES = 16
 OK = 0
