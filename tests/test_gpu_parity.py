@@ -79,8 +79,9 @@ def test_demod_matches_reference_golden(name, pname, prec, tol, monkeypatch):
 @pytest.mark.parametrize("name", [c["name"] for c in golden().manifest["cases"] if "trace" in c])
 def test_intermediates_match_reference(name, pname, prec, tol):
     """north_star: intermediate I/Q magnitudes within 1e-5 relative of the reference (fp32 path);
-    the fp64 path reproduces them to 1e-12.  Relative to the sample's own magnitude wherever the
-    signal is above 1 % of the stream's peak, relative to that floor below it.  The slicer bits of
+    the fp64 path reproduces them to 1e-12.  Plain relative error wherever the amplitude is above
+    1e-4 of the stream's peak (80 dB down: below that the fp32 filters' own rounding noise, ~1e-7 of
+    the peak, is no longer 1e-5 of the sample), relative to that floor below it.  The slicer bits of
     these fixtures must be identical."""
     g = golden()
     c = g.cases[name]
@@ -93,7 +94,7 @@ def test_intermediates_match_reference(name, pname, prec, tol):
     eng.demodulate_data(x.reshape(1, -1))
     tr = eng.trace_read()
     assert tr["amp"].size == ref_amp.size
-    floor = 0.01 * ref_amp.max()
+    floor = 1.0e-4 * ref_amp.max()
     rel = np.abs(tr["amp"] - ref_amp) / np.maximum(ref_amp, floor)
     assert rel.max() <= tol, rel.max()
     assert np.abs(tr["post_out"] - ref_post).max() <= (1e-9 if prec == 1 else 2e-5)
