@@ -45,7 +45,7 @@ int fskhip_xmodem_serialize_host(int device, const uint8_t *payloads, size_t pay
 enum {
   FSKHIP_XM_NEED_MORE = 0,           /* ran out of bytes between packets (the reference would wait / time out) */
   FSKHIP_XM_EOT = 1,                 /* EOT seen where a packet could start (xmodem.ts:241-244) */
-  FSKHIP_XM_TRUNCATED = 2,           /* ran out of bytes inside a packet; `consumed` points at its SOH */
+  FSKHIP_XM_TRUNCATED = 2,           /* ran out of bytes inside a packet (the reference's waitForBytes times out) */
   FSKHIP_XM_INVALID_SEQUENCE = 3,    /* (seq + nseq) != 255            'Invalid sequence number' xmodem.ts:270-274 */
   FSKHIP_XM_INVALID_CRC = 4,         /* CRC16(payload) != received CRC 'Invalid CRC'             xmodem.ts:287-291 */
   FSKHIP_XM_UNEXPECTED_SEQUENCE = 5  /* neither expected nor previous  'Unexpected sequence number' xmodem.ts:315-319 */
@@ -54,9 +54,11 @@ enum {
 typedef struct fskhip_xmodem_result {
   uint32_t status;         /* FSKHIP_XM_* */
   uint32_t expected_after; /* receive.expectedSequence after the scan (xmodem.ts:303) */
-  uint32_t packets;        /* accepted data packets (statistics.packetsReceived of accepted ones) */
+  uint32_t packets;        /* statistics.packetsReceived: packets with the expected sequence whose payload + CRC arrived
+                              (counted before the CRC check, xmodem.ts:280, so a bad-CRC packet is in it) */
   uint32_t dropped;        /* statistics.packetsDropped increments: bad seq pair / CRC / duplicate / unexpected */
-  uint32_t consumed;       /* bytes of the burst consumed; a later call resumes here */
+  uint32_t consumed;       /* bytes taken out of the receive buffer (xmodem.ts:475-499): everything up to the end of the last
+                              complete step; inside a truncated packet SOH (+ the 3 header bytes once complete) */
   uint32_t data_len;       /* bytes of assembled payload written (true size, even beyond data_pitch) */
   int32_t err_seq;         /* header of the packet that ended the scan with an error / truncation, else -1 */
   int32_t err_len;

@@ -105,10 +105,25 @@ static bool to_config(napi_env env, napi_value obj, fskhip_config *c) {
   return true;
 }
 
+// Engines with a demodulateAsync call in flight on a libuv worker (touched on the JS thread only).  EVERY entry point
+// that takes the engine handle goes through get_engine(), which refuses a busy engine: the worker is inside
+// fskhip_demodulate_host with the engine's staging buffers and host-side counters.  destroy() of a busy engine is
+// deferred until its call completes.
+static std::vector<fskhip_engine *> g_busy;
+static std::vector<fskhip_engine *> g_doomed;
+static bool is_busy(const fskhip_engine *e) {
+  for (const fskhip_engine *b : g_busy)
+    if (b == e) return true;
+  return false;
+}
 static fskhip_engine *get_engine(napi_env env, napi_value v) {
   void *p = nullptr;
   if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
     napi_throw_error(env, nullptr, "FSK modulator not configured");
+    return nullptr;
+  }
+  if (is_busy((fskhip_engine *)p)) {
+    napi_throw_error(env, nullptr, "an asynchronous call is in flight on this engine");
     return nullptr;
   }
   return (fskhip_engine *)p;
@@ -153,7 +168,10 @@ static napi_value Destroy(napi_env env, napi_callback_info info) {
   napi_value argv[1];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   void *p = nullptr;
-  if (argc == 1 && napi_get_value_external(env, argv[0], &p) == napi_ok && p) fskhip_destroy((fskhip_engine *)p);
+  if (argc == 1 && napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+    if (is_busy((fskhip_engine *)p)) g_doomed.push_back((fskhip_engine *)p);   // destroyed by demod_complete
+    else fskhip_destroy((fskhip_engine *)p);
+  }
   return nullptr;
 }
 
@@ -184,7 +202,7 @@ static napi_value Demodulate(napi_env env, napi_callback_info info) {
   napi_get_value_uint32(env, argv[4], &flags);
   const uint32_t S = fskhip_n_streams(e);
   if (pitch < n || (size_t)pitch * (S ? S - 1 : 0) + n > len) { napi_throw_range_error(env, nullptr, "samples too short"); return nullptr; }
-  const size_t out_pitch = n / 32 + 8;  // >= one byte per 9 bit times at >= 4 samples per bit
+  const size_t out_pitch = fskhip_max_bytes(e, n);  // the library's own bound (a byte needs >= 8 bit times of samplesPerBit samples)
   void *out = nullptr, *counts = nullptr, *eod = nullptr;
   napi_value out_v = make_typed(env, napi_uint8_array, out_pitch * S, 1, &out);
   napi_value cnt_v = make_typed(env, napi_uint32_array, S, 4, &counts);
@@ -219,8 +237,6 @@ struct DemodWork {
   int rc = 0;
   std::string err;
 };
-static std::vector<fskhip_engine *> g_busy;  // engines with an async call in flight (JS thread only)
-
 static void demod_execute(napi_env, void *data) {
   DemodWork *w = (DemodWork *)data;
   w->rc = fskhip_demodulate_host(w->e, w->samples, w->n, w->pitch, w->out, w->out_pitch, w->counts, w->eod, w->flags);
@@ -230,6 +246,9 @@ static void demod_complete(napi_env env, napi_status, void *data) {
   DemodWork *w = (DemodWork *)data;
   for (size_t i = 0; i < g_busy.size(); i++)
     if (g_busy[i] == w->e) { g_busy.erase(g_busy.begin() + i); break; }
+  bool doomed = false;
+  for (size_t i = 0; i < g_doomed.size(); i++)
+    if (g_doomed[i] == w->e) { g_doomed.erase(g_doomed.begin() + i); doomed = true; break; }
   if (w->rc == FSKHIP_OK) {
     napi_value res, out_v, cnt_v, eod_v, op;
     napi_create_object(env, &res);
@@ -253,6 +272,7 @@ static void demod_complete(napi_env env, napi_status, void *data) {
   napi_delete_reference(env, w->cnt_ref);
   napi_delete_reference(env, w->eod_ref);
   napi_delete_async_work(env, w->work);
+  if (doomed) fskhip_destroy(w->e);   // destroy() was called while the worker held the engine
   delete w;
 }
 
@@ -274,9 +294,7 @@ static napi_value DemodulateAsync(napi_env env, napi_callback_info info) {
   napi_get_value_uint32(env, argv[4], &w->flags);
   const uint32_t S = fskhip_n_streams(e);
   if (w->pitch < w->n || (size_t)w->pitch * (S ? S - 1 : 0) + w->n > len) { delete w; napi_throw_range_error(env, nullptr, "samples too short"); return nullptr; }
-  for (fskhip_engine *b : g_busy)
-    if (b == e) { delete w; napi_throw_error(env, nullptr, "an asynchronous call is already in flight on this engine"); return nullptr; }
-  w->out_pitch = w->n / 32 + 8;
+  w->out_pitch = fskhip_max_bytes(e, w->n);
   void *out = nullptr, *counts = nullptr, *eod = nullptr;
   napi_value out_v = make_typed(env, napi_uint8_array, w->out_pitch * S, 1, &out);
   napi_value cnt_v = make_typed(env, napi_uint32_array, S, 4, &counts);

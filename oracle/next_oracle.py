@@ -49,7 +49,11 @@ def serialize(packet):
 def scan_burst(data, expected):
     """The receive grammar of XModemTransport over a recorded burst: xmodem.ts:233-320 (receiveAllPackets,
     receiveAndProcessPacket, isPreviousSequence 525-530, assembleData 322-333) with "no more bytes" where the
-    reference would time out.  Stops at the first error, like the reference's throw."""
+    reference would time out.  Stops at the first error, like the reference's throw with maxRetries 0.  Pinned to the
+    REAL class (tests/golden/manifest_next.json "scans": receiveData() over a scripted data channel): `packets` is
+    statistics.packetsReceived (counted when the payload has been read, before its CRC is checked, xmodem.ts:280),
+    `consumed` the bytes taken out of the receive buffer (a time-out after SOH leaves SOH consumed, after the 3-byte header
+    the header too: waitForBytes, xmodem.ts:475-499)."""
     data = bytes(data)
     pos = 0
     out = bytearray()
@@ -68,7 +72,7 @@ def scan_burst(data, expected):
             continue
         if pos + 4 > len(data):
             r["status"] = XM_TRUNCATED
-            r["consumed"] = pos
+            r["consumed"] = pos + 1
             break
         seq, nseq, ln = data[pos + 1], data[pos + 2], data[pos + 3]
         if seq + nseq != 255:
@@ -81,18 +85,18 @@ def scan_burst(data, expected):
             r["dropped"] += 1
             break
         if pos + 6 + ln > len(data):
-            r.update(status=XM_TRUNCATED, err_seq=seq, err_len=ln, consumed=pos)
+            r.update(status=XM_TRUNCATED, err_seq=seq, err_len=ln, consumed=pos + 4)
             break
         if seq == expected:
             payload = data[pos + 4:pos + 4 + ln]
             crc = (data[pos + 4 + ln] << 8) | data[pos + 5 + ln]
             calc = crc16(payload)
+            r["packets"] += 1
             if calc != crc:
                 r.update(status=XM_INVALID_CRC, err_seq=seq, err_len=ln, crc_rx=crc, crc_calc=calc, consumed=pos + 6 + ln)
                 r["dropped"] += 1
                 break
             out += payload
-            r["packets"] += 1
             expected = (expected % 255) + 1
         else:
             r["dropped"] += 1

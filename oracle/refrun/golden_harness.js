@@ -162,10 +162,10 @@ async function main() {
   for (const [fc, sr, nt] of [[1000, 48000, 51], [1200, 48000, 50], [300, 8000, 11]]) {
     fd.push({ fn: 'sincLowpass', args: [fc, sr, nt], out: R.FilterDesign.sincLowpass(fc, sr, nt) });
   }
-  for (const [fc, sr, nt] of [[1000, 48000, 51], [300, 8000, 11]]) {
+  for (const [fc, sr, nt] of [[1000, 48000, 51], [300, 8000, 11], [1000, 48000, 50]]) {
     fd.push({ fn: 'sincHighpass', args: [fc, sr, nt], out: R.FilterDesign.sincHighpass(fc, sr, nt) });
   }
-  for (const [fc, bw, sr, nt] of [[1750, 800, 48000, 51], [1000, 500, 8000, 21]]) {
+  for (const [fc, bw, sr, nt] of [[1750, 800, 48000, 51], [1000, 500, 8000, 21], [1750, 800, 48000, 50], [1200, 600, 44100, 8]]) {  // incl. even tap counts
     fd.push({ fn: 'sincBandpass', args: [fc, bw, sr, nt], out: R.FilterDesign.sincBandpass(fc, bw, sr, nt) });
   }
   manifest.filter_design = fd;

@@ -4,8 +4,9 @@
 //   CRC16 (src/utils/crc16.ts), XModemPacket (src/transports/xmodem/packet.ts), ChunkedModulator
 //   (src/webaudio/chunked-modulator.ts), RingBuffer (src/utils.ts) + FSKCore in 128-sample quanta as
 //   FSKProcessor drives them (src/webaudio/processors/fsk-processor.ts:152-167, 256-322).
-// FSKProcessor and XModemTransport themselves need AudioWorklet / AbortController globals Node 12 lacks, so
-// the few lines of glue around the real classes are restated here, each block citing what it follows.
+// FSKProcessor itself needs AudioWorklet globals Node does not have, so the few lines of glue around the real FSKCore /
+// RingBuffer / ChunkedModulator are restated here, each block citing what it follows.  XModemTransport runs as is
+// (xmodem.ts, with stand-ins for three standard web APIs Node 12 lacks -- see scanBurst).
 //
 // usage: node golden_harness_next.js <ref_bundle.js> <out_dir>
 'use strict';
@@ -59,48 +60,79 @@ function mkCore(cfg) {
   return f;
 }
 
-// ---- the receive grammar of XModemTransport over a recorded byte burst -------------------------
-// Restates xmodem.ts:233-320 (receiveAllPackets / receiveAndProcessPacket) with "no more bytes" in place of
-// the timeout; CRC16 is the real class.  Stops at the first error like the reference's throw.
-function scanBurst(bytes, expected) {
-  let pos = 0;
-  const payloads = [];
-  let status = 'need_more', packets = 0, dropped = 0, errSeq = -1, errLen = -1, crcRx = -1, crcCalc = -1;
-  let resume = 0; // offset of the first byte not yet consumed by a completed step
-  for (;;) {
-    if (pos >= bytes.length) { status = 'need_more'; resume = pos; break; }
-    const first = bytes[pos];
-    if (first === R.ControlType.EOT) { pos++; resume = pos; status = 'eot'; break; }
-    if (first !== R.ControlType.SOH) { pos++; resume = pos; continue; }           // ignored byte
-    const start = pos;
-    if (pos + 4 > bytes.length) { status = 'truncated'; resume = start; break; }   // waitForBytes(3) times out
-    const seq = bytes[pos + 1], nseq = bytes[pos + 2], len = bytes[pos + 3];
-    if ((seq + nseq) !== 255) { status = 'invalid_sequence'; errSeq = seq; errLen = len; dropped++; resume = pos + 4; break; }
-    const prev = expected === 1 ? 255 : expected - 1;                              // isPreviousSequence 525-530
-    if (seq === expected || seq === prev) {
-      if (pos + 4 + len + 2 > bytes.length) { status = 'truncated'; errSeq = seq; errLen = len; resume = start; break; }
-      if (seq === expected) {
-        const payload = bytes.slice(pos + 4, pos + 4 + len);
-        const crc = (bytes[pos + 4 + len] << 8) | bytes[pos + 4 + len + 1];
-        const calc = R.CRC16.calculate(payload);
-        if (calc !== crc) { status = 'invalid_crc'; errSeq = seq; errLen = len; crcRx = crc; crcCalc = calc; dropped++; resume = pos + 6 + len; break; }
-        payloads.push(payload);
-        packets++;
-        expected = (expected % 255) + 1;
-      } else {
-        dropped++;                                                                  // duplicate: consumed, ACKed, ignored
-      }
-      pos += 6 + len; resume = pos;
-    } else {
-      status = 'unexpected_sequence'; errSeq = seq; errLen = len; dropped++; resume = pos + 4; break;
-    }
+// ---- the receive grammar of XModemTransport over a recorded byte burst ---------------------------
+// The REAL class (xmodem.ts, type-stripped by strip_ts.py): receiveData() is run against a scripted data channel that
+// delivers the burst and then nothing, like the reference's own tests drive it (tests/transports/xmodem/xmodem.node.test.ts).
+// Node 12 lacks three standard web APIs the class uses (AbortController xmodem.ts:55,73; AbortSignal.timeout / .any
+// xmodem.ts:536-542): minimal stand-ins with the standard semantics, nothing of the reference's.
+class MiniSignal {
+  constructor() { this.aborted = false; this.reason = undefined; this._l = []; }
+  addEventListener(t, f) { if (t === 'abort') this._l.push(f); }
+  removeEventListener(t, f) { this._l = this._l.filter(x => x !== f); }
+  _fire(reason) { if (this.aborted) return; this.aborted = true; this.reason = reason; this._l.slice().forEach(f => f()); }
+}
+global.AbortController = class { constructor() { this.signal = new MiniSignal(); } abort(r) { this.signal._fire(r || new Error('This operation was aborted')); } };
+global.AbortSignal = {
+  timeout(ms) { const s = new MiniSignal(); const t = setTimeout(() => s._fire(new Error('The operation was aborted due to timeout')), ms); return s; },
+  any(list) { const s = new MiniSignal(); for (const x of list) { if (x.aborted) { s._fire(x.reason); break; } x.addEventListener('abort', () => s._fire(x.reason)); } return s; },
+};
+class ScriptChannel {        // IDataChannel (core.ts:45-86): modulate records what the transport sends, demodulate hands out the script
+  constructor(chunks) { this.q = chunks.slice(); this.sent = []; }
+  async modulate(data) { this.sent.push(Array.from(data)); }
+  async demodulate(options) {
+    if (this.q.length) return this.q.shift();
+    return new Promise((resolve, reject) => {   // nothing more arrives: only the caller's timeout signal ends the wait
+      const sig = options && options.signal;
+      if (!sig) return;
+      if (sig.aborted) { reject(new Error('Demodulation aborted')); return; }
+      sig.addEventListener('abort', () => reject(new Error('Demodulation aborted')));
+    });
   }
-  let total = 0;
-  payloads.forEach(p => { total += p.length; });
-  const data = new Uint8Array(total);
-  let o = 0;
-  payloads.forEach(p => { data.set(p, o); o += p.length; });                        // assembleData 322-333
-  return { status, expected_after: expected, packets, dropped, consumed: resume, err_seq: errSeq, err_len: errLen, crc_rx: crcRx, crc_calc: crcCalc, data };
+  reset() {}
+}
+// One burst through XModemTransport.receiveData() (xmodem.ts:184-214 -> receiveAllPackets 232-264 -> receiveAndProcessPacket
+// 266-320) with maxRetries 0, so that the first error (or the timeout once the bytes run out) ends the call like one scan.
+// Instrumentation only: the starting sequence number is planted after initializeReceive() (a receiver that is already
+// `expected - 1` packets into a transfer), and receiveAndProcessPacket is wrapped to know whether a timeout hit mid-packet.
+async function scanBurst(bytes, expected, split) {
+  const log = console.log, warn = console.warn;
+  console.log = () => {}; console.warn = () => {};
+  try {
+    const chunks = [];
+    if (split && bytes.length) { for (let i = 0; i < bytes.length; i += split) chunks.push(bytes.slice(i, i + split)); } else if (bytes.length) chunks.push(bytes);
+    const ch = new ScriptChannel(chunks);
+    const t = new R.XModemTransport(ch);
+    t.configure({ timeoutMs: 10, maxRetries: 0 });
+    const init = t.initializeReceive;
+    t.initializeReceive = function () { init.call(this); this.receive.expectedSequence = expected; };
+    let inPacket = false, header = null;
+    const rap = t.receiveAndProcessPacket;
+    t.receiveAndProcessPacket = async function (sig) { inPacket = true; const r = await rap.call(this, sig); inPacket = false; return r; };
+    const wfb = t.waitForBytes;
+    t.waitForBytes = async function (count, opt) { const r = await wfb.call(this, count, opt); if (inPacket && count === 3) header = Array.from(r); return r; };
+    const errors = [];
+    t.on('error', ev => errors.push(ev.data));
+    let result = null, err = null;
+    try { result = await t.receiveData(); } catch (e) { err = e.message; }
+    const st = t.getStatistics();
+    let status;
+    if (result) status = 'eot';
+    else if (/Invalid sequence number/.test(err)) status = 'invalid_sequence';
+    else if (/Invalid CRC/.test(err)) status = 'invalid_crc';
+    else if (/Unexpected sequence number/.test(err)) status = 'unexpected_sequence';
+    else if (/aborted/i.test(err)) status = inPacket ? 'truncated' : 'need_more';
+    else throw new Error('unclassified receive error: ' + err);
+    let data = result;
+    if (!data) { let n = 0; t.receive.data.forEach(p => { n += p.length; }); data = new Uint8Array(n); let o = 0; t.receive.data.forEach(p => { data.set(p, o); o += p.length; }); }
+    const e0 = errors[0] || {};
+    const errSeq = status === 'truncated' ? (header ? header[0] : -1) : (e0.seq !== undefined ? e0.seq : (e0.received !== undefined ? e0.received : -1));
+    const errLen = (status !== 'eot' && status !== 'need_more' && header) ? header[2] : -1;
+    const acks = ch.sent.filter(m => m.length === 1 && m[0] === R.ControlType.ACK).length;
+    const naks = ch.sent.filter(m => m.length === 1 && m[0] === R.ControlType.NAK).length;
+    return { status, expected_after: t.receive.expectedSequence, packets: st.packetsReceived, dropped: st.packetsDropped,
+      consumed: bytes.length - t.receive.buffer.length - ch.q.reduce((a, c) => a + c.length, 0), err_seq: errSeq, err_len: errLen,
+      crc_rx: e0.crc !== undefined ? e0.crc : -1, crc_calc: e0.calculatedCrc !== undefined ? e0.calculatedCrc : -1, acks, naks, error: err, data };
+  } finally { console.log = log; console.warn = warn; }
 }
 
 async function main() {
@@ -193,13 +225,21 @@ async function main() {
       if (rand() < 0.5) parts.push(Uint8Array.from([0x04]));
       add('rand_' + i, cat(...parts), start);
     }
-    const outs = bursts.map(b => scanBurst(b.bytes, b.expected));
+    const outs = [];
+    for (const b of bursts) outs.push(await scanBurst(b.bytes, b.expected, 0));
+    // the same bursts delivered 7 bytes at a time must scan identically (waitForBytes accumulates across demodulate() calls)
+    for (let i = 0; i < bursts.length; i++) {
+      const o7 = await scanBurst(bursts[i].bytes, bursts[i].expected, 7);
+      for (const k of ['status', 'expected_after', 'packets', 'dropped', 'consumed', 'err_seq', 'crc_rx', 'crc_calc', 'acks'])
+        if (o7[k] !== outs[i][k]) throw new Error('burst ' + bursts[i].name + ': ' + k + ' depends on the chunking: ' + o7[k] + ' vs ' + outs[i][k]);
+    }
     const pb = packRagged('scan.bytes', bursts.map(b => b.bytes));
     const pd = packRagged('scan.out', outs.map(o => o.data));
     manifest.scans = { bytes: pb, data: pd, cases: bursts.map((b, i) => {
       const o = outs[i];
       return { name: b.name, expected: b.expected, status: o.status, expected_after: o.expected_after, packets: o.packets,
-        dropped: o.dropped, consumed: o.consumed, err_seq: o.err_seq, err_len: o.err_len, crc_rx: o.crc_rx, crc_calc: o.crc_calc };
+        dropped: o.dropped, consumed: o.consumed, err_seq: o.err_seq, err_len: o.err_len, crc_rx: o.crc_rx, crc_calc: o.crc_calc,
+        acks: o.acks, naks: o.naks, error: o.error };
     }) };
   }
   // ---------------- ChunkedModulator (chunked-modulator.ts; tests/webaudio/chunked-modulator.node.test.ts) ----------------

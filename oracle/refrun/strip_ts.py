@@ -107,6 +107,47 @@ def strip(src, name):
     return src
 
 
+def strip_transport(ref):
+    """BaseTransport (core.ts:292-351) + XModemTransport (transports/xmodem/xmodem.ts), erased to Node-12 JavaScript.
+    The receive grammar of SURVEY.md 8(f2) is pinned against THIS class (golden_harness_next.js drives receiveData() through a
+    scripted data channel); AbortController / AbortSignal.timeout / AbortSignal.any, which Node 12 lacks, are provided by
+    the harness as globals."""
+    with open(os.path.join(ref, "src/core.ts"), encoding="utf-8") as fh:
+        core = "\n".join(fh.read().split("\n")[298:351])
+    with open(os.path.join(ref, "src/transports/xmodem/xmodem.ts"), encoding="utf-8") as fh:
+        xm = fh.read()
+    src = core + "\n" + xm
+    src = re.sub(r"^import .*?;\s*$", "", src, flags=re.M)
+    src = drop_blocks(src, r"^(?:export )?interface [A-Za-z0-9_<>, ]+ (?:extends [A-Za-z0-9_<>, ]+ )?\{")
+
+    def state_enum(m):   # auto-numbered enum with reverse mapping (State[this.protocol.state])
+        body = re.sub(r"//[^\n]*", "", m.group(2))
+        names = [it.strip() for it in body.split(",") if it.strip()]
+        return "const %s = {};\n%s.forEach((n, i) => { %s[n] = i; %s[i] = n; });" % (m.group(1), repr(names).replace("'", '"'), m.group(1), m.group(1))
+    src = re.sub(r"^(?:export )?enum (\w+) \{(.*?)^\}", state_enum, src, flags=re.M | re.S)
+    src = re.sub(r"^export ", "", src, flags=re.M)
+    src = re.sub(r"abstract class BaseTransport\s+extends EventEmitter\s+implements ITransport \{", "class BaseTransport extends EventEmitter {", src)
+    src = re.sub(r"^\s*abstract .*$", "", src, flags=re.M)
+    # method with a type parameter and function-typed arguments
+    src = src.replace("private async withRetry<T>(\n    operation: () => Promise<T>,\n    maxRetries: number,\n    onRetry?: (_retryCount: number) => void,\n    externalSignal?: AbortSignal\n  ): Promise<T> {",
+                      "async withRetry(operation, maxRetries, onRetry, externalSignal) {")
+    # casts
+    src = src.replace("[] as Uint8Array[]", "[]").replace("[] as number[]", "[]")
+    src = src.replace("undefined as AbortController | undefined", "undefined")
+    src = re.sub(r"\s+as (?:StateChangeEvent|[A-Z][A-Za-z0-9_]*)\)", ")", src)
+    # access modifiers
+    src = re.sub(r"\b(?:private|protected|public|readonly)\s+", "", src)
+    # parameter / return annotations
+    obj_t = r"\{\s*signal\??:\s*AbortSignal\s*\}"
+    atom = r"(?:number\[\]|number|void|boolean|string|unknown|any|" + obj_t + r"|Promise<[A-Za-z0-9_\[\]]+>|Partial<[A-Za-z0-9_]+>|[A-Z][A-Za-z0-9_]*(?:\[\])?(?:\s*\|\s*undefined)?)"
+    for _ in range(4):
+        src = re.sub(r"(\b[A-Za-z_][A-Za-z0-9_]*|\))\??:\s*" + atom + r"(?=\s*[,)=;{])", r"\1", src)
+    # optional chaining (Node 12 has none)
+    src = re.sub(r"(\bonRetry)\?\.\(", r"\1 && \1(", src)
+    src = re.sub(r"((?:this\.)?[A-Za-z_][A-Za-z0-9_.]*)\?\.([A-Za-z_][A-Za-z0-9_.]*)", r"(\1 ? \1.\2 : undefined)", src)
+    return "// ---- src/core.ts:292-351 + src/transports/xmodem/xmodem.ts ----\n" + src
+
+
 def main():
     ref, out = sys.argv[1], sys.argv[2]
     os.makedirs(out, exist_ok=True)
@@ -114,10 +155,11 @@ def main():
     for f in FILES + NEXT_FILES:
         with open(os.path.join(ref, f), encoding="utf-8") as fh:
             parts.append("// ---- %s ----\n%s" % (f, strip(fh.read(), f)))
+    parts.append(strip_transport(ref))
     parts.append(
         "module.exports = {FSKCore, DEFAULT_FSK_CONFIG, IIRFilter, FIRFilter, "
         "FilterDesign, FilterFactory, RingBuffer, CRC16, XModemPacket, ControlType, PacketConstants, "
-        "ChunkedModulator};\n"
+        "ChunkedModulator, XModemTransport, Event};\n"
     )
     with open(os.path.join(out, "ref_bundle.js"), "w", encoding="utf-8") as fh:
         fh.write("\n".join(parts))

@@ -168,8 +168,8 @@ int fskhip_sinc_highpass(double cutoff, double sampleRate, uint32_t n_taps, doub
 }
 int fskhip_sinc_bandpass(double center, double bandwidth, double sampleRate, uint32_t n_taps, double *taps) {  // filters.ts:296-314
   if (!taps || n_taps == 0) return fail(FSKHIP_E_INVALID, "fskhip_sinc_bandpass: bad argument");
-  if (n_taps % 2 == 0)
-    return fail(FSKHIP_E_UNSUPPORTED, "sincBandpass with an even numTaps reads past the reference's arrays (filters.ts:304-311)");
+  // (an even numTaps works in the reference too: its sincHighpass / sincLowpass return numTaps + 1 taps then, of which
+  // the convolution below only reads the first numTaps)
   std::vector<double> hp, lp;
   sinc_highpass(center - bandwidth / 2, sampleRate, n_taps, hp);
   sinc_lowpass(center + bandwidth / 2, sampleRate, n_taps, lp);

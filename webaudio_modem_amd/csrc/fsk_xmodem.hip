@@ -193,6 +193,7 @@ struct Scan {
         consumed = pos + 1;
         state = ST_IDLE;
         if (accept) {
+          packets++;        // statistics.packetsReceived: counted once the payload is in, before the CRC check (xmodem.ts:280)
           if (rx != crc) {  // xmodem.ts:287-291
             status = FSKHIP_XM_INVALID_CRC;
             err_seq = (int32_t)seq;
@@ -203,7 +204,6 @@ struct Scan {
             state = ST_DONE;
           } else {  // xmodem.ts:293-303
             data_len += len;
-            packets++;
             expected = (expected % 255u) + 1;
           }
         } else {
@@ -216,9 +216,11 @@ struct Scan {
   }
 
   __device__ __forceinline__ void finish(fskhip_xmodem_result *out) {
-    if (state != ST_IDLE && state != ST_DONE) {  // ran out of bytes inside a packet
+    if (state != ST_IDLE && state != ST_DONE) {  // ran out of bytes inside a packet (the reference's wait times out)
       status = FSKHIP_XM_TRUNCATED;
-      consumed = start;
+      // what waitForBytes has taken out of the receive buffer by then (xmodem.ts:475-499): SOH, and the three header
+      // bytes once they were all there -- pinned to the real XModemTransport by tests/golden/manifest_next.json
+      consumed = state >= ST_PAYLOAD ? start + 4u : start + 1u;
       if (state >= ST_PAYLOAD) {
         err_seq = (int32_t)seq;
         err_len = (int32_t)len;
