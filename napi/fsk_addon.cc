@@ -123,7 +123,7 @@ static fskhip_engine *get_engine(napi_env env, napi_value v) {
     return nullptr;
   }
   if (is_busy((fskhip_engine *)p)) {
-    napi_throw_error(env, nullptr, "an asynchronous call is in flight on this engine");
+    napi_throw_error(env, nullptr, "an asynchronous call is already in flight on this engine");
     return nullptr;
   }
   return (fskhip_engine *)p;
