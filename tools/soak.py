@@ -127,7 +127,8 @@ def main(budget=None, seed=None, max_rounds=None):
                     SOFT["n"] += 1
                     SOFT["first"] = SOFT["first"] or ("eod", cfg, S, s, off, n, int(eod[s]), oe)
                 elif (int(eod[s]) != oe and counts_comparable(cfg, prec)) or out[s] != ob:
-                    np.save("gpurun_out/soak_fail_x.npy", x[s])
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    np.save("gpurun_out/soak_fail_%x.npy" % seed, x[s])
                     raise AssertionError(("mismatch", cfg, prec, S, s, off, n, int(eod[s]), oe, out[s], ob, log[-12:]))
             off += n
             u = rng.random()

@@ -96,7 +96,7 @@ __global__ void init_kernel(DemodState S, uint32_t n, uint32_t matched_zero) {
   rs[(size_t)RF_sil_thr * n + s] = (Real)0.01;
   S.is[(size_t)IF_matched * n + s] = matched_zero;
   S.is[(size_t)IF_bit_wait * n + s] = kBigWait;
-  S.is[(size_t)IF_zr_dph * n + s] = 2u;
+  S.is[(size_t)IF_zr_dph * n + s] = kDirectPairs;
 }
 
 // reset() fsk.ts:464-469 = resetState() + syncSamplesBuffer.clear() (+ host-side counters).
@@ -123,7 +123,7 @@ __global__ void reset_kernel(DemodState S, uint32_t n, int64_t stream) {
     const int zz[] = {RF_zq_ai, RF_zq_aq, RF_zq_bi, RF_zq_bq, RF_zq_0i, RF_zq_0q, RF_zd_ix1, RF_zd_ix2, RF_zd_iy, RF_zd_iv,
                       RF_zd_qx1, RF_zd_qx2, RF_zd_qy, RF_zd_qv};
     for (int f : zz) rs[(size_t)f * n + s] = (Real)0;
-    S.is[(size_t)IF_zr_dph * n + s] = 2u;
+    S.is[(size_t)IF_zr_dph * n + s] = kDirectPairs;
     double r = (double)fr0 * 5.42101086242752217e-20 * 6.283185307179586476925;
     r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
     for (int f : iz) S.is[(size_t)f * n + s] = 0u;
@@ -594,7 +594,7 @@ int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_
     // Lock-step fp32 batches with narrow integer-capacity rings never leave fsk_pipe.hip's arithmetic: a head of
     // single samples up to an even decimator parity and a 16-byte boundary, whole 16-sample tiles, a tail of single
     // samples -- so cutting a stream into calls of any lengths changes nothing, bit for bit.  Everything else (fp64,
-    // wide / fractional rings, traces, streams out of lock step) is the generic kernel's.
+    // wide / fractional rings, streams out of lock step) is the generic kernel's.
     e->last_kernel = "";
     if (n > 0 && !e->force_generic && !e->gen_odd && demod_fast_applicable(e->precision, e->ds_uniform, e->P, e->S, d_samples, pitch)) {
       const size_t wgs_per_cu = (e->n_blocks + e->split_cus - 1) / e->split_cus;
@@ -609,6 +609,7 @@ int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_
         if ((a & 3u) != 0 || ((a >> 2) & 1u) != p0) tiles = false;
         else head = a >> 2;
       }
+      if (e->S.trace_stream != 0xFFFFFFFFu) tiles = false;   // a traced engine stays on the sample-granular kernel
       if (tiles && head < n) n_fast = (n - head) & ~(size_t)15;
       if (!n_fast) head = n;   // all of it sample by sample
       bool app = false;

@@ -157,7 +157,7 @@ __device__ inline void pipe_to_actual(Lane<float> &L, const DemodParams &P, cons
   const double th = (double)off * 5.42101086242752217e-20 * 6.283185307179586476925;   // 2^-64 turns -> radians
   const double c = cos(th), sn = sin(th);
   double x1i, x1q, x2i, x2q, yi, yq, vi, vq;
-  if (IQ(zr_dph) < 2u) {   // the direct instance IS the state
+  if (IQ(zr_dph) < kDirectPairs) {   // the direct instance IS the state
     x1i = RQ(zd_ix1); x1q = RQ(zd_qx1); x2i = RQ(zd_ix2); x2q = RQ(zd_qx2);
     yi = RQ(zd_iy); yq = RQ(zd_qy); vi = RQ(zd_iv); vq = RQ(zd_qv);
   } else {                 // free-running state minus the zero-input response (its x history is zero by now)
@@ -168,10 +168,17 @@ __device__ inline void pipe_to_actual(Lane<float> &L, const DemodParams &P, cons
     vi = L.li_y2 - __builtin_fmaf(P.z_vb, qbi, P.z_va * qai);
     vq = L.lq_y2 - __builtin_fmaf(P.z_vb, qbq, P.z_va * qaq);
   }
-  rot2(c, sn, x1i, x1q, L.li_x1, L.lq_x1);
-  rot2(c, sn, x2i, x2q, L.li_x2, L.lq_x2);
-  rot2(c, sn, yi, yq, L.li_y1, L.lq_y1);
-  rot2(c, sn, vi, vq, L.li_y2, L.lq_y2);
+  // fsk_pipe.hip runs the branch from the pre-filter output on 2^60 times the reference's size (kIqScale there)
+  const double un = 8.67361737988403547e-19;       // 2^-60
+  L.bp_y1 *= 8.67361737988403547e-19f; L.bp_y2 *= 8.67361737988403547e-19f;
+  rot2(c, sn, x1i * un, x1q * un, L.li_x1, L.lq_x1);
+  rot2(c, sn, x2i * un, x2q * un, L.li_x2, L.lq_x2);
+  rot2(c, sn, yi * un, yq * un, L.li_y1, L.lq_y1);
+  rot2(c, sn, vi * un, vq * un, L.li_y2, L.lq_y2);
+  {
+    const double ai = L.acc_i, aq = L.acc_q;       // an open decimator pair's first low-pass outputs
+    rot2(c, sn, ai * un, aq * un, L.acc_i, L.acc_q);
+  }
   double r = (double)L.last_phase + th;            // th in [0, 2 pi)
   r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
   L.last_phase = (float)r;
@@ -186,17 +193,21 @@ __device__ inline void actual_to_pipe(Lane<float> &L, const DemodState &S, size_
   const uint64_t off = acc - (fr.free0 + inc * (uint64_t)n_done);
   const double th = (double)off * 5.42101086242752217e-20 * 6.283185307179586476925;
   const double c = cos(th), sn = -sin(th);         // rotate back by -theta
-  const double x1i = L.li_x1, x1q = L.lq_x1, x2i = L.li_x2, x2q = L.lq_x2, yi = L.li_y1, yq = L.lq_y1, vi = L.li_y2, vq = L.lq_y2;
+  const double up = 1152921504606846976.0;         // 2^60 (kIqScale of fsk_pipe.hip)
+  const double x1i = up * L.li_x1, x1q = up * L.lq_x1, x2i = up * L.li_x2, x2q = up * L.lq_x2, yi = up * L.li_y1, yq = up * L.lq_y1,
+               vi = up * L.li_y2, vq = up * L.lq_y2, ai = up * L.acc_i, aq = up * L.acc_q;
+  L.bp_y1 *= 1152921504606846976.0f; L.bp_y2 *= 1152921504606846976.0f;
   rot2(c, sn, x1i, x1q, L.li_x1, L.lq_x1);
   rot2(c, sn, x2i, x2q, L.li_x2, L.lq_x2);
   rot2(c, sn, yi, yq, L.li_y1, L.lq_y1);
   rot2(c, sn, vi, vq, L.li_y2, L.lq_y2);
+  rot2(c, sn, ai, aq, L.acc_i, L.acc_q);
   double r = (double)L.last_phase - th;
   r = r < -3.14159265358979323846 ? r + 6.283185307179586476925 : r;
   L.last_phase = (float)r;
   S.is[(size_t)IF_fr_lo * n + row] = (uint32_t)off;
   S.is[(size_t)IF_fr_hi * n + row] = (uint32_t)(off >> 32);
-  S.is[(size_t)IF_zr_dph * n + row] = 2u;
+  S.is[(size_t)IF_zr_dph * n + row] = kDirectPairs;
   const int zf[] = {RF_zq_ai, RF_zq_aq, RF_zq_bi, RF_zq_bq, RF_zq_0i, RF_zq_0q, RF_zd_ix1, RF_zd_ix2, RF_zd_iy, RF_zd_iv,
                     RF_zd_qx1, RF_zd_qx2, RF_zd_qy, RF_zd_qv};
   for (int f : zf) rs[(size_t)f * n + row] = 0.0f;
@@ -759,8 +770,8 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
 bool demod_fast_applicable(int precision, bool uniform, const DemodParams &P, const DemodState &S,
                            const float *samples, size_t pitch) {
   (void)samples;
-  return precision == 0 && uniform && !P.wide && !P.frac && P.d >= 2 && S.trace_stream == 0xFFFFFFFFu &&
-         sizeof(float4) * (4 * kSlotStride + 16) + sizeof(uint32_t) * 64u * P.d <= 48 * 1024 && (uint64_t)P.amp_cap * P.n_streams * 4u < 0xFFFFFFF0ull &&
+  return precision == 0 && uniform && !P.wide && !P.frac && P.d >= 2 &&
+         sizeof(float4) * (4 * kSlotStride + 16) + sizeof(uint32_t) * 64u * (P.d + 1u) <= 48 * 1024 && (uint64_t)P.amp_cap * P.n_streams * 4u < 0xFFFFFFF0ull &&
          (uint64_t)pitch * 4u * 64u < 0x7FFFFFF0ull;  // per-wave input descriptor and offsets fit 31 bits
 }
 size_t demod_lds_bytes(const DemodParams &P) {

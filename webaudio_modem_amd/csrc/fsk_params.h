@@ -20,9 +20,11 @@ namespace fsk {
   X(last_phase)                         /* iqState.lastPhase fsk.ts:102 */                  \
   X(nco_phase)                          /* iqState.localOscPhase (f64 path only) */         \
   X(sil_thr)                            /* silence.threshold fsk.ts:128 */
-// fp32 engines keep the I/Q low-pass in a FREE-RUNNING frame (fsk_pipe.hip): li_*, lq_*, last_phase are that frame's;
-// what resetState() would have zeroed is carried as a zero-input response (pair sums zq_*), or, for the two decimated
-// samples after a reset (zr_dph = 0, 1), as a zero-started direct instance zd_*.  (Not part of the generic kernel's Lane.)
+// fp32 engines keep the I/Q low-pass in a FREE-RUNNING frame (fsk_pipe.hip): li_*, lq_*, last_phase are that frame's.
+// After a resetState() the next kDirectPairs decimated samples come from a zero-started direct instance zd_* (zr_dph =
+// how many it has produced); kZeroLagPairs decimated samples after the reset the free-running filters are zeroed, and
+// what they then lack -- the direct instance's memory at that point -- is carried as a zero-input response (pair sums
+// zq_*) from the direct instance's last two samples on.  (Not part of the generic kernel's Lane.)
 #define FSK_REAL_FIELDS_PIPE(X)                                                             \
   X(zq_ai) X(zq_aq) X(zq_bi) X(zq_bq) X(zq_0i) X(zq_0q)                                     \
   X(zd_ix1) X(zd_ix2) X(zd_iy) X(zd_iv) X(zd_qx1) X(zd_qx2) X(zd_qy) X(zd_qv)
@@ -50,7 +52,7 @@ namespace fsk {
 #define FSK_INT_FIELDS_PIPE(X)                                                              \
   X(fr_lo) X(fr_hi)     /* fp32: NCO phase minus the free-running frame's phase (64-bit turns); */ \
                         /* changes only at resetState()                                     */      \
-  X(zr_dph)             /* fp32: 2 = zq_* valid; 0, 1 = decimated samples done by the direct instance */
+  X(zr_dph)             /* fp32: decimated samples the direct instance has produced since resetState(); kDirectPairs = zq_* valid */
 
 enum RealField {
 #define X(n) RF_##n,
@@ -166,6 +168,11 @@ struct ProcState {
   uint32_t *tx_completed;
 };
 
+// fp32 free-running frame (fsk_pipe.hip): the front end zeroes a stream's I/Q low-pass kZeroLagPairs decimated samples
+// after a resetState() -- far enough for the two-wave kernel's front wave (at most kPipeSlots = 4 half tiles = 16
+// decimated samples ahead) to learn of the reset in time -- and a direct instance covers those plus two more.
+static constexpr uint32_t kZeroLagPairs = 16;
+static constexpr uint32_t kDirectPairs = kZeroLagPairs + 2;
 static constexpr uint32_t kBigWait = 0x40000000u;  // bit_wait while !started (12 h of decimated samples)
 #ifndef FSK_TILE
 #define FSK_TILE 32

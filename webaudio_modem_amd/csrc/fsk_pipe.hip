@@ -13,13 +13,19 @@
 //                              started at phase 0 when the launch did -> I/Q low-pass -> pair sums U[m]  (fsk.ts:228-248)
 //   back (per decimated sample): w[m] = U[m] - q[m], discriminator, post filter, slicer (fsk.ts:251-264) and the whole
 //                              frame state machine (fsk.ts:278-375).
-// q[m] is the zero-input response of the free-running filters' state at the last reset, as a pair sum: with Z[n] the
-// response of  y[n] = -a1 y[n-1] - a2 y[n-2]  it obeys  q[m+2] = (a1^2 - 2 a2) q[m+1] - a2^2 q[m].  Its first two values
-// come from computing the two pairs after a reset directly (a second, zero-started filter instance fed with the same
-// pre-filter outputs): q = U - W_direct.  What the reference's restarted NCO changes on top of that is a constant
-// rotation e^{-j w n0} of the I/Q plane, which the amplitude does not see and the phase DIFFERENCE only sees once:
-// lastPhase = 0 in the reference's frame is w*n0 in the free-running one.  tools/zir_model.py checks the algebra
-// against a sample-serial model (f64: 7e-14; f32: 1e-7 of the signal peak, i.e. the rounding the fp32 path has anyway).
+// After a reset the back wave computes the next kDirectPairs = 18 decimated samples itself, with a second, zero-started
+// filter instance fed with the same pre-filter outputs (W_direct).  kZeroLagPairs = 16 decimated samples after the
+// reset -- the front wave is at most 16 ahead, and the lag is counted in the stream's own samples, so it does not
+// depend on how the stream is cut into launches -- the front zeroes that stream's filters (the back posts the position
+// in an LDS mailbox).  From there U lacks only the direct instance's memory at that point, a zero-input response q[m]
+// of the size of the signal itself: as a pair sum, with Z[n] the response of  y[n] = -a1 y[n-1] - a2 y[n-2],  it obeys
+// q[m+2] = (a1^2 - 2 a2) q[m+1] - a2^2 q[m],  and its first two values are U - W_direct of the direct instance's last
+// two samples.  (Subtracting the response of the state AT the reset instead, without ever zeroing the front, is the
+// same algebra but not the same arithmetic: where the input has dropped by more than ~1e-7 before the reset --
+// the ringing after a frame followed by digital silence -- U - q cancels to rounding noise; tools/soak.py found that.)
+// What the reference's restarted NCO changes on top is a constant rotation e^{-j w n0} of the I/Q plane, which the
+// amplitude does not see and the phase DIFFERENCE only sees once: lastPhase = 0 in the reference's frame is w*n0 in the
+// free-running one.  tools/zir_model.py checks the algebra against a sample-serial model.
 //
 // Because the front's frame is uniform over the batch when all streams share one configuration, its NCO is not per-lane
 // arithmetic: sixteen lanes evaluate e^{j w n} for the sixteen samples of a tile (v_cos / v_sin of the exact 64-bit turn
@@ -27,8 +33,8 @@
 // the mixer (an operand from an SGPR would make every multiply a half-rate instruction, profiles/r02_valu_probe_summary.md).
 //
 // State.  fp32 engines keep this representation in HBM between launches (fsk_params.h: li_*/lq_*/last_phase are the
-// free-running frame's, fr_* the frame offset, zq_*/zd_*/zr_dph the correction), so a stream cut into launches at any
-// whole-tile boundaries computes bit for bit what one launch computes; the generic kernel (fsk_demod.hip), which runs
+// free-running frame's, fr_* the frame offset, zq_*/zd_*/zr_dph the correction), so a stream cut into launches
+// anywhere computes bit for bit what one launch computes; the generic kernel (fsk_demod.hip), which runs
 // ragged tails and the uncommon configurations with real resets, converts on load and store (pipe_to_actual /
 // actual_to_pipe in fsk_dev.h, f64 rotation).
 //
@@ -48,7 +54,14 @@ namespace fsk {
 
 static constexpr uint32_t kPipeSlots = 4;          // half tiles (8 samples) in the LDS ring between the two waves
 static constexpr uint32_t kStartedP = 0x7FFFFFFFu;  // thr_eff while a frame is started, in these kernels: matched - thr_eff stays negative
-static constexpr uint32_t kSlotV4 = 6 * 64;        // v4f per ring slot and lane: y[8] | U[4 pairs x (I, Q)] | (phase, magnitude)[4 pairs]
+static constexpr uint32_t kSlotV4 = 6 * 64;
+// Everything between the pre-filter and the discriminator is linear, so the whole I/Q branch runs 2^60 times larger than
+// the reference's (folded into the pre-filter's b0; the magnitude is scaled back where it is formed).  The reference's
+// doubles follow the ringing after a frame down to 1e-300; plain fp32 would lose it at 1e-38 -- and the (0, 0) guard of
+// atan2_amp_fma would bend phases from 1e-35 on -- while the bits sliced from that ringing are what a lowered
+// syncThreshold syncs on (tools/soak.py).  Scaled, the fp32 branch is exact in the same sense down to 1e-56.
+static constexpr float kIqScale = 1152921504606846976.0f;          // 2^60
+static constexpr float kIqUnscale = 8.67361737988403547e-19f;      // 2^-60        // v4f per ring slot and lane: y[8] | U[4 pairs x (I, Q)] | (phase, magnitude)[4 pairs]
 
 // ---- front: everything before the decimator, free-running --------------------------------------------------------
 struct FrontLane {
@@ -60,7 +73,7 @@ struct FrontK {                   // all in VGPRs: an SGPR operand halves a vect
   float att_m_rel, rel;          // AGC: attack - release, release
   float step_k, step_b;          // 2^40, -2^39: clamp(level*2^40 - 2^39) = [level > 0.5]
   float g_lo, g_hi;              // 0.1, 10
-  float bp_b0, bp_na1, bp_na2;   // pre-filter: y = b0*(x - x2) - a2*y2 - a1*y1
+  float bp_b0, bp_na1, bp_na2;   // pre-filter: y = b0*(x - x2) - a2*y2 - a1*y1; b0 carries the low-pass gain b0/2 and kIqScale
   float lp_a2, lp_nd;            // low-pass a2, -(1 + a1 + a2)
   float tiny; uint32_t sgn;      // 1e-37f, 0x80000000 (atan2_amp_fma)
 };
@@ -99,6 +112,13 @@ __device__ inline void front_sample(FrontLane &F, const FrontK &K, float xin, fl
   F.qx2 = F.qx1; F.qx1 = mq;
   oi = F.iy; oq = F.qy;
 }
+
+// resetState() reaches the free-running I/Q low-pass kZeroLagPairs decimated samples late (see the file comment)
+__device__ inline void front_zero(FrontLane &F, bool hit) {
+  if (hit) { F.ix1 = F.ix2 = F.iy = F.iv = 0.f; F.qx1 = F.qx2 = F.qy = F.qv = 0.f; }
+}
+// mailbox value at the start of a launch: the direct instance has produced dph decimated samples since the reset
+__device__ inline uint32_t zmail_init(uint32_t dph) { return dph <= kZeroLagPairs ? kZeroLagPairs - dph : 0xFFFFFFFFu; }
 
 // Discriminator front half (fsk.ts:251-252): phase and magnitude of one decimated I/Q pair sum, with FMA-class
 // instructions only besides the two transcendentals (no min/max, compare or select: those issue at half rate).
@@ -149,8 +169,9 @@ __device__ inline uint32_t sign_bit(uint32_t v) {
 struct BackLane {
   float qai, qaq, qbi, qbq;      // ZIR pair sums of the upcoming two decimated samples
   float px1, px2, py, pv;        // post filter (velocity form)
-  float last_phase, thr;         // lastPhase in the launch frame; silence threshold
-  // the two pairs after a reset are computed directly by a zero-started filter instance (dph = 0, 1; 2 = steady)
+  float last_phase, thr;         // lastPhase in the free-running frame; silence threshold
+  float thf;                     // the reference's phase 0 seen from the free-running frame (changes at resetState() only)
+  // the kDirectPairs decimated samples after a reset come from a zero-started filter instance (dph = how many so far)
   uint32_t dph;
   float dix1, dix2, diy, dvi, dqx1, dqx2, dqy, dqv, q0i, q0q;
   // frame state machine, as absolute push counts of this launch (k = pushes so far, wave-uniform):
@@ -170,6 +191,8 @@ struct BackK {                    // VGPRs, like FrontK
   float tiny; uint32_t sgn;      // 1e-37f, 0x80000000 (atan2_amp_fma)
   uint32_t edge_min;             // (1 << stop_pos) - 2: sreg - 2 >= edge_min (unsigned) <=> start or stop position
   uint32_t eod_m1;               // samplesForEOD - 1
+  float zk;                      // -1e37: clamp(2 + zk * |w|) = [the I/Q pair sum is exactly (0, 0)] (its scaled magnitude is the 1e-37 guard)
+  float unscale;                 // 2^-60
 };
 struct BackU {                   // wave-uniform context of one decimated sample
   uint32_t k;                    // pushes of this launch including this one
@@ -178,12 +201,14 @@ struct BackU {                   // wave-uniform context of one decimated sample
   uint32_t amp_soff;             // byte offset of the amplitude-ring row
   uint32_t direct;               // decimated samples for which some lane still runs the direct instance (after a reset)
   uint32_t zlive;                // some lane carries a non-zero correction (or runs the direct instance)
+  uint32_t *zmail;               // LDS [64]: decimated-sample index of this launch before which the front zeroes the lane's filters
   uint64_t free0;                // free-running frame: NCO phase (turns * 2^64) at the first sample of the launch
 };
 
 // resetState() fsk.ts:175-188 at the end of push k: the next input sample is n0 = 2k of this launch.
 template <bool UNI>
-__device__ inline void back_reset(BackLane &B, const DemodParams &P, const FastMem &M, const BackU &X, uint64_t inc) {
+__device__ inline void back_reset(BackLane &B, const DemodParams &P, const FastMem &M, const BackU &X, uint64_t inc,
+                                  uint32_t lane) {
   // the reference's NCO restarts at 0: from here on its phase is the free-running frame's minus that frame's phase at
   // n0, and its lastPhase = 0 is that phase in the free frame
   const uint64_t fr0 = X.free0 + inc * (uint64_t)(2u * X.k);
@@ -194,8 +219,10 @@ __device__ inline void back_reset(BackLane &B, const DemodParams &P, const FastM
     double r = (double)fr0 * 5.42101086242752217e-20 * 6.283185307179586476925;   // 2^-64 turns -> radians
     r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
     B.last_phase = (float)r;
+    B.thf = (float)r;
   }
   B.dph = 0;
+  X.zmail[lane] = X.k + kZeroLagPairs;   // the next decimated sample is number X.k of this launch (0-based)
   B.dix1 = B.dix2 = B.diy = B.dvi = 0.f;
   B.dqx1 = B.dqx2 = B.dqy = B.dqv = 0.f;
   B.px1 = B.px2 = B.py = B.pv = 0.f;
@@ -220,14 +247,14 @@ __device__ inline void nco_phasor(uint64_t acc, float &c, float &s) {
 // correction changed a bit of U in some lane (w == U bit for bit wherever q has decayed below half an ulp of U, i.e. from
 // ~40 decimated samples after a reset on), in which case the wave re-evaluates -- same function, same inputs where
 // nothing changed, so the result does not depend on which wave computed it.
-template <bool UNI, bool PA = false>
+// TRC: honour fskhip_trace_enable (the sample-granular kernel only; a traced engine runs entirely on it).
+template <bool UNI, bool PA = false, bool TRC = false>
 __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams &P, const DemodState &S, const FastMem &M,
                                  uint32_t *poly, uint32_t lane, __amdgpu_buffer_rsrc_t amp_rsrc, uint8_t *out,
                                  uint32_t out_pitch, uint32_t *eod_counts, BackU &X, float Ui, float Uq,
                                  const float *ypair, uint32_t r_old, uint64_t inc, float ph_u = 0.f, float amp_u = 0.f) {
   // ---- ZIR correction: w = U - q, q advances by its two-term recurrence.  Skipped (exactly: U - 0 = U) while no lane of
-  // the wave carries a correction; a correction whose four values are all below 1e-20 is retired to exactly zero (a rule
-  // of the stream's own history only, so every kernel and every chunking retires it at the same decimated sample).
+  // the wave carries a correction.
   float wi = Ui, wq = Uq;
   float amp, ph;
   if (X.zlive) {
@@ -237,10 +264,11 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
       const float nq = __builtin_fmaf(K.c1, B.qbq, -(K.c2 * B.qaq));
       B.qai = B.qbi; B.qaq = B.qbq; B.qbi = ni; B.qbq = nq;
     }
-    // ---- rare: the two pairs after a reset come from the zero-started instance, which also yields q's start values
+    // ---- rare: the decimated samples after a reset come from the zero-started instance; its last two (the first two
+    // after the front has zeroed its filters) also yield q's start values
     if (X.direct) {
       X.direct--;
-      if (B.dph < 2u) {
+      if (B.dph < kDirectPairs) {
         const float y0 = ypair[0], y1 = ypair[1];
         const uint32_t n0 = 2u * (X.k - 1u);
         // the front's phasors of these two samples, evaluated the same way (nco_phasor)
@@ -267,9 +295,9 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
           di += B.diy; dq += B.dqy;
         }
         wi = di; wq = dq;
-        if (B.dph == 0u) {
+        if (B.dph == kZeroLagPairs) {
           B.q0i = Ui - di; B.q0q = Uq - dq;
-        } else {
+        } else if (B.dph == kZeroLagPairs + 1u) {
           const float q1i = Ui - di, q1q = Uq - dq;
           B.qai = __builtin_fmaf(K.c1, q1i, -(K.c2 * B.q0i));
           B.qaq = __builtin_fmaf(K.c1, q1q, -(K.c2 * B.q0q));
@@ -279,13 +307,6 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
         B.dph += 1u;
       }
     }
-    {
-      const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(B.qai), __builtin_fabsf(B.qaq)),
-                                        __builtin_fmaxf(__builtin_fabsf(B.qbi), __builtin_fabsf(B.qbq)));
-      const bool steady = B.dph >= 2u;
-      if (steady & (big < 1.0e-20f)) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }
-      X.zlive = __builtin_amdgcn_ballot_w64(!steady | (big >= 1.0e-20f)) ? 1u : 0u;
-    }
     if (PA) {
       ph = ph_u; amp = amp_u;
       const uint32_t changed = (__builtin_bit_cast(uint32_t, wi) ^ __builtin_bit_cast(uint32_t, Ui)) |
@@ -294,12 +315,34 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
     } else {
       ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
     }
+    {
+      // a correction that has decayed below 2^-28 of the magnitude it corrects is retired to exactly zero (both decay at
+      // the low-pass's own rate at least, so it stays negligible; a rule of the stream's own values only, so every kernel
+      // and every chunking retires it at the same decimated sample)
+      const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(B.qai), __builtin_fabsf(B.qaq)),
+                                        __builtin_fmaxf(__builtin_fabsf(B.qbi), __builtin_fabsf(B.qbq)));
+      const bool steady = B.dph >= kDirectPairs;
+      const bool small = big < amp * 3.7252902984619141e-09f;
+      if (steady & small) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }
+      X.zlive = __builtin_amdgcn_ballot_w64(!steady | !small) ? 1u : 0u;
+    }
   } else if (PA) {
     ph = ph_u; amp = amp_u;
   } else {
     ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
   }
   // ---- discriminator (fsk.ts:251-264)
+  // Math.atan2(0, 0) = 0 is a convention of the reference's frame: an exactly-zero I/Q pair sum (digital silence through
+  // zero-started filters: lead-ins, long gaps) has the reference's phase 0, which in the free-running frame is thf --
+  // otherwise a resetState() inside such silence would feed the post filter a spurious step of w*n0, and its decaying
+  // response would put bits into the silence that the reference does not see (found by tools/soak.py).  Arithmetic
+  // select: zf = 1 exactly when the scaled magnitude is the 1e-37 guard alone, 0 from 2e-37 on.
+  {
+    float zf;
+    asm("v_fma_f32 %0, %1, %2, 2.0 clamp" : "=v"(zf) : "v"(amp), "v"(K.zk));
+    ph = __builtin_fmaf(zf, B.thf, (1.0f - zf) * ph);
+  }
+  amp *= K.unscale;                                            // the reference's magnitude (0 for the guard alone)
   float dphi = ph - B.last_phase;
   {
     // wrap into (-pi, pi] (fsk.ts:255-257): |dphi| < 2 pi, so one rounded quotient does both branches; rounding to
@@ -320,6 +363,15 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   }
   // slicer (fsk.ts:264): f > 0  <=>  sign bit of 0 - f  (f = +-0 gives +0, i.e. bit 0)
   const uint32_t bit = sign_bit(__builtin_bit_cast(uint32_t, 0.0f - f));
+  if (TRC) {
+    if (S.trace_stream != 0xFFFFFFFFu && M.voff == S.trace_stream * 4u) {
+      const uint32_t kk = *S.trace_n;
+      if (kk < S.trace_cap) {
+        S.trace_amp[kk] = (double)amp; S.trace_post[kk] = (double)f; S.trace_bit[kk] = (uint8_t)bit;
+      }
+      *S.trace_n = kk + 1;
+    }
+  }
 
   // ---- processDownsampledBit (fsk.ts:278-344)
   const uint32_t qn = K.qn, mask = K.mask;
@@ -347,7 +399,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
     if (eod) {                                                 // fsk.ts:288-291
       ist_store(M, IF_eod_total, ist_load(M, IF_eod_total) + 1u);
       if (eod_counts && M.voff < 0xFFFFFFF0u) eod_counts[M.voff >> 2] += 1u;
-      back_reset<UNI>(B, P, M, X, inc);
+      back_reset<UNI>(B, P, M, X, inc, lane);
       did_reset = true;
     }
     // ring length >= preamble window? (fsk.ts:302); ring_len / amp_len in HBM hold the launch-start values
@@ -412,11 +464,11 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
       }
     }
     if (__builtin_amdgcn_ballot_w64(bad_start)) {
-      if (bad_start) back_reset<UNI>(B, P, M, X, inc);
+      if (bad_start) back_reset<UNI>(B, P, M, X, inc, lane);
       did_reset = true;
     }
   }
-  if (__builtin_amdgcn_ballot_w64(did_reset)) { X.direct = 2u; X.zlive = 1u; }
+  if (__builtin_amdgcn_ballot_w64(did_reset)) { X.direct = kDirectPairs; X.zlive = 1u; }
 }
 
 // ---- state arrays <-> registers ------------------------------------------------------------------------------
@@ -474,9 +526,9 @@ __device__ inline void front_load(FrontLane &F, FrontK &K, const DemodParams &P,
   K.step_k = 1099511627776.0f; K.step_b = -549755813888.0f;
   K.g_lo = 0.1f; K.g_hi = 10.0f;
   if (UNI) {
-    K.bp_b0 = P.u_bp_b0h; K.bp_na1 = P.u_bp_na1; K.bp_na2 = P.u_bp_na2;
+    K.bp_b0 = P.u_bp_b0h * kIqScale; K.bp_na1 = P.u_bp_na1; K.bp_na2 = P.u_bp_na2;
   } else {
-    K.bp_b0 = (float)(PIPE_CLOAD(CF_bp_b0) * (0.5 * P.lp_b0));
+    K.bp_b0 = (float)(PIPE_CLOAD(CF_bp_b0) * (0.5 * P.lp_b0)) * kIqScale;
     K.bp_na1 = -(float)PIPE_CLOAD(CF_bp_a1); K.bp_na2 = -(float)PIPE_CLOAD(CF_bp_a2);
   }
   K.lp_a2 = P.f_lp_a2; K.lp_nd = -P.f_lp_delta;
@@ -496,6 +548,12 @@ __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, co
   B.q0i = PIPE_RLOAD(zq_0i); B.q0q = PIPE_RLOAD(zq_0q);
   B.px1 = PIPE_RLOAD(po_x1); B.px2 = PIPE_RLOAD(po_x2); B.py = PIPE_RLOAD(po_y1); B.pv = PIPE_RLOAD(po_y2);
   B.last_phase = PIPE_RLOAD(last_phase);
+  {
+    const uint64_t off = ((uint64_t)PIPE_ILOAD(fr_hi) << 32) | PIPE_ILOAD(fr_lo);
+    double r = (double)(0ull - off) * 5.42101086242752217e-20 * 6.283185307179586476925;   // as back_reset computes it
+    r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
+    B.thf = (float)r;
+  }
   B.thr = PIPE_RLOAD(sil_thr);
   B.dph = PIPE_ILOAD(zr_dph);
   B.dix1 = PIPE_RLOAD(zd_ix1); B.dix2 = PIPE_RLOAD(zd_ix2); B.diy = PIPE_RLOAD(zd_iy); B.dvi = PIPE_RLOAD(zd_iv);
@@ -528,8 +586,8 @@ __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, co
   K.c1 = P.z_c1; K.c2 = P.z_c2;
   K.lp_b0 = P.f_lp_b0; K.lp_a2 = P.f_lp_a2; K.lp_nd = -P.f_lp_delta;
   K.qn = ~(uint32_t)P.pat_q; K.mask = (uint32_t)P.pat_mask; K.d = P.d;
-  K.tiny = 1.0e-37f; K.sgn = 0x80000000u; K.edge_min = (1u << P.stop_pos) - 2u; K.eod_m1 = P.eod_min - 1u;
-  asm volatile("" : "+v"(K.edge_min), "+v"(K.eod_m1));
+  K.tiny = 1.0e-37f; K.sgn = 0x80000000u; K.edge_min = (1u << P.stop_pos) - 2u; K.eod_m1 = P.eod_min - 1u; K.zk = -1.0e37f; K.unscale = kIqUnscale;
+  asm volatile("" : "+v"(K.edge_min), "+v"(K.eod_m1), "+v"(K.zk), "+v"(K.unscale));
   asm volatile("" : "+v"(K.c1), "+v"(K.c2), "+v"(K.lp_b0), "+v"(K.lp_a2), "+v"(K.lp_nd), "+v"(K.qn), "+v"(K.mask), "+v"(K.d));
   asm volatile("" : "+v"(K.tiny), "+v"(K.sgn));
 }
@@ -596,7 +654,7 @@ __device__ inline void lds_post(uint32_t *p, uint32_t v) {
 
 // ================================================================================================================
 // Two waves per 64-stream group.
-// LDS: stage [4][65] v4f | ring [kPipeSlots][6][64] v4f | fin [2][64] v4f | zt [2][8] v4f | poly [d][64] u32 | counters
+// LDS: stage [4][65] v4f | ring [kPipeSlots][6][64] v4f | fin [2][64] v4f | zt [2][8] v4f | poly [d][64] u32 | counters | zmail [64] u32
 // ================================================================================================================
 template <bool WB, bool UNI>
 __global__ __launch_bounds__(128) void demod_pipe_kernel(
@@ -610,6 +668,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
   v4f *zt = fin + 2 * 64;                                 // NCO phasors of two tiles: [2][16 samples] x (cos, sin)
   uint32_t *poly = reinterpret_cast<uint32_t *>(zt + 2 * 8);
   uint32_t *ctr = poly + 64u * P.d;                       // [0] tiles produced, [1] tiles consumed
+  uint32_t *zmail = ctr + 4;                              // [64] back -> front: where to zero a lane's I/Q low-pass
   uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
 
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -621,6 +680,11 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
   const uint64_t free0 = pipe_free0<UNI>(C);
 
   if (threadIdx.x == 0) { ctr[0] = 0; ctr[1] = 0; }
+  if (wave == 0) {
+    const FastMem &M = C.M;
+    const uint32_t fld = C.fld, row4 = C.row4;
+    zmail[lane] = zmail_init(PIPE_ILOAD(zr_dph));
+  }
   __syncthreads();
 
   if (wave == 0) {
@@ -705,6 +769,10 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
         for (uint32_t cc = 0; cc < 2; cc++) {
           const uint32_t c = 2u * hf + cc;
           const v4f x4 = stage[c * kSlotStride + lane];     // written by this wave: a wave's ds ops are ordered
+          // a reset the back wave has seen: zero this lane's filters in front of decimated sample zj (rare; two scalar
+          // branches per four samples otherwise)
+          const uint32_t zj = zmail[lane], pb = 4u * hidx + 2u * cc;
+          const bool zh = __builtin_amdgcn_ballot_w64(zj - pb < 2u) != 0;
           float zc[4], zs[4];
           if (UNI) {
             const v4f z01 = ztile[c * 2u], z23 = ztile[c * 2u + 1u];   // same address in every lane: LDS broadcast
@@ -721,7 +789,10 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
           const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
           float xs[4], y[4], oi[4], oq[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) front_sample(F, K, xin[j], zc[j], zs[j], xs[j], y[j], oi[j], oq[j]);
+          for (int j = 0; j < 4; j++) {
+            if (!(j & 1) && zh) front_zero(F, zj == pb + (uint32_t)(j >> 1));
+            front_sample(F, K, xin[j], zc[j], zs[j], xs[j], y[j], oi[j], oq[j]);
+          }
           const float u0i = oi[0] + oi[1], u0q = oq[0] + oq[1], u1i = oi[2] + oi[3], u1q = oq[2] + oq[3];
           // the discriminator's phase / magnitude of the uncorrected pair sums, speculatively (see back_pair)
           float am0, am1;
@@ -768,10 +839,9 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
     const uint32_t fld = C.fld, row4 = C.row4;
     for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
     BackU X;
-    X.k = 0; X.kv = 0; X.free0 = free0;
-    X.direct = __builtin_amdgcn_ballot_w64(B.dph < 2u) ? 2u : 0u;
-  X.zlive = __builtin_amdgcn_ballot_w64((B.dph < 2u) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
-    X.zlive = __builtin_amdgcn_ballot_w64((B.dph < 2u) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
+    X.k = 0; X.kv = 0; X.free0 = free0; X.zmail = zmail;
+    X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) ? kDirectPairs : 0u;
+    X.zlive = __builtin_amdgcn_ballot_w64((B.dph < kDirectPairs) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
     asm volatile("" : "+v"(X.kv));
     X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
     const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
@@ -827,7 +897,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
 
 // ================================================================================================================
 // One wave per 64-stream group: the same two halves, pair by pair through registers.
-// LDS: stage [4][65] v4f | zt [2][8] v4f | poly [d][64] u32
+// LDS: stage [4][65] v4f | zt [2][8] v4f | poly [d][64] u32 | zmail [64] u32
 // ================================================================================================================
 template <bool WB, bool UNI>
 __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
@@ -838,6 +908,7 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
   v4f *stage = reinterpret_cast<v4f *>(lds);
   v4f *zt = stage + 4 * kSlotStride;
   uint32_t *poly = reinterpret_cast<uint32_t *>(zt + 2 * 8);
+  uint32_t *zmail = poly + 64u * P.d;
   uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
   const uint32_t lane = threadIdx.x;
   const uint32_t stream = blockIdx.x * 64u + lane;
@@ -860,9 +931,10 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
   }
   for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
   BackU X;
-  X.k = 0; X.kv = 0; X.free0 = free0;
-  X.direct = __builtin_amdgcn_ballot_w64(B.dph < 2u) ? 2u : 0u;
-  X.zlive = __builtin_amdgcn_ballot_w64((B.dph < 2u) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
+  X.k = 0; X.kv = 0; X.free0 = free0; X.zmail = zmail;
+  zmail[lane] = zmail_init(B.dph);
+  X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) ? kDirectPairs : 0u;
+  X.zlive = __builtin_amdgcn_ballot_w64((B.dph < kDirectPairs) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
   asm volatile("" : "+v"(X.kv));
   X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
   const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
@@ -941,9 +1013,12 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
       }
       const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
       float xs[4];
+      const uint32_t zj = zmail[lane], pb = X.k;               // see demod_pipe_kernel
+      const bool zh = __builtin_amdgcn_ballot_w64(zj - pb < 2u) != 0;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         float y0, y1, oi0, oq0, oi1, oq1;
+        if (zh) front_zero(F, zj == pb + (uint32_t)h);
         front_sample(F, FK, xin[2 * h], zc[2 * h], zs[2 * h], xs[2 * h], y0, oi0, oq0);
         front_sample(F, FK, xin[2 * h + 1], zc[2 * h + 1], zs[2 * h + 1], xs[2 * h + 1], y1, oi1, oq1);
         X.k++;
@@ -976,7 +1051,7 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
 // state machine: fsk-demodulation.node.test.ts:363-398, 668-753), with the generic kernel left to the fp64 path, wide
 // or fractional rings, traces and batches that are not in lock step.
 // parity0: downsample.counter at the first sample (fsk.ts:106); the open pair's first low-pass outputs are acc_i / acc_q.
-// LDS: poly [d][64] u32
+// LDS: poly [d][64] u32 | zmail [64] u32
 // ================================================================================================================
 template <bool WB, bool UNI>
 __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
@@ -985,6 +1060,7 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
     uint32_t *__restrict__ eod_counts) {
   extern __shared__ float4 lds[];
   uint32_t *poly = reinterpret_cast<uint32_t *>(lds);
+  uint32_t *zmail = poly + 64u * P.d;
   uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
   const uint32_t lane = threadIdx.x;
   const uint32_t stream = blockIdx.x * 64u + lane;
@@ -1003,10 +1079,11 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
   back_load<UNI>(B, BK, P, S, C, stream, out_counts, eod_counts, append);
   for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
   BackU X;
-  X.k = 0; X.kv = 0;
+  X.k = 0; X.kv = 0; X.zmail = zmail;
+  zmail[lane] = zmail_init(B.dph);
   X.free0 = free0 - (parity0 ? inc : 0ull);             // decimated sample 0 of this launch starts one sample early then
-  X.direct = __builtin_amdgcn_ballot_w64(B.dph < 2u) ? 2u : 0u;
-  X.zlive = __builtin_amdgcn_ballot_w64((B.dph < 2u) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
+  X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) ? kDirectPairs : 0u;
+  X.zlive = __builtin_amdgcn_ballot_w64((B.dph < kDirectPairs) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
   asm volatile("" : "+v"(X.kv));
   X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
   const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
@@ -1022,6 +1099,7 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
     const float xin = C.valid ? xrow[t] : 0.f;
     float zc, zs, xs, y, oi, oq;
     nco_phasor(free0 + inc * (uint64_t)t, zc, zs);
+    if (par == 0) front_zero(F, zmail[lane] == X.k);     // first sample of decimated sample number X.k
     front_sample(F, FK, xin, zc, zs, xs, y, oi, oq);
     if (WB) { if (C.valid) xrow[t] = xs; }
     if (par == 0) {
@@ -1033,8 +1111,8 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
       X.kv += 1u;
       const uint32_t r_old = poly[X.phase * 64u + lane];
       const float ypr[2] = {F.by2, F.by1};               // the pair's two pre-filter outputs
-      back_pair<UNI>(B, BK, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, acc_i + oi, acc_q + oq,
-                     ypr, r_old, inc);
+      back_pair<UNI, false, true>(B, BK, P, S, M, poly, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, acc_i + oi,
+                                  acc_q + oq, ypr, r_old, inc);
       X.amp_soff += amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
       X.phase = (X.phase + 1 == P.d) ? 0u : X.phase + 1;
       acc_i = 0.f; acc_q = 0.f;
@@ -1048,9 +1126,9 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 size_t demod_pipe_lds_bytes(const DemodParams &P) {
-  return sizeof(float4) * (4 * kSlotStride + kPipeSlots * kSlotV4 + 2 * 64 + 2 * 8) + sizeof(uint32_t) * (64u * P.d + 4u);
+  return sizeof(float4) * (4 * kSlotStride + kPipeSlots * kSlotV4 + 2 * 64 + 2 * 8) + sizeof(uint32_t) * (64u * P.d + 4u + 64u);
 }
-size_t demod_fused_lds_bytes(const DemodParams &P) { return sizeof(float4) * (4 * kSlotStride + 2 * 8) + sizeof(uint32_t) * 64u * P.d; }
+size_t demod_fused_lds_bytes(const DemodParams &P) { return sizeof(float4) * (4 * kSlotStride + 2 * 8) + sizeof(uint32_t) * 64u * (P.d + 1u); }
 
 hipError_t set_pipe_lds_limit(size_t pipe_bytes) {
   hipError_t e = hipSuccess;
@@ -1097,7 +1175,7 @@ hipError_t launch_demod_tail(bool writeback, bool append, int parity0, const Dem
                              float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream) {
   const uint32_t blocks = (P.n_streams + 63u) / 64u;
-  const size_t lds = sizeof(uint32_t) * 64u * P.d;
+  const size_t lds = sizeof(uint32_t) * 64u * (P.d + 1u);
 #define FSK_LAUNCH_TAIL(WBV, UNIV)                                                                          \
   hipLaunchKernelGGL((demod_tail_kernel<WBV, UNIV>), dim3(blocks), dim3(64), lds, stream, P, S, samples, n, pitch, \
                      parity0, append ? 1 : 0, out, out_pitch, out_counts, eod_counts)
