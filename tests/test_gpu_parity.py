@@ -102,6 +102,33 @@ def test_intermediates_match_reference(name, pname, prec, tol):
     eng.close()
 
 
+def test_digital_silence_stays_exactly_silent_across_resets():
+    """The reference's discriminator gives phase 0 for an exactly-zero I/Q pair (Math.atan2(0, 0), fsk.ts:251), so digital
+    silence stays f = 0, bit = 0 through every 'eod' resetState().  The fp32 whole-tile arithmetic keeps its I/Q branch in a
+    frame that is NOT reset, where that phase 0 is the frame's offset -- exact only if its branch-free atan2 returns
+    exactly +-0 for (0, 0) (fsk_pipe.hip: atan2_amp_fma), which is a property of the device's v_rcp_f32 / v_sqrt_f32 on
+    powers of two; this pins it.  Then a frame after 3000 samples of such silence must decode."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    cfg = {}
+    o = po.OracleCore(cfg)
+    payload = bytes(range(40, 60))
+    sig = o.modulate(payload)
+    lead = 3000                                   # ten 'eod' resets (280 samples each) inside the silence
+    x = np.concatenate([np.zeros(lead, np.float32), sig, np.zeros(600, np.float32)]).astype(np.float32)
+    eng = wm.FSKEngine(64, cfg, precision=wm.PRECISION_F32)
+    eng.trace_enable(5, len(x))
+    out, eod = eng.demodulate_data(np.tile(x, (64, 1)))
+    assert "tail" in eng.last_kernel()            # a traced engine: fsk_pipe.hip's arithmetic, sample by sample
+    tr = eng.trace_read()
+    k = lead // 2
+    assert int(eod[5]) >= 10
+    assert np.all(tr["amp"][:k] == 0.0) and np.all(tr["post_out"][:k] == 0.0) and not tr["bit"][:k].any()
+    ob, oe = o.demodulate(x)
+    assert out[5] == ob == payload and int(eod[5]) == oe
+    eng.close()
+
+
 @pytest.mark.parametrize("pname,prec,tol", PRECISIONS)
 def test_offset_sweep_batched(pname, prec, tol):
     """fsk-demodulation.node.test.ts:668-716 -- all 128 chunk offsets, here as 128 streams of ONE

@@ -75,7 +75,7 @@ struct FrontK {                   // all in VGPRs: an SGPR operand halves a vect
   float g_lo, g_hi;              // 0.1, 10
   float bp_b0, bp_na1, bp_na2;   // pre-filter: y = b0*(x - x2) - a2*y2 - a1*y1; b0 carries the low-pass gain b0/2 and kIqScale
   float lp_a2, lp_nd;            // low-pass a2, -(1 + a1 + a2)
-  float tiny; uint32_t sgn;      // 1e-37f, 0x80000000 (atan2_amp_fma)
+  float tiny; uint32_t sgn;      // 2^-123, 0x80000000 (atan2_amp_fma)
 };
 
 // one input sample: returns the AGC'd sample (write-back), the pre-filter output and the I/Q low-pass outputs
@@ -125,9 +125,11 @@ __device__ inline uint32_t zmail_init(uint32_t dph) { return dph <= kZeroLagPair
 //   atan(|y|/|x|) = pi/4 + atan(u),  u = (|y| - |x|) / (|y| + |x|) in [-1, 1]      (no octant swap)
 //   |(x, y)| = (|x| + |y|) * sqrt((1 + u^2) / 2)                                     (cannot underflow: see fsk_dev.h)
 //   quadrant: pi/2 + ((atan(u) - pi/4) XOR signbit(x)), then OR signbit(y)
-// |x| carries +1e-37 so that (0, 0) gives u = -1, i.e. angle 0 like Math.atan2(0, 0), without a guard instruction.
-// Same odd minimax polynomial as fsk_dev.h's atan2_amp_fast (|error| <= 1.5e-7 rad on [-1, 1]).
-// tiny = 1e-37f and sgn = 0x80000000 arrive in VGPRs: as literals they would be hoisted into SGPRs (VOP3 cannot
+// |x| carries +2^-123 so that (0, 0) gives u = -1 exactly (the reciprocal of a power of two is exact), without a guard
+// instruction; the polynomial's leading coefficient is nudged so that atan(-1) evaluates to -fl(pi/4) bit for bit, and
+// with fl(pi/2) = 2 fl(pi/4) the angle of (0, 0) is then exactly +-0 like Math.atan2(0, 0) (tests/test_gpu_parity.py
+// checks that on the device).  Otherwise fsk_dev.h's odd minimax polynomial (|error| <= 1.6e-7 rad on [-1, 1]).
+// tiny = 2^-123 and sgn = 0x80000000 arrive in VGPRs: as literals they would be hoisted into SGPRs (VOP3 cannot
 // encode a literal), and an SGPR operand halves the instruction's rate.
 __device__ inline float atan2_amp_fma(float y, float x, float &amp, float tiny, uint32_t sgn) {
   x = x + 0.0f;                                        // -0 counts as +0 (the reference's averages are never -0)
@@ -137,7 +139,7 @@ __device__ inline float atan2_amp_fma(float y, float x, float &amp, float tiny, 
   const float u = (ay - axp) * __builtin_amdgcn_rcpf(sm);
   const float s = u * u;
   amp = sm * __builtin_amdgcn_sqrtf(__builtin_fmaf(s, 0.5f, 0.5f));
-  float p = -4.355408570e-03f;
+  float p = -4.3553458527e-03f;   // (nudged by 135 ulp: see above)
   p = __builtin_fmaf(p, s, 2.304014596e-02f);
   p = __builtin_fmaf(p, s, -5.777360382e-02f);
   p = __builtin_fmaf(p, s, 9.794235514e-02f);
@@ -188,10 +190,10 @@ struct BackK {                    // VGPRs, like FrontK
   float lp_b0, lp_a2, lp_nd;     // post filter: b0, a2, -(1 + a1 + a2)
   uint32_t qn, mask;             // ~pattern, window mask (bits 1 .. nBits-1)
   uint32_t d;                    // downsampledSamplesPerBit
-  float tiny; uint32_t sgn;      // 1e-37f, 0x80000000 (atan2_amp_fma)
+  float tiny; uint32_t sgn;      // 2^-123, 0x80000000 (atan2_amp_fma)
   uint32_t edge_min;             // (1 << stop_pos) - 2: sreg - 2 >= edge_min (unsigned) <=> start or stop position
   uint32_t eod_m1;               // samplesForEOD - 1
-  float zk;                      // -1e37: clamp(2 + zk * |w|) = [the I/Q pair sum is exactly (0, 0)] (its scaled magnitude is the 1e-37 guard)
+  float zk;                      // -2^123: clamp(2 + zk * |w|) = [the I/Q pair sum is exactly (0, 0)] (its scaled magnitude is the 2^-123 guard)
   float unscale;                 // 2^-60
 };
 struct BackU {                   // wave-uniform context of one decimated sample
@@ -243,10 +245,9 @@ __device__ inline void nco_phasor(uint64_t acc, float &c, float &s) {
 
 // One decimated sample: ZIR correction, discriminator (fsk.ts:245-264), processDownsampledBit (fsk.ts:278-344),
 // processByte (346-375).  ypair: LDS address of this pair's two pre-filter outputs (read by the direct instance only).
-// PA: the front wave has evaluated the discriminator's phase / magnitude on U already (ph_u, amp_u); they stand unless the
-// correction changed a bit of U in some lane (w == U bit for bit wherever q has decayed below half an ulp of U, i.e. from
-// ~40 decimated samples after a reset on), in which case the wave re-evaluates -- same function, same inputs where
-// nothing changed, so the result does not depend on which wave computed it.
+// PA: the front wave has evaluated the discriminator's phase / magnitude on U already (ph_u, amp_u); otherwise this
+// function does.  They stand unless the correction changed a bit of U in some lane, in which case the wave re-evaluates --
+// same function, same inputs where nothing changed, so the result does not depend on which wave computed it.
 // TRC: honour fskhip_trace_enable (the sample-granular kernel only; a traced engine runs entirely on it).
 template <bool UNI, bool PA = false, bool TRC = false>
 __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams &P, const DemodState &S, const FastMem &M,
@@ -255,10 +256,14 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
                                  const float *ypair, uint32_t r_old, uint64_t inc, float ph_u = 0.f, float amp_u = 0.f) {
   // ---- ZIR correction: w = U - q, q advances by its two-term recurrence.  Skipped (exactly: U - 0 = U) while no lane of
   // the wave carries a correction.
-  float wi = Ui, wq = Uq;
+  // Phase and magnitude are evaluated on U first (by the front wave already, in the two-wave kernel) and stand unless the
+  // correction changes a bit of U in some lane; so the common path has no else-branch for the register allocator to park
+  // the correction's state copies in.
   float amp, ph;
-  if (X.zlive) {
-    wi = Ui - B.qai; wq = Uq - B.qaq;
+  if (PA) { ph = ph_u; amp = amp_u; }
+  else ph = atan2_amp_fma(Uq, Ui, amp, K.tiny, K.sgn);
+  if (__builtin_expect(X.zlive != 0u, 0)) {
+    float wi = Ui - B.qai, wq = Uq - B.qaq;
     {
       const float ni = __builtin_fmaf(K.c1, B.qbi, -(K.c2 * B.qai));
       const float nq = __builtin_fmaf(K.c1, B.qbq, -(K.c2 * B.qaq));
@@ -266,7 +271,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
     }
     // ---- rare: the decimated samples after a reset come from the zero-started instance; its last two (the first two
     // after the front has zeroed its filters) also yield q's start values
-    if (X.direct) {
+    if (__builtin_expect(X.direct != 0u, 0)) {
       X.direct--;
       if (B.dph < kDirectPairs) {
         const float y0 = ypair[0], y1 = ypair[1];
@@ -307,13 +312,10 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
         B.dph += 1u;
       }
     }
-    if (PA) {
-      ph = ph_u; amp = amp_u;
+    {
       const uint32_t changed = (__builtin_bit_cast(uint32_t, wi) ^ __builtin_bit_cast(uint32_t, Ui)) |
                                (__builtin_bit_cast(uint32_t, wq) ^ __builtin_bit_cast(uint32_t, Uq));
       if (__builtin_amdgcn_ballot_w64(changed != 0u)) ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
-    } else {
-      ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
     }
     {
       // a correction that has decayed below 2^-28 of the magnitude it corrects is retired to exactly zero (both decay at
@@ -322,25 +324,21 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
       const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(B.qai), __builtin_fabsf(B.qaq)),
                                         __builtin_fmaxf(__builtin_fabsf(B.qbi), __builtin_fabsf(B.qbq)));
       const bool steady = B.dph >= kDirectPairs;
-      const bool small = big < amp * 3.7252902984619141e-09f;
+      const bool small = !(big > amp * 3.7252902984619141e-09f);   // (<=: a zero correction under the bare (0, 0) guard retires too)
       if (steady & small) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }
       X.zlive = __builtin_amdgcn_ballot_w64(!steady | !small) ? 1u : 0u;
     }
-  } else if (PA) {
-    ph = ph_u; amp = amp_u;
-  } else {
-    ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
   }
   // ---- discriminator (fsk.ts:251-264)
   // Math.atan2(0, 0) = 0 is a convention of the reference's frame: an exactly-zero I/Q pair sum (digital silence through
   // zero-started filters: lead-ins, long gaps) has the reference's phase 0, which in the free-running frame is thf --
   // otherwise a resetState() inside such silence would feed the post filter a spurious step of w*n0, and its decaying
   // response would put bits into the silence that the reference does not see (found by tools/soak.py).  Arithmetic
-  // select: zf = 1 exactly when the scaled magnitude is the 1e-37 guard alone, 0 from 2e-37 on.
+  // select: zf = 1 exactly when the scaled magnitude is the 2^-123 guard alone, 0 from twice that on.
   {
     float zf;
     asm("v_fma_f32 %0, %1, %2, 2.0 clamp" : "=v"(zf) : "v"(amp), "v"(K.zk));
-    ph = __builtin_fmaf(zf, B.thf, (1.0f - zf) * ph);
+    ph = __builtin_fmaf(zf, B.thf, ph);                        // (ph is exactly +-0 there)
   }
   amp *= K.unscale;                                            // the reference's magnitude (0 for the guard alone)
   float dphi = ph - B.last_phase;
@@ -393,7 +391,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   const uint32_t m1 = B.matched - B.thr_eff;                   // >= 0 (as int32) <=> matched >= thr_eff
 
   bool did_reset = false;
-  if (__builtin_amdgcn_ballot_w64((int32_t)(e1 | ~m1) < 0)) {
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)(e1 | ~m1) < 0) != 0, 0)) {
     const bool eod = (int32_t)e1 < 0;
     const bool cand = ((int32_t)m1 >= 0) & (B.rho == X.k % P.cadence);   // globalSampleCounter % round(dsSPB/4) == 0
     if (eod) {                                                 // fsk.ts:288-291
@@ -463,12 +461,12 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
         B.sreg = s0;
       }
     }
-    if (__builtin_amdgcn_ballot_w64(bad_start)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad_start) != 0, 0)) {
       if (bad_start) back_reset<UNI>(B, P, M, X, inc, lane);
       did_reset = true;
     }
   }
-  if (__builtin_amdgcn_ballot_w64(did_reset)) { X.direct = kDirectPairs; X.zlive = 1u; }
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(did_reset) != 0, 0)) { X.direct = kDirectPairs; X.zlive = 1u; }
 }
 
 // ---- state arrays <-> registers ------------------------------------------------------------------------------
@@ -532,7 +530,7 @@ __device__ inline void front_load(FrontLane &F, FrontK &K, const DemodParams &P,
     K.bp_na1 = -(float)PIPE_CLOAD(CF_bp_a1); K.bp_na2 = -(float)PIPE_CLOAD(CF_bp_a2);
   }
   K.lp_a2 = P.f_lp_a2; K.lp_nd = -P.f_lp_delta;
-  K.tiny = 1.0e-37f; K.sgn = 0x80000000u;
+  K.tiny = 0x1p-123f; K.sgn = 0x80000000u;
   asm volatile("" : "+v"(K.tiny), "+v"(K.sgn));
   asm volatile("" : "+v"(K.att_m_rel), "+v"(K.rel), "+v"(K.step_k), "+v"(K.step_b), "+v"(K.g_lo), "+v"(K.g_hi));
   asm volatile("" : "+v"(K.bp_b0), "+v"(K.bp_na1), "+v"(K.bp_na2), "+v"(K.lp_a2), "+v"(K.lp_nd));
@@ -586,7 +584,7 @@ __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, co
   K.c1 = P.z_c1; K.c2 = P.z_c2;
   K.lp_b0 = P.f_lp_b0; K.lp_a2 = P.f_lp_a2; K.lp_nd = -P.f_lp_delta;
   K.qn = ~(uint32_t)P.pat_q; K.mask = (uint32_t)P.pat_mask; K.d = P.d;
-  K.tiny = 1.0e-37f; K.sgn = 0x80000000u; K.edge_min = (1u << P.stop_pos) - 2u; K.eod_m1 = P.eod_min - 1u; K.zk = -1.0e37f; K.unscale = kIqUnscale;
+  K.tiny = 0x1p-123f; K.sgn = 0x80000000u; K.edge_min = (1u << P.stop_pos) - 2u; K.eod_m1 = P.eod_min - 1u; K.zk = -0x1p123f; K.unscale = kIqUnscale;
   asm volatile("" : "+v"(K.edge_min), "+v"(K.eod_m1), "+v"(K.zk), "+v"(K.unscale));
   asm volatile("" : "+v"(K.c1), "+v"(K.c2), "+v"(K.lp_b0), "+v"(K.lp_a2), "+v"(K.lp_nd), "+v"(K.qn), "+v"(K.mask), "+v"(K.d));
   asm volatile("" : "+v"(K.tiny), "+v"(K.sgn));
@@ -765,14 +763,15 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
         }
         v4f *slot = ring + slot_i * kSlotV4;
         slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
+        // a reset the back wave has seen: zero this lane's filters in front of decimated sample zj (rare; one compare per
+        // half tile and two scalar branches per four samples otherwise)
+        const uint32_t zj = zmail[lane];
+        const uint32_t zh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(zj - 4u * hidx < 4u) != 0));
 #pragma unroll 1
         for (uint32_t cc = 0; cc < 2; cc++) {
           const uint32_t c = 2u * hf + cc;
           const v4f x4 = stage[c * kSlotStride + lane];     // written by this wave: a wave's ds ops are ordered
-          // a reset the back wave has seen: zero this lane's filters in front of decimated sample zj (rare; two scalar
-          // branches per four samples otherwise)
-          const uint32_t zj = zmail[lane], pb = 4u * hidx + 2u * cc;
-          const bool zh = __builtin_amdgcn_ballot_w64(zj - pb < 2u) != 0;
+          const uint32_t pb = 4u * hidx + 2u * cc;
           float zc[4], zs[4];
           if (UNI) {
             const v4f z01 = ztile[c * 2u], z23 = ztile[c * 2u + 1u];   // same address in every lane: LDS broadcast
@@ -788,10 +787,16 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
           }
           const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
           float xs[4], y[4], oi[4], oq[4];
+          if (__builtin_expect(zh != 0u, 0)) {   // (its own copy of the four samples: the common one carries no per-lane test)
+            asm volatile("s_nop 0");
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (!(j & 1) && zh) front_zero(F, zj == pb + (uint32_t)(j >> 1));
-            front_sample(F, K, xin[j], zc[j], zs[j], xs[j], y[j], oi[j], oq[j]);
+            for (int j = 0; j < 4; j++) {
+              if (!(j & 1)) front_zero(F, zj == pb + (uint32_t)(j >> 1));
+              front_sample(F, K, xin[j], zc[j], zs[j], xs[j], y[j], oi[j], oq[j]);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) front_sample(F, K, xin[j], zc[j], zs[j], xs[j], y[j], oi[j], oq[j]);
           }
           const float u0i = oi[0] + oi[1], u0q = oq[0] + oq[1], u1i = oi[2] + oi[3], u1q = oq[2] + oq[3];
           // the discriminator's phase / magnitude of the uncorrected pair sums, speculatively (see back_pair)
@@ -987,6 +992,14 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
     } else {
       nco_phasor(free0 + inc * (uint64_t)t0, zr, zi);
     }
+    // a reset some lane has seen: zero its filters in front of decimated sample zj (see demod_pipe_kernel; posted at
+    // least kZeroLagPairs = 16 decimated samples ahead, so one look per tile is early enough)
+    const uint32_t zj = zmail[lane];
+#ifdef FSK_EXP_NOZ
+    const uint32_t zh = 0;
+#else
+    const uint32_t zh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(zj - X.k < 8u) != 0));
+#endif
     __syncthreads();
     {
       const uint32_t tn = (uint32_t)((t0 + kFastTile < n ? t0 + kFastTile : t0) * 4u);
@@ -1013,12 +1026,11 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
       }
       const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
       float xs[4];
-      const uint32_t zj = zmail[lane], pb = X.k;               // see demod_pipe_kernel
-      const bool zh = __builtin_amdgcn_ballot_w64(zj - pb < 2u) != 0;
+      const uint32_t pb = X.k;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         float y0, y1, oi0, oq0, oi1, oq1;
-        if (zh) front_zero(F, zj == pb + (uint32_t)h);
+        if (__builtin_expect(zh != 0u, 0)) { asm volatile("s_nop 0"); front_zero(F, zj == pb + (uint32_t)h); }
         front_sample(F, FK, xin[2 * h], zc[2 * h], zs[2 * h], xs[2 * h], y0, oi0, oq0);
         front_sample(F, FK, xin[2 * h + 1], zc[2 * h + 1], zs[2 * h + 1], xs[2 * h + 1], y1, oi1, oq1);
         X.k++;
