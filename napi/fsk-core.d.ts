@@ -44,3 +44,13 @@ export class FSKBatch {
   getStatus(stream?: number): FSKStatus;
   close(): void;
 }
+/** one Node process, several GPUs: one FSKBatch per device over contiguous stream blocks, calls issued together */
+export class FSKBatchSharded {
+  constructor(nStreams: number, configs: Partial<FSKConfig> | Partial<FSKConfig>[], options?: { devices?: number[]; precision?: 0 | 1 });
+  readonly shards: { first: number; count: number; device: number; batch: FSKBatch }[];
+  demodulateData(samples: Float32Array, nPerStream: number, pitch?: number, writebackAgc?: boolean): Promise<{ bytes: Uint8Array[]; eod: Uint32Array }>;
+  modulateData(payloads: Uint8Array[]): Float32Array[];
+  reset(stream?: number): void;
+  getStatus(stream?: number): FSKStatus;
+  close(): void;
+}

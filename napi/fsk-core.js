@@ -153,4 +153,63 @@ class FSKBatch {
   close() { if (this.handle) { addon.destroy(this.handle); this.handle = null; } }
 }
 
-module.exports = { FSKCore, FSKBatch, DEFAULT_FSK_CONFIG, Event, EventEmitter, PRECISION_F32, PRECISION_F64, addon };
+// One Node process, several GPUs: one FSKBatch per device, each owning a contiguous block of streams (the layout of
+// webaudio_modem_amd/sharding.py: sizes differ by at most one), the per-device calls issued together as N-API async work
+// (libuv pool threads; every libfskhip entry point selects its engine's device).  No collective: streams are independent.
+class FSKBatchSharded {
+  // options.devices: device ordinals (default: all of addon.deviceCount()); options.precision as FSKBatch
+  constructor(nStreams, configs, options = {}) {
+    let devices = options.devices;
+    if (!devices) {
+      const n = addon.deviceCount();
+      devices = [];
+      for (let d = 0; d < Math.max(n, 1); d++) devices.push(d);   // n == 0: FSKBatch below fails loudly (no CPU path)
+    }
+    if (Array.isArray(configs) && configs.length !== nStreams) throw new Error('need one config per stream');
+    this.nStreams = nStreams;
+    this.shards = [];
+    const base = Math.floor(nStreams / devices.length), extra = nStreams % devices.length;
+    let first = 0;
+    try {
+      devices.forEach((device, r) => {
+        const count = base + (r < extra ? 1 : 0);
+        if (count > 0) {
+          const cfg = Array.isArray(configs) ? configs.slice(first, first + count) : configs;
+          this.shards.push({ first, count, device, batch: new FSKBatch(count, cfg, Object.assign({}, options, { device })) });
+        }
+        first += count;
+      });
+    } catch (e) {
+      this.close();
+      throw e;
+    }
+  }
+  locate(stream) {
+    for (const sh of this.shards) if (stream >= sh.first && stream < sh.first + sh.count) return [sh, stream - sh.first];
+    throw new Error('stream out of range');
+  }
+  // samples: Float32Array [S][pitch]; resolves with {bytes: Uint8Array[S], eod: Uint32Array(S)} in stream order
+  async demodulateData(samples, nPerStream, pitch, writebackAgc) {
+    const p = pitch || nPerStream;
+    const parts = await Promise.all(this.shards.map((sh) =>
+      sh.batch.demodulateDataAsync(samples.subarray(sh.first * p, (sh.first + sh.count) * p), nPerStream, p, writebackAgc)));
+    const bytes = [];
+    const eod = new Uint32Array(this.nStreams);
+    parts.forEach((r, i) => { r.bytes.forEach((b) => bytes.push(b)); eod.set(r.eod, this.shards[i].first); });
+    return { bytes, eod };
+  }
+  modulateData(payloads) {
+    if (payloads.length !== this.nStreams) throw new Error('need one payload per stream');
+    let out = [];
+    for (const sh of this.shards) out = out.concat(sh.batch.modulateData(payloads.slice(sh.first, sh.first + sh.count)));
+    return out;
+  }
+  reset(stream) {
+    if (stream === undefined || stream < 0) this.shards.forEach((sh) => sh.batch.reset());
+    else { const [sh, local] = this.locate(stream); sh.batch.reset(local); }
+  }
+  getStatus(stream) { const [sh, local] = this.locate(stream || 0); return sh.batch.getStatus(local); }
+  close() { this.shards.forEach((sh) => sh.batch.close()); this.shards = []; }
+}
+
+module.exports = { FSKCore, FSKBatch, FSKBatchSharded, DEFAULT_FSK_CONFIG, Event, EventEmitter, PRECISION_F32, PRECISION_F64, addon };

@@ -137,6 +137,32 @@ async function gpuTests() {
     }
     a.close(); b.close();
   }
+  // ---- FSKBatchSharded: three engines (all on device 0 here) driven together == one engine with all streams ----
+  {
+    const S = 50;
+    const cfg = { baudRate: 1200, markFrequency: 1200, spaceFrequency: 2200 };
+    const one = new M.FSKBatch(S, cfg), many = new M.FSKBatchSharded(S, cfg, { devices: [0, 0, 0] });
+    assert.deepStrictEqual(many.shards.map((x) => [x.first, x.count]), [[0, 17], [17, 17], [34, 16]]);
+    const payloads = [];
+    for (let k = 0; k < S; k++) payloads.push(s('sharded stream ' + k));
+    const sigs = many.modulateData(payloads);
+    one.modulateData(payloads).forEach((x, k) => assert.deepStrictEqual(Array.from(x), Array.from(sigs[k])));
+    const n = sigs.reduce((m, x) => Math.max(m, x.length), 0) + 64;
+    const buf = new Float32Array(S * n);
+    sigs.forEach((x, k) => buf.set(x, k * n));
+    const want = one.demodulateData(Float32Array.from(buf), n, n, false);
+    const got = await many.demodulateData(buf, n, n, false);
+    for (let k = 0; k < S; k++) {
+      assert.strictEqual(Buffer.from(got.bytes[k]).toString('ascii'), 'sharded stream ' + k);
+      assert.deepStrictEqual(Array.from(got.bytes[k]), Array.from(want.bytes[k]));
+    }
+    assert.deepStrictEqual(Array.from(got.eod), Array.from(want.eod));
+    assert.deepStrictEqual(many.getStatus(40), one.getStatus(40));
+    many.reset(40); one.reset(40);
+    assert.deepStrictEqual(many.getStatus(40), one.getStatus(40));
+    assert.throws(() => many.getStatus(50), /out of range/);
+    one.close(); many.close();
+  }
   // ---- FIR (tests/dsp/filters.node.test.ts:190-206: impulse response = taps) ----
   {
     const taps = [0.1, -0.2, 0.3, 0.25, -0.05];

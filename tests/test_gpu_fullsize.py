@@ -363,3 +363,50 @@ def test_odd_call_lengths_and_unaligned_buffers_stay_on_the_fp32_arithmetic(S):
         assert rows[s] == ob and int(eod[s]) == oe
     gen.device_free(d_x)
     gen.close()
+
+
+def test_one_process_several_engines_sharded_host_matches_one_engine():
+    """webaudio_modem_amd/sharded.py (one host process, one engine per device, calls fanned out on threads): on this
+    1-GPU box the three shards are three engines on device 0, driven concurrently from three threads -- the streams'
+    bytes, eod counts and status must be those of one engine holding the whole batch, on any chunk schedule."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    S = 200
+    cfg = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
+    rng = np.random.default_rng(0x5AAD)
+    o = po.OracleCore(cfg)
+    sigs = [np.concatenate([np.zeros(int(rng.integers(0, 400)), np.float32),
+                            o.modulate(bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))) * np.float32(rng.uniform(0.1, 1.0))])
+            for _ in range(S)]
+    N = max(len(v) for v in sigs) + 300
+    x = np.zeros((S, N), np.float32)
+    for s, v in enumerate(sigs):
+        x[s, :len(v)] = v
+    one = wm.FSKEngine(S, cfg)
+    many = wm.FSKEngineSharded(S, cfg, devices=[0, 0, 0])
+    assert [c for _, c, _ in many.shards] == [67, 67, 66]
+    got_one, got_many = [b""] * S, [b""] * S
+    eod_one, eod_many = np.zeros(S, np.int64), np.zeros(S, np.int64)
+    off = 0
+    for n in (1000, 17, 4096, 1, N):
+        n = min(n, N - off)
+        a, ea = one.demodulate_data(x[:, off:off + n].copy())
+        b, eb = many.demodulate_data(x[:, off:off + n].copy())
+        for s in range(S):
+            got_one[s] += a[s]
+            got_many[s] += b[s]
+        eod_one += ea
+        eod_many += eb
+        off += n
+    assert got_one == got_many and np.array_equal(eod_one, eod_many)
+    assert sum(len(v) for v in got_one) > 10 * S
+    for s in (0, 66, 67, 133, 134, 199):
+        assert many.get_status(s) == one.get_status(s)
+    many.reset(70)
+    one.reset(70)
+    assert many.get_status(70) == one.get_status(70)
+    pay = [bytes([s % 251] * (1 + s % 7)) for s in range(S)]
+    for u, v in zip(one.modulate_data(pay), many.modulate_data(pay)):
+        assert np.array_equal(u, v)
+    one.close()
+    many.close()

@@ -8,12 +8,13 @@ import webaudio_modem_amd as wm
 from oracle import pyoracle as po
 x = np.load(sys.argv[1]).astype(np.float32)
 cfg = json.loads(sys.argv[2])
+PER_STREAM = bool(cfg.pop("_per_stream", False))   # a list of S equal configs: the per-stream-constant kernel variants
 sched = [int(v) for v in sys.argv[3].split(",")]
 S = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 KEYS = ["frameStarted", "globalSampleCounter", "receivedBitsLength", "syncDetections", "silenceThreshold", "agcGain"]
 def run(name, env, prec):
     os.environ.update(env)
-    eng = wm.FSKEngine(S, cfg, precision=prec)
+    eng = wm.FSKEngine(S, [cfg] * S if PER_STREAM else cfg, precision=prec)
     for k in env: os.environ.pop(k)
     o = po.OracleCore(cfg)
     off = 0

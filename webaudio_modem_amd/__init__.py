@@ -10,7 +10,8 @@ from .filters import FilterDesign, FilterFactory, FIRFilter, FIRFilterBatch  # n
 from .processor import ChunkedModulator, FSKProcessorBatch  # noqa: F401
 from .xmodem import CRC16, XModemPacket, ControlType, crc16_batch, serialize_batch, scan_bursts  # noqa: F401
 from . import sharding  # noqa: F401
+from .sharded import FSKEngineSharded  # noqa: F401
 
-__all__ = ["FSKEngine", "FSKCore", "FilterDesign", "FilterFactory", "FIRFilter", "FIRFilterBatch", "ChunkedModulator",
+__all__ = ["FSKEngine", "FSKEngineSharded", "FSKCore", "FilterDesign", "FilterFactory", "FIRFilter", "FIRFilterBatch", "ChunkedModulator",
            "FSKProcessorBatch", "CRC16", "XModemPacket", "ControlType", "crc16_batch", "serialize_batch", "scan_bursts",
            "DEFAULT_FSK_CONFIG", "FskHipError", "PRECISION_F32", "PRECISION_F64"]
