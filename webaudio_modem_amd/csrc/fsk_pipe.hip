@@ -326,7 +326,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
       const bool steady = B.dph >= kDirectPairs;
       const bool small = !(big > amp * 3.7252902984619141e-09f);   // (<=: a zero correction under the bare (0, 0) guard retires too)
       if (steady & small) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }
-      X.zlive = __builtin_amdgcn_ballot_w64(!steady | !small) ? 1u : 0u;
+      X.zlive = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(!steady | !small) != 0));
     }
   }
   // ---- discriminator (fsk.ts:251-264)
@@ -390,15 +390,16 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   // is on the search cadence is only looked at inside)
   const uint32_t m1 = B.matched - B.thr_eff;                   // >= 0 (as int32) <=> matched >= thr_eff
 
-  bool did_reset = false;
   if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)(e1 | ~m1) < 0) != 0, 0)) {
     const bool eod = (int32_t)e1 < 0;
     const bool cand = ((int32_t)m1 >= 0) & (B.rho == X.k % P.cadence);   // globalSampleCounter % round(dsSPB/4) == 0
-    if (eod) {                                                 // fsk.ts:288-291
-      ist_store(M, IF_eod_total, ist_load(M, IF_eod_total) + 1u);
-      if (eod_counts && M.voff < 0xFFFFFFF0u) eod_counts[M.voff >> 2] += 1u;
-      back_reset<UNI>(B, P, M, X, inc, lane);
-      did_reset = true;
+    if (__builtin_amdgcn_ballot_w64(eod)) {                    // fsk.ts:288-291
+      if (eod) {
+        ist_store(M, IF_eod_total, ist_load(M, IF_eod_total) + 1u);
+        if (eod_counts && M.voff < 0xFFFFFFF0u) eod_counts[M.voff >> 2] += 1u;
+        back_reset<UNI>(B, P, M, X, inc, lane);
+      }
+      X.direct = kDirectPairs; X.zlive = 1u;                   // (wave-uniform: set where the wave-uniform branch is)
     }
     // ring length >= preamble window? (fsk.ts:302); ring_len / amp_len in HBM hold the launch-start values
     bool sync_now = false;
@@ -445,28 +446,30 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   B.tlast = (B.tlast & ~dm) | (X.kv & dm);
   const bool edge = ((s0 - 2u >= K.edge_min) ? dm : 0u) != 0u;
   if (__builtin_amdgcn_ballot_w64(edge)) {
-    bool bad_start = false;
-    if (edge) {
-      if (s0 == 1u) {
-        bad_start = b != 0;                                    // fsk.ts:352-355
-      } else if (b) {                                          // stop bit: fsk.ts:367-368
-        if (M.voff < 0xFFFFFFF0u && B.out_cnt < out_pitch)
-          out[(size_t)(M.voff >> 2) * out_pitch + B.out_cnt] = (uint8_t)(s0 >> (P.stop_pos - 9u));
-        B.out_cnt++;
-        B.sreg = 1u;
-      } else {                                                 // bad stop bit: fsk.ts:363-366 -- started = false, byteState stays
+    // flat on purpose: one masked region for the common case (a byte completes), one wave-uniform test for the two rare ones
+    const bool at_stop = edge & (s0 != 1u);
+    const bool good_stop = at_stop & (b != 0u);
+    const bool bad_stop = at_stop & (b == 0u);
+    const bool bad_start = edge & (s0 == 1u) & (b != 0u);            // fsk.ts:352-355
+    if (good_stop) {                                                 // stop bit: fsk.ts:367-368
+      if (M.voff < 0xFFFFFFF0u && B.out_cnt < out_pitch)
+        out[(size_t)(M.voff >> 2) * out_pitch + B.out_cnt] = (uint8_t)(s0 >> (P.stop_pos - 9u));
+      B.out_cnt++;
+      B.sreg = 1u;
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad_stop | bad_start) != 0, 0)) {
+      if (bad_stop) {                                                // fsk.ts:363-366 -- started = false, byteState stays
         const uint32_t reload = B.T - B.tlast;
         B.T = X.k + kBigWait; B.tlast = B.T - reload;
         B.thr_eff = P.matched_min;
         B.sreg = s0;
       }
-    }
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad_start) != 0, 0)) {
-      if (bad_start) back_reset<UNI>(B, P, M, X, inc, lane);
-      did_reset = true;
+      if (__builtin_amdgcn_ballot_w64(bad_start)) {
+        if (bad_start) back_reset<UNI>(B, P, M, X, inc, lane);
+        X.direct = kDirectPairs; X.zlive = 1u;
+      }
     }
   }
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(did_reset) != 0, 0)) { X.direct = kDirectPairs; X.zlive = 1u; }
 }
 
 // ---- state arrays <-> registers ------------------------------------------------------------------------------
