@@ -123,9 +123,11 @@ const char *fskhip_last_kernel(const fskhip_engine *e);
  * of 'eod' events emitted during the call to eod_counts[s] (may be NULL).
  * flags: FSKHIP_DEMOD_WRITEBACK_AGC writes the AGC-scaled samples back into `samples`, which
  * the reference does as a side effect (fsk.ts:55,201).
- * The _host form takes host pointers (H2D/D2H inside, synchronous); the _device form takes
- * device pointers, is asynchronous on `hip_stream` (a hipStream_t, NULL = default stream) and
- * moves nothing over PCIe.
+ * The _host form takes host pointers (H2D/D2H inside, synchronous); a call of more than ~1.5 time
+ * slabs (96 MB of samples each) is pipelined: the next slab crosses PCIe while the current one is
+ * demodulated -- fully only if `samples` is page-locked memory (fskhip_host_alloc below, or the
+ * caller's own pinned buffer).  The _device form takes device pointers, is asynchronous on
+ * `hip_stream` (a hipStream_t, NULL = default stream) and moves nothing over PCIe.
  */
 #define FSKHIP_DEMOD_WRITEBACK_AGC 1u
 int fskhip_demodulate_host(fskhip_engine *e, float *samples, size_t n_per_stream, size_t pitch,
@@ -198,6 +200,10 @@ int fskhip_probe_read_device(fskhip_engine *e, const float *d_buf, size_t n_per_
 void fskhip_butterworth_lowpass(double cutoff, double sampleRate, double b[3], double a[3]);
 void fskhip_butterworth_highpass(double cutoff, double sampleRate, double b[3], double a[3]);
 void fskhip_butterworth_bandpass(double center, double bandwidth, double sampleRate, double b[3], double a[3]);
+
+/* Page-locked host memory for the _host entry points (hipHostMalloc / hipHostFree). */
+int fskhip_host_alloc(size_t bytes, void **ptr);
+int fskhip_host_free(void *ptr);
 
 /* Raw device memory helpers for hosts without a HIP binding of their own (ctypes / N-API). */
 int fskhip_device_malloc(fskhip_engine *e, size_t bytes, void **d_ptr);

@@ -410,3 +410,40 @@ def test_one_process_several_engines_sharded_host_matches_one_engine():
         assert np.array_equal(u, v)
     one.close()
     many.close()
+
+
+@pytest.mark.parametrize("writeback", [False, True])
+def test_host_entry_point_pipelined_over_time_slabs_gives_the_one_shot_result(writeback, monkeypatch):
+    """fskhip_demodulate_host cuts a long call into time slabs and overlaps the next slab's H2D copy with the current
+    slab's kernels (include/fskhip.h).  Bytes, eod counts, status and the written-back AGC samples must be those of the
+    one-shot call -- from pageable and from page-locked (fskhip_host_alloc) buffers, with a slab length that does not
+    divide the call."""
+    import webaudio_modem_amd as wm
+    S, N = 96, 30011
+    gen = wm.FSKEngine(S, BELL)
+    d_x = gen.device_malloc(S * N * 4)
+    gen.synth_device(d_x, N, N, 24, SEED + 9, 400, 0.1, 1.0)
+    gen.synchronize()
+    x = np.zeros((S, N), np.float32)
+    gen.d2h(x, d_x)
+    gen.device_free(d_x)
+    gen.close()
+
+    def run(slab, pinned):
+        monkeypatch.setenv("FSKHIP_HOST_SLAB", str(slab))
+        e = wm.FSKEngine(S, BELL)
+        buf = wm.pinned_empty((S, N), np.float32) if pinned else np.empty((S, N), np.float32)
+        buf[:] = x
+        out, eod = e.demodulate_data(buf, writeback_agc=writeback)
+        st = [e.get_status(s) for s in (0, 17, 95)]
+        e.close()
+        return out, eod, st, buf.copy()
+
+    ref = run(0, False)                       # no pipeline
+    assert sum(len(b) for b in ref[0]) > 20 * S
+    for slab, pinned in ((4096, False), (4096, True), (10000, True)):
+        got = run(slab, pinned)
+        assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+        assert np.array_equal(got[3], ref[3])  # the input, or the AGC-scaled samples when written back
+    if writeback:
+        assert not np.array_equal(ref[3], x)

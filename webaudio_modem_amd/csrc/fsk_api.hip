@@ -167,6 +167,9 @@ struct fskhip_engine {
   // scratch for the _host entry points
   hipStream_t stream = nullptr;
   float *d_samples = nullptr; size_t d_samples_cap = 0;
+  float *d_samples2 = nullptr; size_t d_samples2_cap = 0;   // second time slab of fskhip_demodulate_host's pipeline
+  hipStream_t copy_stream = nullptr;                        // its H2D stream
+  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_used_up[2] = {nullptr, nullptr};
   uint8_t *d_out = nullptr; size_t d_out_cap = 0;
   uint32_t *d_counts = nullptr, *d_eod = nullptr, *d_lens = nullptr;
   uint8_t *d_payloads = nullptr; size_t d_payloads_cap = 0;
@@ -281,11 +284,16 @@ int fskhip_destroy(fskhip_engine *e) {
   (void)hipSetDevice(e->device);
   (void)hipDeviceSynchronize();
   void *bufs[] = {e->S.rs, e->S.is, e->S.poly, e->S.amp_ring, (void *)e->S.coef, (void *)e->S.nco_inc, e->d_samples,
-                  e->d_out, e->d_counts, e->d_eod, e->d_lens, e->d_payloads, e->d_status, e->d_sigma,
+                  e->d_samples2, e->d_out, e->d_counts, e->d_eod, e->d_lens, e->d_payloads, e->d_status, e->d_sigma,
                   e->S.trace_amp, e->S.trace_post, e->S.trace_bit, e->S.trace_n, e->S.poly_u};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (auto ev : e->ev) (void)hipEventDestroy(ev);
+  for (int i = 0; i < 2; i++) {
+    if (e->ev_copied[i]) (void)hipEventDestroy(e->ev_copied[i]);
+    if (e->ev_used_up[i]) (void)hipEventDestroy(e->ev_used_up[i]);
+  }
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return FSKHIP_OK;
@@ -568,9 +576,11 @@ uint32_t fskhip_n_streams(const fskhip_engine *e) { return e ? e->n_streams : 0;
 size_t fskhip_max_bytes(const fskhip_engine *e, size_t n_per_stream) { return e ? engine_max_bytes(e, n_per_stream) : 0; }
 const char *fskhip_last_kernel(const fskhip_engine *e) { return e ? e->last_kernel : ""; }
 
-int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_t pitch, uint8_t *d_out,
+// append_first: this launch sequence continues a call that has produced output already (a time slab of
+// fskhip_demodulate_host's pipeline); count_call: it is (the first part of) a demodulateData() call of its own
+static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_t pitch, uint8_t *d_out,
                              size_t out_pitch, uint32_t *d_out_counts, uint32_t *d_eod_counts, uint32_t flags,
-                             void *hip_stream) {
+                             void *hip_stream, bool append_first, bool count_call) {
   if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "FSK demodulator not configured");
   if (!d_out_counts || (n > 0 && !d_samples) || (out_pitch > 0 && !d_out))
     return fail(FSKHIP_E_INVALID, "fskhip_demodulate_device: null buffer");
@@ -612,9 +622,9 @@ int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_
       if (e->S.trace_stream != 0xFFFFFFFFu) tiles = false;   // a traced engine stays on the sample-granular kernel
       if (tiles && head < n) n_fast = (n - head) & ~(size_t)15;
       if (!n_fast) head = n;   // all of it sample by sample
-      bool app = false;
+      bool app = append_first;
       if (head) {
-        HIP_TRY(launch_demod_tail(wb, false, (int)p0, e->P, e->S, d_samples, head, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+        HIP_TRY(launch_demod_tail(wb, app, (int)p0, e->P, e->S, d_samples, head, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
         e->last_kernel = "fsk::demod_tail_kernel";
         app = true;
       }
@@ -634,7 +644,7 @@ int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_
           HIP_TRY(launch_demod_tail(wb, true, 0, e->P, e->S, d_samples + done, n - done, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
       }
     } else {
-      HIP_TRY(launch_demod(e->precision, e->ds_uniform, wb, false, e->P, e->S, d_samples, n, pitch, d_out, out_pitch,
+      HIP_TRY(launch_demod(e->precision, e->ds_uniform, wb, append_first, e->P, e->S, d_samples, n, pitch, d_out, out_pitch,
                            d_out_counts, d_eod_counts, st));
       e->last_kernel = e->precision == FSKHIP_PRECISION_F64 ? "fsk::demod_kernel<double, ...>" : "fsk::demod_kernel<float, ...>";
       // the generic kernel keeps an open decimator pair's partial sums in the reference's own frame: stay with it
@@ -646,12 +656,23 @@ int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_
     HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], st));
     e->ev_used += 2;
   }
-  e->calls += 1;
+  e->calls += count_call ? 1 : 0;
   e->total_samples += n;
   e->ds_parity = (e->ds_parity + (uint32_t)(n & 1)) & 1u;
   return FSKHIP_OK;
 }
 
+int fskhip_demodulate_device(fskhip_engine *e, float *d_samples, size_t n, size_t pitch, uint8_t *d_out,
+                             size_t out_pitch, uint32_t *d_out_counts, uint32_t *d_eod_counts, uint32_t flags,
+                             void *hip_stream) {
+  return demod_device_impl(e, d_samples, n, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, flags, hip_stream, false, true);
+}
+
+// Host buffers in, bytes out.  A call longer than one time slab is a two-buffer pipeline over TIME: slab j+1 crosses PCIe
+// on the copy stream while slab j is demodulated on the compute stream.  Cutting along time needs no sub-batch launches,
+// and the engine gives the same bytes for any cut (the reference is a streaming state machine, fsk.ts:190-222).  The
+// copies only overlap if `samples` is page-locked (fskhip_host_alloc, or any pinned buffer of the caller); with pageable
+// memory the runtime stages each copy itself and the pipeline degrades gracefully to what one big copy costs.
 int fskhip_demodulate_host(fskhip_engine *e, float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch,
                            uint32_t *out_counts, uint32_t *eod_counts, uint32_t flags) {
   if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "FSK demodulator not configured");
@@ -659,26 +680,81 @@ int fskhip_demodulate_host(fskhip_engine *e, float *samples, size_t n, size_t pi
   if (pitch < n) return fail(FSKHIP_E_INVALID, "pitch %zu < n_per_stream %zu", pitch, n);
   HIP_TRY(hipSetDevice(e->device));
   const size_t S = e->n_streams;
-  // device copy keeps the caller's row pitch rounded up to 4 floats so the 16-B tile loads apply
-  const size_t dpitch = (n + 3) & ~(size_t)3;
+  const bool wb = (flags & FSKHIP_DEMOD_WRITEBACK_AGC) != 0;
+  // slab length: ~96 MB of samples per slab, a multiple of 16 (whole tiles, even decimator parity), at least 4096
+  size_t slab = ((size_t)96 << 20) / (S * sizeof(float));
+  slab = slab < 4096 ? 4096 : slab;
+  slab &= ~(size_t)15;
+  const char *env = getenv("FSKHIP_HOST_SLAB");          // measurement / test override (samples per slab; 0 = no pipeline)
+  if (env) slab = (size_t)strtoull(env, nullptr, 10) & ~(size_t)15;
+  const bool piped = slab > 0 && n > slab + slab / 2;
+  const size_t len0 = piped ? slab + slab / 2 : n;    // (the last slab of a pipelined call takes the remainder, < 1.5 slabs)
+  // device copies keep a row pitch that is a multiple of 4 floats so the 16-B tile loads apply
+  const size_t dpitch = ((len0 + 3) & ~(size_t)3) ? ((len0 + 3) & ~(size_t)3) : 4;
   int rc;
-  if ((rc = ensure(e->d_samples, e->d_samples_cap, (dpitch ? dpitch : 4) * S)) != FSKHIP_OK) return rc;
+  if ((rc = ensure(e->d_samples, e->d_samples_cap, dpitch * S)) != FSKHIP_OK) return rc;
   if ((rc = ensure(e->d_out, e->d_out_cap, (out_pitch ? out_pitch : 1) * S)) != FSKHIP_OK) return rc;
-  if (n > 0)
-    HIP_TRY(hipMemcpy2DAsync(e->d_samples, dpitch * sizeof(float), samples, pitch * sizeof(float), n * sizeof(float), S,
-                             hipMemcpyHostToDevice, e->stream));
-  rc = fskhip_demodulate_device(e, e->d_samples, n, dpitch ? dpitch : 4, e->d_out, out_pitch, e->d_counts, e->d_eod,
-                                flags, e->stream);
-  if (rc != FSKHIP_OK) return rc;
+  if (!piped) {
+    if (n > 0)
+      HIP_TRY(hipMemcpy2DAsync(e->d_samples, dpitch * sizeof(float), samples, pitch * sizeof(float), n * sizeof(float), S,
+                               hipMemcpyHostToDevice, e->stream));
+    rc = fskhip_demodulate_device(e, e->d_samples, n, dpitch, e->d_out, out_pitch, e->d_counts, e->d_eod, flags, e->stream);
+    if (rc != FSKHIP_OK) return rc;
+    if (wb && n > 0)
+      HIP_TRY(hipMemcpy2DAsync(samples, pitch * sizeof(float), e->d_samples, dpitch * sizeof(float), n * sizeof(float), S,
+                               hipMemcpyDeviceToHost, e->stream));
+  } else {
+    if ((rc = ensure(e->d_samples2, e->d_samples2_cap, dpitch * S)) != FSKHIP_OK) return rc;
+    if (!e->copy_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+      for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_copied[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_used_up[i], hipEventDisableTiming));
+      }
+    }
+    float *buf[2] = {e->d_samples, e->d_samples2};
+    size_t off = 0;
+    for (size_t j = 0; off < n; j++) {
+      // the last slab takes the remainder (up to 1.5 slabs would not be worth another round trip)
+      const size_t len = (n - off > slab + slab / 2) ? slab : n - off;
+      if (len > dpitch) return fail(FSKHIP_E_INVALID, "internal: slab %zu exceeds staging pitch %zu", len, dpitch);
+      const int b = (int)(j & 1);
+      if (j >= 2) HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_used_up[b], 0));   // its previous user has finished
+      HIP_TRY(hipMemcpy2DAsync(buf[b], dpitch * sizeof(float), samples + off, pitch * sizeof(float), len * sizeof(float), S,
+                               hipMemcpyHostToDevice, e->copy_stream));
+      HIP_TRY(hipEventRecord(e->ev_copied[b], e->copy_stream));
+      HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_copied[b], 0));
+      rc = demod_device_impl(e, buf[b], len, dpitch, e->d_out, out_pitch, e->d_counts, e->d_eod, flags, e->stream,
+                             /*append_first=*/j > 0, /*count_call=*/j == 0);
+      if (rc != FSKHIP_OK) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamSynchronize(e->stream); return rc; }
+      if (wb)
+        HIP_TRY(hipMemcpy2DAsync(samples + off, pitch * sizeof(float), buf[b], dpitch * sizeof(float), len * sizeof(float), S,
+                                 hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipEventRecord(e->ev_used_up[b], e->stream));
+      off += len;
+    }
+  }
   if (out_pitch > 0) HIP_TRY(hipMemcpyAsync(out, e->d_out, out_pitch * S, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipMemcpyAsync(out_counts, e->d_counts, sizeof(uint32_t) * S, hipMemcpyDeviceToHost, e->stream));
   if (eod_counts) HIP_TRY(hipMemcpyAsync(eod_counts, e->d_eod, sizeof(uint32_t) * S, hipMemcpyDeviceToHost, e->stream));
-  if ((flags & FSKHIP_DEMOD_WRITEBACK_AGC) && n > 0)
-    HIP_TRY(hipMemcpy2DAsync(samples, pitch * sizeof(float), e->d_samples, dpitch * sizeof(float), n * sizeof(float), S,
-                             hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->copy_stream) HIP_TRY(hipStreamSynchronize(e->copy_stream));
   for (size_t s = 0; s < S; s++)
     if (out_counts[s] > out_pitch) return fail(FSKHIP_E_OVERFLOW, "stream %zu produced %u bytes, slab holds %zu", s, out_counts[s], out_pitch);
+  return FSKHIP_OK;
+}
+
+// Page-locked host memory for the _host entry points (so that their H2D / D2H copies run asynchronously at full PCIe
+// rate); plain hipHostMalloc / hipHostFree for hosts without a HIP binding of their own.
+int fskhip_host_alloc(size_t bytes, void **ptr) {
+  if (!ptr) return fail(FSKHIP_E_INVALID, "null pointer");
+  *ptr = nullptr;
+  hipError_t err = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
+  if (err != hipSuccess) return fail(err == hipErrorNoDevice ? FSKHIP_E_NO_DEVICE : FSKHIP_E_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(err));
+  return FSKHIP_OK;
+}
+int fskhip_host_free(void *ptr) {
+  if (ptr) HIP_TRY(hipHostFree(ptr));
   return FSKHIP_OK;
 }
 

@@ -61,6 +61,40 @@ def _status_dict(st):
     }
 
 
+class _PinnedBlock:
+    """owner of one fskhip_host_alloc allocation (freed when the last array viewing it is collected)"""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _lib.check(_lib.lib().fskhip_host_alloc(nbytes, C.byref(p)))
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.lib().fskhip_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """numpy array in page-locked host memory (fskhip_host_alloc): the buffer to hand to demodulate_data /
+    modulate_data when the PCIe copies should overlap the kernels (include/fskhip.h, fskhip_demodulate_host)."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    blk = _PinnedBlock(max(1, n * dt.itemsize))
+    buf = (C.c_char * blk.nbytes).from_address(blk.ptr)
+    arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    _PINNED_OWNERS[id(buf)] = blk          # keep the block alive as long as the ctypes buffer is
+    import weakref
+    weakref.finalize(buf, _PINNED_OWNERS.pop, id(buf), None)
+    return arr
+
+
+_PINNED_OWNERS = {}
+
+
 class FSKEngine:
     """S FSKCore instances on one GPU.
 
