@@ -100,6 +100,14 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
                   int precision, fskhip_engine **out);
 int fskhip_destroy(fskhip_engine *e);
 
+/*
+ * FSKCore.configure() on an already configured instance (fsk.ts:133-157) rebuilds everything and calls
+ * resetState(), which leaves silence.threshold (fsk.ts:128, 321-326) and the debug counters
+ * (fsk.ts:131) of the old life in place.  A host re-configures with fskhip_create + this + fskhip_destroy
+ * of the old engine; the two engines must agree in stream count, precision and device.
+ */
+int fskhip_carry_over(fskhip_engine *dst, const fskhip_engine *src);
+
 uint32_t fskhip_n_streams(const fskhip_engine *e);
 
 /*

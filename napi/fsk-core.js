@@ -56,9 +56,14 @@ class FSKCore extends EventEmitter {
   }
 
   configure(config) {               // fsk.ts:133-157
-    if (this.handle) { addon.destroy(this.handle); this.handle = null; }
+    const old = this.handle;
     this.config = Object.assign({}, DEFAULT_FSK_CONFIG, config);
     this.handle = addon.create(this.config, 1, this.device, this.precision);
+    if (old) {
+      // the reference rebuilds in place and keeps silence.threshold and the debug counters (fsk.ts:133-157)
+      addon.carryOver(this.handle, old);
+      addon.destroy(old);
+    }
     this.ready = true;
     this.emit('configured');
   }

@@ -378,6 +378,20 @@ static napi_value Reset(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// carryOver(dst, src): what FSKCore.configure() leaves in place on a configured instance (fskhip_carry_over)
+static napi_value CarryOver(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  fskhip_engine *dst = get_engine(env, argv[0]);
+  if (!dst) return nullptr;
+  fskhip_engine *src = get_engine(env, argv[1]);
+  if (!src) return nullptr;
+  int rc = fskhip_carry_over(dst, src);
+  if (rc != FSKHIP_OK) return throw_fsk(env, rc);
+  return nullptr;
+}
+
 static void set_num(napi_env env, napi_value obj, const char *k, double v) {
   napi_value n;
   napi_create_double(env, v, &n);
@@ -445,6 +459,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"modulate", nullptr, Modulate, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"modulatedLength", nullptr, ModulatedLength, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"reset", nullptr, Reset, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"carryOver", nullptr, CarryOver, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"getStatus", nullptr, GetStatus, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"demodSupported", nullptr, DemodSupported, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},

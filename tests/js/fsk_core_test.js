@@ -55,6 +55,17 @@ async function gpuTests() {
     assert.strictEqual(st.totalSamplesProcessed, 2480);
     assert.ok(Math.abs(st.silenceThreshold - 0.16749451808631421) < (precision === M.PRECISION_F64 ? 1e-12 : 2e-6));
     assert.strictEqual(events.filter((e) => e === 'eod').length, 1);
+    // configure() on a configured instance (fsk.ts:133-157): resetState() semantics, silence.threshold and the debug
+    // counters survive, the AGC is new
+    const thrBefore = st.silenceThreshold;
+    core.configure({ markFrequency: 1200, spaceFrequency: 2200 });
+    st = core.getStatus();
+    assert.strictEqual(st.silenceThreshold, thrBefore);
+    assert.strictEqual(st.syncDetections, 1);
+    assert.strictEqual(st.demodulationCalls, 1);
+    assert.strictEqual(st.globalSampleCounter, 0);
+    assert.strictEqual(st.frameStarted, false);
+    core.configure({});
     // reset keeps ready (fsk.ts:464-469), clears counters
     core.reset();
     assert.strictEqual(core.isReady(), true);

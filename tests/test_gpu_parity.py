@@ -130,6 +130,46 @@ def test_digital_silence_stays_exactly_silent_across_resets():
 
 
 @pytest.mark.parametrize("pname,prec,tol", PRECISIONS)
+def test_reconfigure_keeps_silence_threshold_and_debug_counters(pname, prec, tol):
+    """configure() on a configured FSKCore (fsk.ts:133-157) rebuilds AGC / filters / rings and calls resetState(), which
+    leaves silence.threshold (set at the last sync, fsk.ts:321-326) and the debug counters alone -- so the first 'eod' of
+    the next burst is still judged against the OLD threshold.  The host classes re-configure with fskhip_create +
+    fskhip_carry_over + fskhip_destroy; bytes, per-call eod counts and status must follow the oracle through it."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    cfg_a = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
+    cfg_b = dict(baudRate=1200, markFrequency=1650, spaceFrequency=1850)
+    o = po.OracleCore(cfg_a)
+    core = wm.FSKCore(precision=prec)
+    core.configure(cfg_a)
+    eods = []
+    core.on("eod", lambda *_a: eods.append(1))
+    burst_a = np.concatenate([o.modulate(b"first life") * np.float32(0.8), np.zeros(700, np.float32)])
+    got = core.demodulateData(burst_a.copy())
+    want, oe = o.demodulate(burst_a.copy())
+    assert bytes(got) == want == b"first life" and len(eods) == oe
+    thr_a = o.status()["silenceThreshold"]
+    assert thr_a > 0.02                                   # the sync has replaced the initial 0.01
+    core.configure(cfg_b)
+    o.configure(cfg_b)
+    st, ost = core.getStatus(), o.status()
+    assert abs(st["silenceThreshold"] - thr_a) <= tol * thr_a and ost["silenceThreshold"] == thr_a
+    assert st["syncDetections"] == ost["syncDetections"] == 1 and st["agcGain"] == 1.0
+    # a weak second burst: its tail crosses the OLD threshold earlier than it would cross 0.01
+    burst_b = np.concatenate([np.zeros(300, np.float32), o.modulate(b"second life") * np.float32(0.05), np.zeros(900, np.float32)])
+    for lo in range(0, len(burst_b), 128):
+        del eods[:]
+        chunk = burst_b[lo:lo + 128]
+        got = core.demodulateData(chunk.copy())
+        want, oe = o.demodulate(chunk.copy())
+        assert bytes(got) == want and len(eods) == oe, lo
+    st, ost = core.getStatus(), o.status()
+    for k in STATUS_EXACT_KEYS:
+        assert st[k] == ost[k], k
+    core.close() if hasattr(core, "close") else None
+
+
+@pytest.mark.parametrize("pname,prec,tol", PRECISIONS)
 def test_offset_sweep_batched(pname, prec, tol):
     """fsk-demodulation.node.test.ts:668-716 -- all 128 chunk offsets, here as 128 streams of ONE
     engine call sequence (stream k = k leading zeros + the frame), 128-sample chunks."""

@@ -85,6 +85,7 @@ _SYMBOLS = [
     ("fskhip_butterworth_highpass", None, [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("fskhip_butterworth_bandpass", None, [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
                                            C.POINTER(C.c_double)]),
+    ("fskhip_carry_over", C.c_int, [_P, _P]),
     ("fskhip_host_alloc", C.c_int, [C.c_size_t, C.POINTER(_P)]),
     ("fskhip_host_free", C.c_int, [_P]),
     ("fskhip_device_malloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),

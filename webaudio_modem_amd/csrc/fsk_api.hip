@@ -572,6 +572,28 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   return FSKHIP_OK;
 }
 
+// What FSKCore.configure() on an already configured instance leaves in place (fsk.ts:133-157 rebuilds filters, rings and
+// pattern and calls resetState(), 175-188): silence.threshold (fsk.ts:128, 321-326) and the debug counters (fsk.ts:131).
+// A host re-configures by creating a new engine, carrying these over from the old one and destroying that.
+int fskhip_carry_over(fskhip_engine *dst, const fskhip_engine *src) {
+  if (!dst || !src) return fail(FSKHIP_E_INVALID, "fskhip_carry_over: null engine");
+  if (dst->n_streams != src->n_streams || dst->precision != src->precision || dst->device != src->device)
+    return fail(FSKHIP_E_INVALID, "fskhip_carry_over: engines differ in stream count, precision or device");
+  HIP_TRY(hipSetDevice(dst->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t n = dst->n_streams, rsz = dst->precision == FSKHIP_PRECISION_F64 ? sizeof(double) : sizeof(float);
+  HIP_TRY(hipMemcpy((char *)dst->S.rs + (size_t)RF_sil_thr * n * rsz, (const char *)src->S.rs + (size_t)RF_sil_thr * n * rsz,
+                    n * rsz, hipMemcpyDeviceToDevice));
+  const int rows[] = {IF_sync_det, IF_eod_total};
+  for (int f : rows)
+    HIP_TRY(hipMemcpy(dst->S.is + (size_t)f * n, src->S.is + (size_t)f * n, n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+  dst->calls = src->calls;
+  dst->total_samples = src->total_samples;
+  dst->base_calls = src->base_calls;
+  dst->base_samples = src->base_samples;
+  return FSKHIP_OK;
+}
+
 uint32_t fskhip_n_streams(const fskhip_engine *e) { return e ? e->n_streams : 0; }
 size_t fskhip_max_bytes(const fskhip_engine *e, size_t n_per_stream) { return e ? engine_max_bytes(e, n_per_stream) : 0; }
 const char *fskhip_last_kernel(const fskhip_engine *e) { return e ? e->last_kernel : ""; }

@@ -128,6 +128,10 @@ class FSKEngine:
             self._L.fskhip_destroy(self._h)
             self._h = None
 
+    def carry_over_from(self, old):
+        """what FSKCore.configure() leaves in place on a configured instance: silence threshold, debug counters"""
+        _lib.check(self._L.fskhip_carry_over(self._h, old._h))
+
     def __del__(self):
         try:
             self.close()

@@ -65,9 +65,12 @@ class FSKCore(EventEmitter):
 
     # configure() fsk.ts:133-157
     def configure(self, config=None):
-        if self._engine is not None:
-            self._engine.close()
+        old = self._engine
         self._engine = FSKEngine(1, dict(config or {}), device=self._device, precision=self._precision)
+        if old is not None:
+            # the reference rebuilds in place and keeps silence.threshold and the debug counters (fsk.ts:133-157)
+            self._engine.carry_over_from(old)
+            old.close()
         self.config = dict(self._engine.config)
         self.ready = True
         self.emit("configured")
