@@ -769,8 +769,8 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
         // a reset the back wave has seen: zero this lane's filters in front of decimated sample zj (rare; one compare per
         // half tile and two scalar branches per four samples otherwise)
         const uint32_t zj = zmail[lane];
-        const uint32_t zh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(zj - 4u * hidx < 4u) != 0));
-#pragma unroll 1
+        const uint64_t zh = __builtin_amdgcn_ballot_w64(zj - 4u * hidx < 4u);
+#pragma unroll
         for (uint32_t cc = 0; cc < 2; cc++) {
           const uint32_t c = 2u * hf + cc;
           const v4f x4 = stage[c * kSlotStride + lane];     // written by this wave: a wave's ds ops are ordered
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
           }
           const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
           float xs[4], y[4], oi[4], oq[4];
-          if (__builtin_expect(zh != 0u, 0)) {   // (its own copy of the four samples: the common one carries no per-lane test)
+          if (__builtin_expect(zh != 0ull, 0)) {   // (its own copy of the four samples: the common one carries no per-lane test)
             asm volatile("s_nop 0");
 #pragma unroll
             for (int j = 0; j < 4; j++) {
