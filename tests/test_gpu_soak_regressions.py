@@ -52,3 +52,26 @@ def test_soak_found_streams_decode_like_the_reference(fname, cfg, sched, path, e
             for k in KEYS:
                 assert st[k] == ost[k], (fname, path, k)
         eng.close()
+
+
+def test_the_one_fp32_divergence_of_the_soak_is_a_marginal_slicer_decision():
+    """soak_r02_stop2_s80: the one stream in ~600 000 randomised stream-runs on which an fp32 engine decoded other bytes
+    than the reference after the round-2 fixes.  It is the generic fp32 kernel (fractional ring capacity), and the cause is
+    one slicer decision the reference itself takes at |post-filter output| = 1.0e-8 (fp32: +1.1e-8) while its sync count
+    sits exactly on the threshold.  tools/soak.py accepts a divergence only if it traces back to such a decision; this
+    pins both that classification and that the fp64 engine follows the reference on the same stream."""
+    import sys
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import soak
+    cfg = {"stopBits": 2, "markFrequency": 900.0, "spaceFrequency": 1100.0}
+    x = np.load(os.path.join(ROOT, "tools", "diag_data", "soak_r02_stop2_s80.npy")).astype(np.float32)
+    ok, why = soak.fp32_mismatch_is_marginal(cfg, x, False)
+    assert ok, why
+    o = po.OracleCore(cfg)
+    want, oe = o.demodulate(x)
+    e64 = wm.FSKEngine(1, cfg, precision=wm.PRECISION_F64)
+    got, eod = e64.demodulate_data(x.reshape(1, -1))
+    assert got[0] == want and int(eod[0]) == oe and len(want) >= 1
+    e64.close()
