@@ -152,11 +152,17 @@ def test_whole_tile_kernels_never_spill():
     for name, v in fused.items():
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
         assert v["VGPRs"] <= 168, (name, v)
-    pipe = {k: v for k, v in res.items() if "demod_pipe_kernel" in k}
+    pipe = {k: v for k, v in res.items() if "demod_pipe_kernel" in k}    # (not demod_pipe3_kernel)
     assert len(pipe) == 4
     for name, v in pipe.items():
+        assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
+        assert v["VGPRs"] <= 256, (name, v)
+    pipe3 = {k: v for k, v in res.items() if "demod_pipe3_kernel" in k}
+    assert len(pipe3) == 4
+    for name, v in pipe3.items():
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
         assert v["VGPRs"] <= 256, (name, v)
     # the registers the asm prefetch lands in are never touched while a load may still be in flight
     assert check_isa.prefetch_register_hazards() == []
     assert check_isa.pipe_prefetch_hazards() == []
+    assert check_isa.pipe_prefetch_hazards(r"_ZN3fsk18demod_pipe3_kernel") == []

@@ -179,7 +179,8 @@ def test_whole_tile_kernels_agree_on_ragged_batches(S, monkeypatch):
     gen.synth_device(d_x, N, N, 12, SEED + 1, 300, 0.1, 1.0)
     gen.synchronize()
     digests = {}
-    for name, env in (("split", {"FSKHIP_SPLIT": "1"}), ("one_wave", {"FSKHIP_SPLIT": "0"}), ("generic", {"FSKHIP_FORCE_GENERIC": "1"})):
+    for name, env in (("split", {"FSKHIP_SPLIT": "1"}), ("one_wave", {"FSKHIP_SPLIT": "0"}), ("three_wave", {"FSKHIP_SPLIT": "3"}),
+                      ("generic", {"FSKHIP_FORCE_GENERIC": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
@@ -188,13 +189,13 @@ def test_whole_tile_kernels_agree_on_ragged_batches(S, monkeypatch):
         rows, eod = _demod_schedule(eng, d_x, N, N, [4096, 16, 1000, 48, 20000])
         digests[name] = (_digest(rows, eod), sum(len(r) for r in rows))
         eng.close()
-    assert digests["split"] == digests["one_wave"] == digests["generic"], digests
+    assert digests["split"] == digests["one_wave"] == digests["three_wave"] == digests["generic"], digests
     assert digests["split"][1] >= 12 * S * 0.5
     gen.device_free(d_x)
     gen.close()
 
 
-@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("split", ["0", "1", "3"])
 def test_partial_wave_lanes_stay_out_of_rare_paths(split, monkeypatch):
     """Regression (found by tools/soak.py): one stream in a 64-lane wave, lowered syncThreshold, a chunk schedule that
     hands a synced state to the whole-tile kernels.  The 63 lanes beyond the batch used to reach the sync path, whose
@@ -239,6 +240,7 @@ def test_config2_v21_300_baud_batch(monkeypatch):
     gen.synchronize()
     results = {}
     for name, env, schedule in (("pipe_one_call", {"FSKHIP_SPLIT": "1"}, [N]), ("pipe_quanta", {"FSKHIP_SPLIT": "1"}, [128]),
+                                ("pipe3_one_call", {"FSKHIP_SPLIT": "3"}, [N]), ("pipe3_ragged", {"FSKHIP_SPLIT": "3"}, [4096, 19, 128, 48000, 7]),
                                 ("fused_ragged", {"FSKHIP_SPLIT": "0"}, [30000, 17, 4096, 3, 128, 2049])):
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -34,9 +34,10 @@ def _check_status(st, ref, tol, agc_gain):
         assert st["agcGain"] == pytest.approx(agc_gain, rel=max(tol, 1e-12) * 10)
 
 
-# the fp32 path has two kernels for whole tiles: one wave per 64 streams (large batches) and the two-wave split
-# (batches of at most one wave per SIMD, i.e. every small test).  FSKHIP_SPLIT pins one of them at engine creation.
-GOLDEN_VARIANTS = PRECISIONS + [("f32-one-wave", 0, 1e-5)]
+# the fp32 path has three kernels for whole tiles: one wave per 64 streams (large batches), two waves (fewer than two
+# waves per SIMD) and three waves per group (at most two groups per CU, i.e. every small test).  FSKHIP_SPLIT pins one of
+# them at engine creation.
+GOLDEN_VARIANTS = PRECISIONS + [("f32-one-wave", 0, 1e-5), ("f32-three-wave", 0, 1e-5)]
 
 
 @pytest.mark.parametrize("pname,prec,tol", GOLDEN_VARIANTS)
@@ -45,6 +46,8 @@ def test_demod_matches_reference_golden(name, pname, prec, tol, monkeypatch):
     import webaudio_modem_amd as wm
     if pname == "f32-one-wave":
         monkeypatch.setenv("FSKHIP_SPLIT", "0")
+    elif pname == "f32-three-wave":
+        monkeypatch.setenv("FSKHIP_SPLIT", "3")
     elif pname == "f32":
         monkeypatch.setenv("FSKHIP_SPLIT", "1")
     g = golden()

@@ -103,8 +103,9 @@ def prefetch_register_hazards():
     return problems
 
 
-def pipe_prefetch_hazards():
-    """The two-wave kernel's front wave keeps three register sets of asm-issued tile loads in flight (unrolled by three).
+def pipe_prefetch_hazards(symbol=r"_ZN3fsk17demod_pipe_kernel"):
+    """The two-wave kernel's front wave (and the three-wave kernel's first wave: symbol=_ZN3fsk18demod_pipe3_kernel) keeps
+    three register sets of asm-issued tile loads in flight (unrolled by three).
     In its tile loop (everything after the prologue's `s_waitcnt vmcnt(0)` up to the epilogue's) a register of a set may
     only be read after the `s_waitcnt vmcnt(N)` placed in front of that set's ds_write_b128 staging, and only by it."""
     src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_pipe.hip")
@@ -123,9 +124,9 @@ def pipe_prefetch_hazards():
         return out
 
     problems = []
-    found = list(re.finditer(r"^(_ZN3fsk17demod_pipe_kernel\w+):[^\n]*\n", text, re.M))
+    found = list(re.finditer(r"^(" + symbol + r"\w+):[^\n]*\n", text, re.M))
     if len(found) != 4:
-        problems.append(("demod_pipe_kernel", "expected 4 kernel bodies in the ISA, found %d" % len(found)))
+        problems.append((symbol, "expected 4 kernel bodies in the ISA, found %d" % len(found)))
     for m in found:
         body = [l for l in text[m.end():text.index(".Lfunc_end", m.end())].split("\n")]
         loads = [i for i, l in enumerate(body) if "buffer_load_dwordx4" in l]
@@ -163,7 +164,7 @@ def pipe_prefetch_hazards():
 
 
 if __name__ == "__main__":
-    for name, what in prefetch_register_hazards() + pipe_prefetch_hazards():
+    for name, what in prefetch_register_hazards() + pipe_prefetch_hazards() + pipe_prefetch_hazards(r"_ZN3fsk18demod_pipe3_kernel"):
         print("HAZARD", name[:50], what)
         sys.exit(2)
     r = kernel_resources()

@@ -29,8 +29,9 @@ def run(name, env, prec):
               " ".join("%s=%s/%s" % (k[:6], (round(st[k], 6) if isinstance(st[k], float) else st[k]), (round(ost[k], 6) if isinstance(ost[k], float) else int(ost[k]))) for k in KEYS), flag))
         off += n
     eng.close()
-only = os.environ.get("REPLAY_ONLY", "generic,fused,pipe").split(",")
+only = os.environ.get("REPLAY_ONLY", "generic,fused,pipe,pipe3").split(",")
 if "generic" in only: run("generic f32", {"FSKHIP_FORCE_GENERIC": "1"}, wm.PRECISION_F32)
 if "f64" in only: run("generic f64", {}, wm.PRECISION_F64)
 if "fused" in only: run("fused", {"FSKHIP_SPLIT": "0"}, wm.PRECISION_F32)
 if "pipe" in only: run("pipe", {"FSKHIP_SPLIT": "1"}, wm.PRECISION_F32)
+if "pipe3" in only: run("pipe3", {"FSKHIP_SPLIT": "3"}, wm.PRECISION_F32)

@@ -32,6 +32,10 @@ hipError_t launch_demod_tail(bool writeback, bool append, int parity0, const Dem
                              float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream);
 size_t demod_pipe_lds_bytes(const DemodParams &P);
+size_t demod_pipe3_lds_bytes(const DemodParams &P);
+hipError_t launch_demod_pipe3(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts, uint32_t *eod_counts,
+                              hipStream_t stream);
 size_t demod_fused_lds_bytes(const DemodParams &P);
 hipError_t set_pipe_lds_limit(size_t pipe_bytes);
 hipError_t set_demod_lds_limit(size_t lds_bytes);
@@ -158,6 +162,7 @@ struct fskhip_engine {
   bool use_split = false;        // two waves per 64-stream group (demod_split_kernel): batches of fewer than two waves per SIMD
   uint32_t split_cus = 256;
   bool split_forced = false;     // FSKHIP_SPLIT was set: skip the residency check too
+  bool use_split3 = false;       // three waves per group (demod_pipe3_kernel): at most two groups per CU
   bool gen_odd = false;          // fp32: the last generic-kernel launch left a decimator pair open (its partial sums are in
                                  // the reference's frame, the whole-tile kernels' in the free-running one)
   const char *last_kernel = "";  // what the last fskhip_demodulate_device call launched for its whole tiles
@@ -194,7 +199,7 @@ size_t engine_max_bytes(const fskhip_engine *e, size_t n_per_stream) {
 // everything fskhip_demodulate_device's choice of launches depends on besides its arguments
 uint32_t engine_launch_key(const fskhip_engine *e) {
   return (e->ds_uniform ? 1u : 0u) | (e->ds_parity << 1) | (e->force_generic ? 4u : 0u) | (e->timing ? 8u : 0u) |
-         (e->use_split ? 32u : 0u) | (e->gen_odd ? 64u : 0u) |
+         (e->use_split ? 32u : 0u) | (e->gen_odd ? 64u : 0u) | (e->use_split3 ? 128u : 0u) |
          (e->S.trace_stream != 0xFFFFFFFFu ? 16u : 0u);
 }
 void engine_note_replayed_call(fskhip_engine *e, size_t n) {
@@ -336,7 +341,13 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     const uint32_t n_blocks = (n_streams + 63) / 64;
     e->use_split = n_blocks < (uint32_t)cus * 8u;  // < 2 waves per SIMD (4 SIMDs per CU)
     e->split_cus = (uint32_t)cus;
-    if (const char *sp = getenv("FSKHIP_SPLIT")) { e->use_split = sp[0] == '1'; e->split_forced = true; }
+    // two groups per CU: the two-wave kernel would leave every SIMD one wave, with nothing to cover its LDS round trips; a
+    // third instruction stream per group gives half the SIMDs a second wave (measured: 32 768 streams 245 -> 275
+    // Gsamples/s; at one group per CU or fewer every wave is alone either way and the extra hand-off buys nothing)
+    e->use_split3 = e->use_split && n_blocks > (uint32_t)cus && n_blocks <= (uint32_t)cus * 2u;
+    if (const char *sp = getenv("FSKHIP_SPLIT")) {    // tests / measurements: 0 = one wave, 1 = two, 3 = three per group
+      e->use_split = sp[0] == '1' || sp[0] == '3'; e->use_split3 = sp[0] == '3'; e->split_forced = true;
+    }
   }
 
   // calculateParameters (fsk.ts:426-444), in doubles like the reference
@@ -651,7 +662,12 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
         app = true;
       }
       if (n_fast) {
-        if (two_wave) {
+        const size_t pipe3_lds = demod_pipe3_lds_bytes(e->P);
+        if (two_wave && e->use_split3 && pipe3_lds <= 160 * 1024 && (wgs_per_cu * pipe3_lds <= 160 * 1024 || e->split_forced)) {
+          HIP_TRY(launch_demod_pipe3(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+          e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_pipe3_kernel<true, true>" : "fsk::demod_pipe3_kernel<true, false>")
+                              : (e->P.uni_cfg ? "fsk::demod_pipe3_kernel<false, true>" : "fsk::demod_pipe3_kernel<false, false>");
+        } else if (two_wave) {
           HIP_TRY(launch_demod_pipe(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
           e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_pipe_kernel<true, true>" : "fsk::demod_pipe_kernel<true, false>")
                               : (e->P.uni_cfg ? "fsk::demod_pipe_kernel<false, true>" : "fsk::demod_pipe_kernel<false, false>");
