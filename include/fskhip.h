@@ -209,6 +209,38 @@ void fskhip_butterworth_lowpass(double cutoff, double sampleRate, double b[3], d
 void fskhip_butterworth_highpass(double cutoff, double sampleRate, double b[3], double a[3]);
 void fskhip_butterworth_bandpass(double center, double bandwidth, double sampleRate, double b[3], double a[3]);
 
+/*
+ * Signal-quality ESTIMATES.  The reference's getSignalQuality() (fsk.ts:471-479,
+ * core.ts:280-288) is a stub that returns zeros for the five fields of SignalQuality (core.ts:10-16), and the host
+ * classes' getSignalQuality() keeps returning those zeros.  These two calls are an opt-in EXTENSION with its own
+ * definition (there is no reference behaviour to match; oracle/fsk_oracle.h restates it for the tests), built from values
+ * the demodulator has anyway, in its rare paths only:
+ *   at a sync (fsk.ts:315-326)            signalLevel = the mean of syncAmplitudeBuffer the silence threshold is taken from
+ *   at the first 'eod' after a sync       noiseFloor = mean of the newest floor(samplesForEOD) amplitudes (the silence that
+ *                                         caused it); frames += 1
+ *   at every completed byte (fsk.ts:367)  the stop bit's vote (ones of count slicer samples, fsk.ts:335-336):
+ *                                         eye += |2 ones - count| / count, minority += min(ones, count - ones), votes +=
+ *                                         count; and, if the data ended ...1 0, sums of f and f^2, f = the post-filter
+ *                                         output at the decision instant
+ *   at every good start bit (fsk.ts:352)  if the byte before ended ...0: sum of f at its decision instant (the mirror
+ *                                         image of the case above: one isolated bit, then the flip)
+ *   snr             20 log10(signalLevel / noiseFloor) dB, capped at 200 (digital silence has a floor of 0)
+ *   ber             minority / votes: how often a slicer sample disagrees with the bit it was voted into
+ *   eyeOpening      mean vote margin, 0 .. 1
+ *   phaseJitter     standard deviation of f over those stop-bit instants (rad per decimated sample)
+ *   frequencyOffset minus the mid-point of the two mean f, as a frequency f * (sampleRate / 2) / (2 pi) Hz: the post
+ *                   filter's lag acts on both mirrored transitions alike, a carrier offset shifts both (indicative: the
+ *                   decision instants sit one sample after the bit edge, which leaves a bias of ~15 % of the deviation)
+ * fskhip_enable_signal_quality(e, 1) clears the accumulators of every stream and starts them, (e, 0) stops them; while
+ * they run, fp32 engines demodulate on their sample-granular kernel (like traced engines), so this is a diagnostic.
+ */
+typedef struct fskhip_signal_quality {
+  double snr, ber, eyeOpening, phaseJitter, frequencyOffset;   /* SignalQuality core.ts:10-16 */
+  double signalLevel, noiseFloor, frames, bytes;               /* what they are made of */
+} fskhip_signal_quality;
+int fskhip_enable_signal_quality(fskhip_engine *e, int on);
+int fskhip_get_signal_quality(fskhip_engine *e, uint32_t stream, fskhip_signal_quality *q);
+
 /* Page-locked host memory for the _host entry points (hipHostMalloc / hipHostFree). */
 int fskhip_host_alloc(size_t bytes, void **ptr);
 int fskhip_host_free(void *ptr);

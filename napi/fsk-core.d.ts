@@ -31,8 +31,15 @@ export class FSKCore extends EventEmitter {
   reset(): void;
   isReady(): boolean;
   getSignalQuality(): { snr: number; ber: number; eyeOpening: number; phaseJitter: number; frequencyOffset: number };
+  /** opt-in extension: real estimates (include/fskhip.h), off by default; getSignalQuality() keeps the reference's zeros */
+  enableSignalQualityEstimates(on?: boolean): void;
+  getSignalQualityEstimates(): SignalQualityEstimates;
   getStatus(): FSKStatus;
   close(): void;
+}
+export interface SignalQualityEstimates {
+  snr: number; ber: number; eyeOpening: number; phaseJitter: number; frequencyOffset: number;
+  signalLevel: number; noiseFloor: number; frames: number; bytes: number;
 }
 export class FSKBatch {
   constructor(nStreams: number, configs: Partial<FSKConfig> | Partial<FSKConfig>[], options?: { device?: number; precision?: 0 | 1 });
@@ -42,6 +49,8 @@ export class FSKBatch {
   modulateData(payloads: Uint8Array[]): Float32Array[];
   reset(stream?: number): void;
   getStatus(stream?: number): FSKStatus;
+  enableSignalQualityEstimates(on?: boolean): void;
+  getSignalQualityEstimates(stream?: number): SignalQualityEstimates;
   close(): void;
 }
 /** one Node process, several GPUs: one FSKBatch per device over contiguous stream blocks, calls issued together */

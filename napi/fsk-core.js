@@ -99,6 +99,15 @@ class FSKCore extends EventEmitter {
   getSignalQuality() {              // fsk.ts:471-479: all-zero stub in the reference
     return { snr: 0, ber: 0, eyeOpening: 0, phaseJitter: 0, frequencyOffset: 0 };
   }
+  // opt-in extension (include/fskhip.h): real estimates of the same five fields plus what they are made of
+  enableSignalQualityEstimates(on) {
+    if (!this.ready || !this.handle) throw new Error('FSK demodulator not configured');
+    addon.enableSignalQuality(this.handle, on === undefined ? true : !!on);
+  }
+  getSignalQualityEstimates() {
+    if (!this.handle) return Object.assign(this.getSignalQuality(), { signalLevel: 0, noiseFloor: 0, frames: 0, bytes: 0 });
+    return addon.getSignalQualityEstimates(this.handle, 0);
+  }
 
   getStatus() {                     // fsk.ts:481-493
     if (!this.handle) {
@@ -155,6 +164,8 @@ class FSKBatch {
   }
   reset(stream) { addon.reset(this.handle, stream === undefined ? -1 : stream); }
   getStatus(stream) { return addon.getStatus(this.handle, stream || 0); }
+  enableSignalQualityEstimates(on) { addon.enableSignalQuality(this.handle, on === undefined ? true : !!on); }
+  getSignalQualityEstimates(stream) { return addon.getSignalQualityEstimates(this.handle, stream || 0); }
   close() { if (this.handle) { addon.destroy(this.handle); this.handle = null; } }
 }
 

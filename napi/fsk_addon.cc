@@ -392,6 +392,41 @@ static napi_value CarryOver(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+static void set_num(napi_env env, napi_value obj, const char *k, double v);
+
+// enableSignalQuality(handle, on) / getSignalQualityEstimates(handle, stream): the opt-in estimates of include/fskhip.h
+static napi_value EnableSignalQuality(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  fskhip_engine *e = get_engine(env, argv[0]);
+  if (!e) return nullptr;
+  bool on = true;
+  if (argc > 1) napi_get_value_bool(env, argv[1], &on);
+  int rc = fskhip_enable_signal_quality(e, on ? 1 : 0);
+  if (rc != FSKHIP_OK) return throw_fsk(env, rc);
+  return nullptr;
+}
+static napi_value GetSignalQualityEstimates(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  fskhip_engine *e = get_engine(env, argv[0]);
+  if (!e) return nullptr;
+  uint32_t stream = 0;
+  if (argc > 1) napi_get_value_uint32(env, argv[1], &stream);
+  fskhip_signal_quality q;
+  int rc = fskhip_get_signal_quality(e, stream, &q);
+  if (rc != FSKHIP_OK) return throw_fsk(env, rc);
+  napi_value obj;
+  NAPI_OK(napi_create_object(env, &obj));
+  set_num(env, obj, "snr", q.snr); set_num(env, obj, "ber", q.ber); set_num(env, obj, "eyeOpening", q.eyeOpening);
+  set_num(env, obj, "phaseJitter", q.phaseJitter); set_num(env, obj, "frequencyOffset", q.frequencyOffset);
+  set_num(env, obj, "signalLevel", q.signalLevel); set_num(env, obj, "noiseFloor", q.noiseFloor);
+  set_num(env, obj, "frames", q.frames); set_num(env, obj, "bytes", q.bytes);
+  return obj;
+}
+
 static void set_num(napi_env env, napi_value obj, const char *k, double v) {
   napi_value n;
   napi_create_double(env, v, &n);
@@ -460,6 +495,8 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"modulatedLength", nullptr, ModulatedLength, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"reset", nullptr, Reset, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"carryOver", nullptr, CarryOver, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"enableSignalQuality", nullptr, EnableSignalQuality, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"getSignalQualityEstimates", nullptr, GetSignalQualityEstimates, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"getStatus", nullptr, GetStatus, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"demodSupported", nullptr, DemodSupported, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},

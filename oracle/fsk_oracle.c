@@ -312,6 +312,10 @@ struct fsko_core {
   double sync_detections, demod_calls, total_samples;
   double eod_count;
   fsko_trace *trace;
+  /* signal-quality estimates (fsk_oracle.h: NOT the reference's getSignalQuality(), which returns zeros) */
+  int q_on, q_armed, q_prev_d0;
+  double q_last_post, q_vote_ones, q_vote_count;
+  double q_signal, q_floor, q_frames, q_f_sum, q_f2_sum, q_eye_sum, q_bytes, q_minor, q_votes, q_f0_sum, q_starts, q_ftrans;
 };
 
 void fsko_default_config(fsko_config *cfg) { /* fsk.ts:19-33 */
@@ -442,12 +446,26 @@ static void process_byte(fsko_core *c, int bit) {
   int stopBitPosition = c->cfg.parity == 0 ? 9 : 10;
   if (bitPosition == 0) {
     if (bit != 0) { reset_state(c); return; }
+    if (c->q_on && c->q_prev_d0 == 0) { c->q_f0_sum += c->q_last_post; c->q_starts += 1; } /* 0 1 -> 0: see fsk_oracle.h */
   } else if (bitPosition >= 1 && bitPosition <= 8) {
     c->byte_current |= (bit << (8 - bitPosition));
   } else if (c->cfg.parity != 0 && bitPosition == 9) {
     /* parity bit: not validated */
   } else if (bitPosition == stopBitPosition) {
     if (bit != 1) { c->started = 0; return; }
+    if (c->q_on) { /* a byte completes: the stop bit's vote and the discriminator output at its decision instant */
+      double ones = c->q_vote_ones, cnt = c->q_vote_count, zeros = cnt - ones;
+      c->q_eye_sum += fabs(2 * ones - cnt) / cnt;
+      c->q_minor += ones < zeros ? ones : zeros;
+      c->q_votes += cnt;
+      if ((c->byte_current & 3) == 2) { /* data ends 1 0, then the stop bit: 1 0 -> 1, the mirror image of 0 1 -> 0 */
+        c->q_f_sum += c->q_last_post;
+        c->q_f2_sum += c->q_last_post * c->q_last_post;
+        c->q_ftrans += 1;
+      }
+      c->q_prev_d0 = c->byte_current & 1;
+      c->q_bytes += 1;
+    }
     push_byte(c, c->byte_current);
     c->byte_current = 0;
     c->bit_position = -1;
@@ -468,6 +486,14 @@ static void process_downsampled_bit(fsko_core *c, int bitValue, double amplitude
     c->silence_count += 1;
     if (c->silence_count >= c->samples_for_eod) {
       c->eod_count += 1; /* emit('eod') */
+      if (c->q_on && c->q_armed) { /* first 'eod' after a sync: the amplitude floor of the silence that caused it */
+        double n = floor(c->samples_for_eod), sum = 0, i;
+        if (n > c->amp_ring.length) n = c->amp_ring.length;
+        for (i = 0; i < n; i += 1) sum += ring_get_f32(&c->amp_ring, c->amp_ring.length - 1 - i);
+        c->q_floor = n > 0 ? sum / n : 0;
+        c->q_frames += 1;
+        c->q_armed = 0;
+      }
       reset_state(c);
       return;
     }
@@ -501,6 +527,11 @@ static void process_downsampled_bit(fsko_core *c, int bitValue, double amplitude
           c->sync_detections += 1;
           for (i = 0; i < c->amp_ring.length; i += 1) sum += ring_get_f32(&c->amp_ring, i);
           c->silence_threshold = (sum / c->amp_ring.length) * 0.1;
+          if (c->q_on) {
+            const fsko_config *g = &c->cfg; /* the byte in front of the first start bit is the last one of the pattern */
+            int last = g->sfdLen > 0 ? g->sfdPattern[g->sfdLen - 1] : g->preambleLen > 0 ? g->preamblePattern[g->preambleLen - 1] : 1;
+            c->q_signal = sum / c->amp_ring.length; c->q_armed = 1; c->q_prev_d0 = last & 1;
+          }
         }
       }
     }
@@ -510,6 +541,7 @@ static void process_downsampled_bit(fsko_core *c, int bitValue, double amplitude
     c->bit_sample_counter += 1;
     if (c->bit_sample_counter >= c->next_bit_sample_index) {
       int bit = c->bit_accumulator > (c->bit_accum_count / 2) ? 1 : 0;
+      c->q_vote_ones = c->bit_accumulator; c->q_vote_count = c->bit_accum_count;
       c->bit_accumulator = 0; c->bit_accum_count = 0;
       c->next_bit_sample_index += c->downsampledSamplesPerBit;
       process_byte(c, bit);
@@ -550,6 +582,7 @@ static void process_sample(fsko_core *c, double sample) {
       if (t->post_out) t->post_out[t->n] = filtered;
       t->n++;
     }
+    c->q_last_post = filtered;
     process_downsampled_bit(c, bitValue, amplitude);
   }
 }
@@ -674,4 +707,27 @@ void fsko_get_status(const fsko_core *c, fsko_status *st) {
   st->totalSamplesProcessed = c->total_samples;
   st->agcGain = c->has_agc ? c->agc_gain : NAN;
   st->eodCount = c->eod_count;
+}
+
+/* ---- signal-quality estimates (an extension: the reference's getSignalQuality() is an all-zero stub) ---------------- */
+void fsko_enable_quality(fsko_core *c, int on) {
+  c->q_on = on ? 1 : 0;
+  c->q_armed = 0;
+  c->q_signal = c->q_floor = c->q_frames = c->q_f_sum = c->q_f2_sum = c->q_eye_sum = c->q_bytes = c->q_minor = c->q_votes = 0;
+  c->q_f0_sum = c->q_starts = c->q_ftrans = 0;
+}
+void fsko_get_quality(const fsko_core *c, fsko_quality *q) {
+  memset(q, 0, sizeof(*q));
+  q->frames = c->q_frames; q->bytes = c->q_bytes;
+  q->signalLevel = c->q_signal; q->noiseFloor = c->q_floor;
+  if (c->q_frames > 0) q->snr = c->q_floor > 0 ? fmin(200.0, 20 * log10(c->q_signal / c->q_floor)) : 200.0;
+  if (c->q_votes > 0) q->ber = c->q_minor / c->q_votes;
+  if (c->q_bytes > 0) q->eyeOpening = c->q_eye_sum / c->q_bytes;
+  if (c->q_ftrans > 0) {
+    double m = c->q_f_sum / c->q_ftrans, v = c->q_f2_sum / c->q_ftrans - m * m;
+    q->phaseJitter = sqrt(v > 0 ? v : 0);
+    if (c->q_starts > 0) /* mid-point of the two mirrored transitions: the post filter's lag cancels, a carrier offset does not.
+                            The mixer turns a tone ABOVE the centre into a phase that falls (fsk.ts:229-230), hence the sign */
+      q->frequencyOffset = -0.5 * (m + c->q_f0_sum / c->q_starts) * (c->cfg.sampleRate / c->downsampleRatio) / (2 * M_PI);
+  }
 }

@@ -76,6 +76,10 @@ def lib():
         L.fsko_reset.argtypes = [C.c_void_p]
         L.fsko_get_status.argtypes = [C.c_void_p, C.POINTER(Status)]
         L.fsko_set_trace.argtypes = [C.c_void_p, C.POINTER(Trace)]
+        L.fsko_enable_quality.argtypes = [C.c_void_p, C.c_int]
+        L.fsko_enable_quality.restype = None
+        L.fsko_get_quality.argtypes = [C.c_void_p, C.POINTER(Quality)]
+        L.fsko_get_quality.restype = None
         L.fsko_default_config.argtypes = [C.POINTER(Config)]
         for nm in ("lowpass", "highpass"):
             f = getattr(L, "fsko_butterworth_" + nm)
@@ -104,6 +108,12 @@ def lib():
         L.fsko_fir_reset.argtypes = [C.c_void_p]
         _lib = L
     return _lib
+
+
+class Quality(C.Structure):
+    """fsko_quality (fsk_oracle.h): signal-quality estimates, an extension the oracle defines"""
+    _fields_ = [(k, C.c_double) for k in ("snr", "ber", "eyeOpening", "phaseJitter", "frequencyOffset",
+                                          "signalLevel", "noiseFloor", "frames", "bytes")]
 
 
 def make_config(cfg=None):
@@ -182,6 +192,14 @@ class OracleCore:
         st = Status()
         lib().fsko_get_status(self._h, C.byref(st))
         return {k: getattr(st, k) for k, _ in Status._fields_}
+
+    def enable_quality(self, on=True):
+        lib().fsko_enable_quality(self._h, 1 if on else 0)
+
+    def quality(self):
+        q = Quality()
+        lib().fsko_get_quality(self._h, C.byref(q))
+        return {k: getattr(q, k) for k, _ in Quality._fields_}
 
     def enable_trace(self, cap, pre_cap):
         t = Trace()

@@ -55,6 +55,24 @@ async function gpuTests() {
     assert.strictEqual(st.totalSamplesProcessed, 2480);
     assert.ok(Math.abs(st.silenceThreshold - 0.16749451808631421) < (precision === M.PRECISION_F64 ? 1e-12 : 2e-6));
     assert.strictEqual(events.filter((e) => e === 'eod').length, 1);
+    // getSignalQuality(): the reference's zeros (fsk.ts:471-479); the opt-in estimates are an extension (include/fskhip.h)
+    assert.deepStrictEqual(core.getSignalQuality(), { snr: 0, ber: 0, eyeOpening: 0, phaseJitter: 0, frequencyOffset: 0 });
+    {
+      const q = new M.FSKCore({ precision });
+      q.configure({});
+      q.enableSignalQualityEstimates();
+      const msg = await q.modulateData(str('signal quality estimates, please'));
+      const padded = new Float32Array(msg.length + 1200);
+      padded.set(msg, 100);
+      assert.strictEqual(Buffer.from(await q.demodulateData(padded)).toString('ascii'), 'signal quality estimates, please');
+      const est = q.getSignalQualityEstimates();
+      assert.strictEqual(est.frames, 1);
+      assert.strictEqual(est.bytes, 32);
+      assert.ok(est.snr > 60 && est.eyeOpening > 0.5 && est.eyeOpening <= 1 && est.signalLevel > 0.1, JSON.stringify(est));
+      assert.ok(Math.abs(est.frequencyOffset) < 40, JSON.stringify(est));
+      assert.deepStrictEqual(q.getSignalQuality(), { snr: 0, ber: 0, eyeOpening: 0, phaseJitter: 0, frequencyOffset: 0 });
+      q.close();
+    }
     // configure() on a configured instance (fsk.ts:133-157): resetState() semantics, silence.threshold and the debug
     // counters survive, the AGC is new
     const thrBefore = st.silenceThreshold;

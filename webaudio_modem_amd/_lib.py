@@ -35,6 +35,12 @@ class Config(C.Structure):
     ]
 
 
+class SignalQuality(C.Structure):
+    """fskhip_signal_quality (include/fskhip.h): opt-in estimates; the reference's getSignalQuality() is all zeros"""
+    _fields_ = [(k, C.c_double) for k in ("snr", "ber", "eyeOpening", "phaseJitter", "frequencyOffset",
+                                          "signalLevel", "noiseFloor", "frames", "bytes")]
+
+
 class Status(C.Structure):
     """fskhip_status == getStatus() (fsk.ts:481-493) + agcGain + eodCount."""
     _fields_ = [
@@ -86,6 +92,8 @@ _SYMBOLS = [
     ("fskhip_butterworth_bandpass", None, [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
                                            C.POINTER(C.c_double)]),
     ("fskhip_carry_over", C.c_int, [_P, _P]),
+    ("fskhip_enable_signal_quality", C.c_int, [_P, C.c_int]),
+    ("fskhip_get_signal_quality", C.c_int, [_P, C.c_uint32, C.POINTER(SignalQuality)]),
     ("fskhip_host_alloc", C.c_int, [C.c_size_t, C.POINTER(_P)]),
     ("fskhip_host_free", C.c_int, [_P]),
     ("fskhip_device_malloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),

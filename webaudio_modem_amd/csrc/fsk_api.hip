@@ -199,7 +199,7 @@ size_t engine_max_bytes(const fskhip_engine *e, size_t n_per_stream) {
 // everything fskhip_demodulate_device's choice of launches depends on besides its arguments
 uint32_t engine_launch_key(const fskhip_engine *e) {
   return (e->ds_uniform ? 1u : 0u) | (e->ds_parity << 1) | (e->force_generic ? 4u : 0u) | (e->timing ? 8u : 0u) |
-         (e->use_split ? 32u : 0u) | (e->gen_odd ? 64u : 0u) | (e->use_split3 ? 128u : 0u) |
+         (e->use_split ? 32u : 0u) | (e->gen_odd ? 64u : 0u) | (e->use_split3 ? 128u : 0u) | (e->P.quality ? 256u : 0u) |
          (e->S.trace_stream != 0xFFFFFFFFu ? 16u : 0u);
 }
 void engine_note_replayed_call(fskhip_engine *e, size_t n) {
@@ -428,6 +428,10 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     // sampleCount is >= 1 when the compare runs, so a threshold <= 1 behaves like 1
     double m = std::ceil(for_eod);
     P.eod_min = m <= 1 ? 1u : (uint32_t)m;
+    // opt-in signal-quality estimates (include/fskhip.h)
+    P.quality = 0;
+    P.q_eod_n = (uint32_t)std::floor(for_eod);
+    P.q_last_d0 = (uint32_t)((c0.sfdLen > 0 ? c0.sfdPattern[c0.sfdLen - 1] : c0.preambleLen > 0 ? c0.preamblePattern[c0.preambleLen - 1] : 1) & 1);
   }
   P.pat_q = 0; P.pat_mask = 0;
   for (uint32_t j = 1; j < n_bits && j < 64; j++) {
@@ -652,7 +656,7 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
         if ((a & 3u) != 0 || ((a >> 2) & 1u) != p0) tiles = false;
         else head = a >> 2;
       }
-      if (e->S.trace_stream != 0xFFFFFFFFu) tiles = false;   // a traced engine stays on the sample-granular kernel
+      if (e->S.trace_stream != 0xFFFFFFFFu || e->P.quality) tiles = false;   // diagnostics (traces, quality estimates) run on the sample-granular kernel
       if (tiles && head < n) n_fast = (n - head) & ~(size_t)15;
       if (!n_fast) head = n;   // all of it sample by sample
       bool app = append_first;
@@ -890,6 +894,60 @@ int fskhip_get_status(fskhip_engine *e, uint32_t stream, fskhip_status *st) {
   st->totalSamplesProcessed = (double)(e->total_samples - e->base_samples[stream]);
   st->agcGain = e->P.agc_on ? r.agc_gain : std::numeric_limits<double>::quiet_NaN();
   st->eodCount = r.eod_total;
+  return FSKHIP_OK;
+}
+
+// ---- opt-in signal-quality estimates (the definition is in include/fskhip.h) ----------------
+int fskhip_enable_signal_quality(fskhip_engine *e, int on) {
+  if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "not configured");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t n = e->n_streams, rsz = e->precision == FSKHIP_PRECISION_F64 ? sizeof(double) : sizeof(float);
+  if (on) {   // the accumulators are contiguous rows at the end of both state arrays
+    HIP_TRY(hipMemset((char *)e->S.rs + (size_t)RF_q_signal * n * rsz, 0, (size_t)(RF_COUNT - RF_q_signal) * n * rsz));
+    HIP_TRY(hipMemset(e->S.is + (size_t)IF_q_armed * n, 0, (size_t)(IF_COUNT - IF_q_armed) * n * sizeof(uint32_t)));
+  }
+  e->P.quality = on ? 1u : 0u;
+  return FSKHIP_OK;
+}
+
+int fskhip_get_signal_quality(fskhip_engine *e, uint32_t stream, fskhip_signal_quality *q) {
+  if (!q) return fail(FSKHIP_E_INVALID, "null result");
+  std::memset(q, 0, sizeof(*q));
+  if (!e) return FSKHIP_OK;                       // unconfigured FSKCore: the reference's zeros
+  if (stream >= e->n_streams) return fail(FSKHIP_E_INVALID, "stream out of range");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t n = e->n_streams;
+  const bool f64 = e->precision == FSKHIP_PRECISION_F64;
+  double rv[RF_COUNT - RF_q_signal];
+  uint32_t iv[IF_COUNT - IF_q_armed];
+  for (int f = RF_q_signal; f < RF_COUNT; f++) {
+    if (f64) {
+      HIP_TRY(hipMemcpy(&rv[f - RF_q_signal], (const double *)e->S.rs + (size_t)f * n + stream, sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+      float v;
+      HIP_TRY(hipMemcpy(&v, (const float *)e->S.rs + (size_t)f * n + stream, sizeof(float), hipMemcpyDeviceToHost));
+      rv[f - RF_q_signal] = v;
+    }
+  }
+  for (int f = IF_q_armed; f < IF_COUNT; f++)
+    HIP_TRY(hipMemcpy(&iv[f - IF_q_armed], e->S.is + (size_t)f * n + stream, sizeof(uint32_t), hipMemcpyDeviceToHost));
+#define QR(name) rv[RF_##name - RF_q_signal]
+#define QI(name) ((double)iv[IF_##name - IF_q_armed])
+  q->frames = QI(q_frames); q->bytes = QI(q_bytes);
+  q->signalLevel = QR(q_signal); q->noiseFloor = QR(q_floor);
+  if (QI(q_frames) > 0) q->snr = QR(q_floor) > 0 ? std::fmin(200.0, 20.0 * std::log10(QR(q_signal) / QR(q_floor))) : 200.0;
+  if (QI(q_votes) > 0) q->ber = QI(q_minor) / QI(q_votes);
+  if (QI(q_bytes) > 0) q->eyeOpening = QR(q_eye_sum) / QI(q_bytes);
+  if (QI(q_ftrans) > 0) {
+    const double m = QR(q_f_sum) / QI(q_ftrans), v = QR(q_f2_sum) / QI(q_ftrans) - m * m;
+    q->phaseJitter = std::sqrt(v > 0 ? v : 0.0);
+    if (QI(q_starts) > 0)
+      q->frequencyOffset = -0.5 * (m + QR(q_f0_sum) / QI(q_starts)) * (e->cfg0.sampleRate / 2.0) / (2.0 * 3.14159265358979323846);
+  }
+#undef QR
+#undef QI
   return FSKHIP_OK;
 }
 

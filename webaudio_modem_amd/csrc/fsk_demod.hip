@@ -388,7 +388,7 @@ template <typename Real, typename PolyT, bool FRAC>
 __device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, const DemodState &S, PolyT *poly,
                                        PolyT *poly_u, RingPos &R, uint32_t need, uint32_t ring_base,
                                        uint32_t amp_base, uint32_t lane, uint32_t row, bool valid, bool act, bool bitb,
-                                       Real amp, OutCtx &O) {
+                                       Real amp, OutCtx &O, Real post = (Real)0) {
   const PolyT qn = (PolyT)~P.pat_q, mask = (PolyT)P.pat_mask;
   const PolyT qn2 = (PolyT)(qn << 1), mask2 = (PolyT)(mask << 1);
   const uint32_t bit = bitb ? 1u : 0u;
@@ -434,6 +434,11 @@ __device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
 
   // ---- rare path 1: end of data (fsk.ts:288-291) ------------------------------------------------
   if (__ballot(eod)) {
+    if (P.quality) {   // opt-in estimates: the noise floor of the silence that caused the first 'eod' after a sync
+      const uint32_t pushes = amp_base + R.k;
+      quality_on_eod<Real>(P, S, lane, row, eod & valid, R.amp_pos ? R.amp_pos - 1u : P.amp_cap - 1u,
+                           pushes < P.amp_cap ? pushes : P.amp_cap);
+    }
     if (eod) {
       O.eod_cnt++;
       L.eod_total++;
@@ -467,16 +472,21 @@ __device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
         part += (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L1 bypass
       }
       const double sum = wave_sum(part);
-      if ((int)lane == src) L.sil_thr = (Real)((sum / (double)slen) * 0.1);
+      if ((int)lane == src) {
+        L.sil_thr = (Real)((sum / (double)slen) * 0.1);
+        if (P.quality) quality_on_sync<Real>(P, S, row, sum / (double)slen);
+      }
     }
   }
   // ---- rare path 3 (some lane nearly every step): bit decision + processByte (fsk.ts:335-375) ---
   const bool dec_now = decide & !eod & (L.started != 0);
   if (__ballot(dec_now)) {
-    bool emit = false, bad_start = false;
+    bool emit = false, bad_start = false, good_start = false;
+    uint32_t q_cnt = 0, q_ones = 0;
     if (dec_now) {
       const uint32_t cnt = L.bit_reload - L.bit_wait;           // bitAccumCount
       const uint32_t b = (2u * L.bit_acc > cnt) ? 1u : 0u;      // fsk.ts:336
+      q_cnt = cnt; q_ones = L.bit_acc;
       L.bit_acc = 0;
       L.bit_wait += P.d;                                        // nextBitSampleIndex += dsSPB
       L.bit_reload = L.bit_wait;
@@ -486,6 +496,7 @@ __device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
       L.byte_cur |= b << ((8u - pos) & 31u);
       const bool is_stop = pos == P.stop_pos;
       bad_start = (pos == 0) & (b != 0);
+      good_start = (pos == 0) & (b == 0);
       emit = is_stop & (b != 0);
       L.bit_pos = is_stop ? 0u : pos + 1;
       if (is_stop & (b == 0)) {                                 // bad stop bit: fsk.ts:363-366
@@ -495,6 +506,10 @@ __device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
     }
     if (__ballot(bad_start)) {
       if (bad_start) { reset_state(L, P.matched_min); did_reset = true; }  // fsk.ts:352-355
+    }
+    if (P.quality) {
+      if (good_start & valid) quality_on_start<Real>(P, S, row, post);
+      if (emit & valid) quality_on_byte<Real>(P, S, row, (uint32_t)(uint8_t)L.byte_cur, q_ones, q_cnt, post);
     }
     if (__ballot(emit)) {
       if (emit) {
@@ -631,7 +646,7 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
         trace_put(amp, post, bit);
       }
       downsampled_bit<Real, PolyT, FRAC>(L, P, S, poly, poly_u, R, need, ring_base, amp_base, lane, row, valid,
-                                         UNI || dec, bit, amp, O);
+                                         UNI || dec, bit, amp, O, post);
     }
   };
 
@@ -686,7 +701,7 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
       const bool bit = p ? bit1 : bit0;
       trace_put(amp, post, bit);
       const bool rst = downsampled_bit<Real, PolyT, FRAC>(L, P, S, poly, poly_u, R, need, ring_base, amp_base, lane,
-                                                          row, valid, true, bit, amp, O);
+                                                          row, valid, true, bit, amp, O, post);
       if (p == 0 && __ballot(rst)) {
         if (rst) {  // resetState() ran after pair 0: redo the reset-sensitive half of samples 2,3
           Real gi2, gq2, gi3, gq3;

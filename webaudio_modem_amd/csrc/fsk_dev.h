@@ -83,4 +83,71 @@ __device__ inline void ist_store(const FastMem &M, uint32_t field, uint32_t v) {
   __builtin_amdgcn_raw_buffer_store_b32(v, M.is_rsrc, M.voff, field * M.fld, 0);
 }
 
+
+// ---- opt-in signal-quality estimates (definition: include/fskhip.h) -- rare paths only, state read-modify-written -----
+template <typename Real>
+__device__ inline Real &q_real(const DemodState &S, uint32_t n, int field, uint32_t row) { return ((Real *)S.rs)[(size_t)field * n + row]; }
+__device__ inline uint32_t &q_int(const DemodState &S, uint32_t n, int field, uint32_t row) { return S.is[(size_t)field * n + row]; }
+
+template <typename Real>
+__device__ inline void quality_on_sync(const DemodParams &P, const DemodState &S, uint32_t row, double mean_amp) {
+  q_real<Real>(S, P.n_streams, RF_q_signal, row) = (Real)mean_amp;
+  q_int(S, P.n_streams, IF_q_armed, row) = 1u;
+  q_int(S, P.n_streams, IF_q_prev_d0, row) = P.q_last_d0;
+}
+template <typename Real>
+__device__ inline void quality_on_start(const DemodParams &P, const DemodState &S, uint32_t row, Real post) {
+  if (q_int(S, P.n_streams, IF_q_prev_d0, row) == 0u) {
+    q_real<Real>(S, P.n_streams, RF_q_f0_sum, row) += post;
+    q_int(S, P.n_streams, IF_q_starts, row) += 1u;
+  }
+}
+template <typename Real>
+__device__ inline void quality_on_byte(const DemodParams &P, const DemodState &S, uint32_t row, uint32_t byte, uint32_t ones,
+                                       uint32_t cnt, Real post) {
+  const uint32_t n = P.n_streams, zeros = cnt - ones;
+  const int32_t margin = (int32_t)(2u * ones) - (int32_t)cnt;
+  q_real<Real>(S, n, RF_q_eye_sum, row) += (Real)(margin < 0 ? -margin : margin) / (Real)cnt;
+  q_int(S, n, IF_q_minor, row) += ones < zeros ? ones : zeros;
+  q_int(S, n, IF_q_votes, row) += cnt;
+  if ((byte & 3u) == 2u) {
+    q_real<Real>(S, n, RF_q_f_sum, row) += post;
+    q_real<Real>(S, n, RF_q_f2_sum, row) += post * post;
+    q_int(S, n, IF_q_ftrans, row) += 1u;
+  }
+  q_int(S, n, IF_q_prev_d0, row) = byte & 1u;
+  q_int(S, n, IF_q_bytes, row) += 1u;
+}
+// First 'eod' after a sync: mean of the newest min(q_eod_n, len) amplitudes.  Whole wave; `hit` marks the lanes at an
+// 'eod', newest = ring index of the amplitude just stored, len = entries in the ring.
+template <typename Real>
+__device__ inline void quality_on_eod(const DemodParams &P, const DemodState &S, uint32_t lane, uint32_t row, bool hit,
+                                      uint32_t newest, uint32_t len) {
+  const uint32_t n = P.n_streams;
+  const bool armed = hit && q_int(S, n, IF_q_armed, row) != 0u;
+  uint64_t m = __builtin_amdgcn_ballot_w64(armed);
+  if (!m) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's ring stores have reached L2
+  while (m) {
+    const int src = __builtin_ctzll(m);
+    m &= m - 1;
+    const uint32_t srow = (uint32_t)__builtin_amdgcn_readlane((int)row, src);
+    const uint32_t snew = (uint32_t)__builtin_amdgcn_readlane((int)newest, src);
+    uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)len, src);
+    cnt = cnt < P.q_eod_n ? cnt : P.q_eod_n;
+    double part = 0.0;
+    for (uint32_t i = lane; i < cnt; i += 64) {
+      const uint32_t pos = snew >= i ? snew - i : snew + P.amp_cap - i;
+      const float *p = S.amp_ring + (size_t)pos * n + srow;
+      part += (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double sum = wave_sum(part);
+    if ((int)lane == src) {
+      q_real<Real>(S, n, RF_q_floor, row) = (Real)(cnt ? sum / (double)cnt : 0.0);
+      q_int(S, n, IF_q_frames, row) += 1u;
+      q_int(S, n, IF_q_armed, row) = 0u;
+    }
+  }
+}
+
 }  // namespace fsk

@@ -49,6 +49,12 @@ namespace fsk {
   X(amp_pos) X(amp_len) /* syncAmplitudeBuffer write index / length */                      \
   X(sync_det)           /* debug.syncDetections */                                          \
   X(eod_total)          /* 'eod' events since create */
+// Opt-in signal-quality estimates (fskhip_enable_signal_quality; include/fskhip.h has the definition): touched by the
+// rare paths only (sync, first 'eod' after it, start / stop bit positions), read-modify-written in HBM.
+#define FSK_REAL_FIELDS_QUALITY(X)                                                          \
+  X(q_signal) X(q_floor) X(q_f_sum) X(q_f2_sum) X(q_f0_sum) X(q_eye_sum)
+#define FSK_INT_FIELDS_QUALITY(X)                                                           \
+  X(q_armed) X(q_prev_d0) X(q_frames) X(q_bytes) X(q_minor) X(q_votes) X(q_starts) X(q_ftrans)
 #define FSK_INT_FIELDS_PIPE(X)                                                              \
   X(fr_lo) X(fr_hi)     /* fp32: NCO phase minus the free-running frame's phase (64-bit turns); */ \
                         /* changes only at resetState()                                     */      \
@@ -58,6 +64,7 @@ enum RealField {
 #define X(n) RF_##n,
   FSK_REAL_FIELDS(X)
   FSK_REAL_FIELDS_PIPE(X)
+  FSK_REAL_FIELDS_QUALITY(X)
 #undef X
   RF_COUNT
 };
@@ -65,6 +72,7 @@ enum IntField {
 #define X(n) IF_##n,
   FSK_INT_FIELDS(X)
   FSK_INT_FIELDS_PIPE(X)
+  FSK_INT_FIELDS_QUALITY(X)
 #undef X
   IF_COUNT
 };
@@ -120,6 +128,10 @@ struct DemodParams {
   uint32_t u_inc_lo, u_inc_hi;     // one NCO step (turns * 2^64), uniform configuration
   float z_c1, z_c2;                // zero-input response of the I/Q low-pass as pair sums: q[m+2] = c1 q[m+1] - c2 q[m]
   float z_ya, z_yb, z_va, z_vb;    // (y, v) of that response at an even sample from the next two pair sums (q[m], q[m+1])
+  // opt-in signal-quality estimates
+  uint32_t quality;                // 1: accumulate them
+  uint32_t q_last_d0;              // lowest bit of the last pattern byte (the byte in front of a frame's first start bit)
+  uint32_t q_eod_n;                // floor(silence.samplesForEOD): amplitudes averaged for the noise floor
 };
 
 struct DemodState {

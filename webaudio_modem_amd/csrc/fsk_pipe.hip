@@ -256,7 +256,8 @@ __device__ inline void nco_phasor(uint64_t acc, float &c, float &s) {
 // PA: the front wave has evaluated the discriminator's phase / magnitude on U already (ph_u, amp_u); otherwise this
 // function does.  They stand unless the correction changed a bit of U in some lane, in which case the wave re-evaluates --
 // same function, same inputs where nothing changed, so the result does not depend on which wave computed it.
-// TRC: honour fskhip_trace_enable (the sample-granular kernel only; a traced engine runs entirely on it).
+// TRC: honour fskhip_trace_enable and fskhip_enable_signal_quality (the sample-granular kernel only; an engine with
+// either switched on runs entirely on it).
 template <bool UNI, bool PA = false, bool TRC = false>
 __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams &P, const DemodState &S, const FastMem &M,
                                  uint32_t *poly, uint32_t lane, __amdgpu_buffer_rsrc_t amp_rsrc, uint8_t *out,
@@ -402,6 +403,11 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
     const bool eod = (int32_t)e1 < 0;
     const bool cand = ((int32_t)m1 >= 0) & (B.rho == X.k % P.cadence);   // globalSampleCounter % round(dsSPB/4) == 0
     if (__builtin_amdgcn_ballot_w64(eod)) {                    // fsk.ts:288-291
+      if (TRC && P.quality) {   // opt-in estimates (sample-granular kernel only): the noise floor of the silence behind the first 'eod' after a sync
+        const uint32_t pushes = ist_load(M, IF_amp_len) + X.k;
+        quality_on_eod<float>(P, S, lane, M.voff >> 2, eod & (M.voff < 0xFFFFFFF0u), X.amp_soff / (P.n_streams * 4u),
+                              pushes < P.amp_cap ? pushes : P.amp_cap);
+      }
       if (eod) {
         ist_store(M, IF_eod_total, ist_load(M, IF_eod_total) + 1u);
         if (eod_counts && M.voff < 0xFFFFFFF0u) eod_counts[M.voff >> 2] += 1u;
@@ -438,7 +444,10 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
           part += (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const double sum = wave_sum(part);
-        if ((int)lane == src) B.thr = (float)((sum / (double)sl) * 0.1);   // fsk.ts:321-326
+        if ((int)lane == src) {
+          B.thr = (float)((sum / (double)sl) * 0.1);           // fsk.ts:321-326
+          if (TRC && P.quality) quality_on_sync<float>(P, S, M.voff >> 2, sum / (double)sl);
+        }
       }
     }
   }
@@ -447,6 +456,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   // part -- vote, clock advance, shifting the bit in -- runs for all lanes as masked arithmetic (one mask, bit ops) instead
   // of a divergent block per step; only start and stop positions (two in ten decisions) branch.
   const uint32_t s0 = B.sreg;
+  const uint32_t cnt0 = X.kv - B.tlast, ones0 = B.acc;         // the vote, for the opt-in estimates at start / stop positions
   const uint32_t b = sign_bit((X.kv - B.tlast) - B.acc - B.acc);   // 2 * bitAccumulator > bitAccumCount (fsk.ts:336)
   B.sreg = (s0 & ~dm) | ((s0 + s0 + b) & dm);
   B.acc &= ~dm;
@@ -459,6 +469,11 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
     const bool good_stop = at_stop & (b != 0u);
     const bool bad_stop = at_stop & (b == 0u);
     const bool bad_start = edge & (s0 == 1u) & (b != 0u);            // fsk.ts:352-355
+    if (TRC && P.quality) {
+      if (edge & (s0 == 1u) & (b == 0u) & (M.voff < 0xFFFFFFF0u)) quality_on_start<float>(P, S, M.voff >> 2, f);
+      if (good_stop & (M.voff < 0xFFFFFFF0u))
+        quality_on_byte<float>(P, S, M.voff >> 2, (s0 >> (P.stop_pos - 9u)) & 0xFFu, ones0, cnt0, f);
+    }
     if (good_stop) {                                                 // stop bit: fsk.ts:367-368
       if (M.voff < 0xFFFFFFF0u && B.out_cnt < out_pitch)
         out[(size_t)(M.voff >> 2) * out_pitch + B.out_cnt] = (uint8_t)(s0 >> (P.stop_pos - 9u));

@@ -213,6 +213,15 @@ class FSKEngine:
         _lib.check(self._L.fskhip_get_status(self._h, stream, C.byref(st)))
         return _status_dict(st)
 
+    # ---- opt-in signal-quality estimates (include/fskhip.h; the reference's getSignalQuality() returns zeros) -------
+    def enable_signal_quality(self, on=True):
+        _lib.check(self._L.fskhip_enable_signal_quality(self._h, 1 if on else 0))
+
+    def get_signal_quality(self, stream=0):
+        q = _lib.SignalQuality()
+        _lib.check(self._L.fskhip_get_signal_quality(self._h, stream, C.byref(q)))
+        return {k: getattr(q, k) for k, _ in _lib.SignalQuality._fields_}
+
     def demod_supported(self):
         return bool(self._L.fskhip_demod_supported(self._h))
 

@@ -111,8 +111,19 @@ class FSKCore(EventEmitter):
             self._engine.reset(0)
 
     # getSignalQuality() fsk.ts:471-479: all-zero stub in the reference
-    def getSignalQuality(self):
+    def getSignalQuality(self):       # fsk.ts:471-479: the reference's stub, kept
         return {"snr": 0, "ber": 0, "eyeOpening": 0, "phaseJitter": 0, "frequencyOffset": 0}
+
+    # opt-in extension (include/fskhip.h): real estimates of the same five fields, from the demodulator's rare paths
+    def enableSignalQualityEstimates(self, on=True):
+        if self._engine is None:
+            raise RuntimeError("FSK demodulator not configured")
+        self._engine.enable_signal_quality(on)
+
+    def getSignalQualityEstimates(self):
+        if self._engine is None:
+            return dict(self.getSignalQuality(), signalLevel=0, noiseFloor=0, frames=0, bytes=0)
+        return self._engine.get_signal_quality(0)
 
     # getStatus() fsk.ts:481-493
     def getStatus(self):
