@@ -21,7 +21,9 @@
 extern "C" {
 #endif
 
-#define FSKHIP_ABI_VERSION 2
+/* 2: fskhip_max_bytes, fskhip_last_kernel.  3: fskhip_carry_over, fskhip_host_alloc / _free, the pipelined
+ * fskhip_demodulate_host, fskhip_enable_signal_quality / fskhip_get_signal_quality (additions only). */
+#define FSKHIP_ABI_VERSION 3
 #define FSKHIP_MAX_PATTERN_BYTES 16
 
 enum {
