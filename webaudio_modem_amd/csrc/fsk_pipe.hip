@@ -780,7 +780,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
         nco_phasor(tacc, zr, zi);
         tacc += inc16;
       }
-#pragma unroll 1
+#pragma unroll
       for (uint32_t hf = 0; hf < 2; hf++) {
         const uint32_t hidx = 2u * t + hf;                  // half tiles produced so far
         while (hidx - consumed >= kPipeSlots) {             // ring full: wait for the back wave
@@ -882,6 +882,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
     const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
     uint32_t produced = 0, slot_i = 0;
     const uint32_t nh = 2u * (uint32_t)n_tiles;             // half tiles
+#pragma unroll 2
     for (uint32_t t = 0; t < nh; t++) {
       while (produced <= t) {
         produced = lds_peek(&ctr[0]);
