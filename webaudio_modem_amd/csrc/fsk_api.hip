@@ -754,6 +754,15 @@ int fskhip_demodulate_host(fskhip_engine *e, float *samples, size_t n, size_t pi
         HIP_TRY(hipEventCreateWithFlags(&e->ev_used_up[i], hipEventDisableTiming));
       }
     }
+    // on a failure inside the pipeline, let what is in flight on both streams finish before the caller's buffers go away
+#define PIPE_TRY(expr)                                                                               \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess) {                                                                          \
+      (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamSynchronize(e->stream);             \
+      return fail(FSKHIP_E_HIP, "%s: %s", #expr, hipGetErrorString(_e));                            \
+    }                                                                                                \
+  } while (0)
     float *buf[2] = {e->d_samples, e->d_samples2};
     size_t off = 0;
     for (size_t j = 0; off < n; j++) {
@@ -761,20 +770,21 @@ int fskhip_demodulate_host(fskhip_engine *e, float *samples, size_t n, size_t pi
       const size_t len = (n - off > slab + slab / 2) ? slab : n - off;
       if (len > dpitch) return fail(FSKHIP_E_INVALID, "internal: slab %zu exceeds staging pitch %zu", len, dpitch);
       const int b = (int)(j & 1);
-      if (j >= 2) HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_used_up[b], 0));   // its previous user has finished
-      HIP_TRY(hipMemcpy2DAsync(buf[b], dpitch * sizeof(float), samples + off, pitch * sizeof(float), len * sizeof(float), S,
+      if (j >= 2) PIPE_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_used_up[b], 0));   // its previous user has finished
+      PIPE_TRY(hipMemcpy2DAsync(buf[b], dpitch * sizeof(float), samples + off, pitch * sizeof(float), len * sizeof(float), S,
                                hipMemcpyHostToDevice, e->copy_stream));
-      HIP_TRY(hipEventRecord(e->ev_copied[b], e->copy_stream));
-      HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_copied[b], 0));
+      PIPE_TRY(hipEventRecord(e->ev_copied[b], e->copy_stream));
+      PIPE_TRY(hipStreamWaitEvent(e->stream, e->ev_copied[b], 0));
       rc = demod_device_impl(e, buf[b], len, dpitch, e->d_out, out_pitch, e->d_counts, e->d_eod, flags, e->stream,
                              /*append_first=*/j > 0, /*count_call=*/j == 0);
       if (rc != FSKHIP_OK) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamSynchronize(e->stream); return rc; }
       if (wb)
-        HIP_TRY(hipMemcpy2DAsync(samples + off, pitch * sizeof(float), buf[b], dpitch * sizeof(float), len * sizeof(float), S,
+        PIPE_TRY(hipMemcpy2DAsync(samples + off, pitch * sizeof(float), buf[b], dpitch * sizeof(float), len * sizeof(float), S,
                                  hipMemcpyDeviceToHost, e->stream));
-      HIP_TRY(hipEventRecord(e->ev_used_up[b], e->stream));
+      PIPE_TRY(hipEventRecord(e->ev_used_up[b], e->stream));
       off += len;
     }
+#undef PIPE_TRY
   }
   if (out_pitch > 0) HIP_TRY(hipMemcpyAsync(out, e->d_out, out_pitch * S, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipMemcpyAsync(out_counts, e->d_counts, sizeof(uint32_t) * S, hipMemcpyDeviceToHost, e->stream));
