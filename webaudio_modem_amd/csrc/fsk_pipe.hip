@@ -40,10 +40,14 @@
 //
 // Kernels:
 //   demod_pipe_kernel   two waves per 64-stream group: wave 0 front, wave 1 back, hand-off through an LDS ring of
-//                       16-sample tiles with producer/consumer counters (no barrier in the loop).  For batches
+//                       8-sample half tiles with producer/consumer counters (no barrier in the loop).  For batches
 //                       that give a SIMD fewer than ~3 waves (BASELINE configs #2, #3, #5).
+//   demod_pipe3_kernel  three waves per group (AGC + pre-filter | mixer + low-pass + discriminator | back) for batches
+//                       of two groups per CU, where a third instruction stream gives SIMDs a second wave.
 //   demod_fused_kernel  the same two halves called back to back by one wave, pair by pair through registers, for
 //                       batches large enough to fill the SIMDs with one wave per group.
+//   demod_tail_kernel   the same arithmetic one sample at a time: heads and tails of calls, traced engines, engines with
+//                       the signal-quality estimates switched on.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
