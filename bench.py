@@ -284,6 +284,21 @@ def main():
             traffic = round(tj["hbm_bytes_per_input_sample"] * S * N / avg_kernel_s / 1e9, 1)
             traffic_src = "profiles/r02_traffic.json (separate rocprofv3 --pmc passes of this kernel; bytes per input sample x this run's rate, not counters of this run)"
 
+    # the ceiling that actually binds (VERDICT r01 #2b): instruction issue.  The instruction mix and its pricing are a
+    # committed profile of this kernel (like the traffic figure); the nanoseconds per sample are this run's.
+    issue = None
+    is_path = os.path.join(ROOT, "profiles", "r02_issue.json")
+    if os.path.exists(is_path):
+        with open(is_path) as fh:
+            ij = json.load(fh)
+        if ij.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
+            ns = avg_kernel_s / N * 1e9
+            issue = {"insts_per_group_sample": ij["insts_per_group_sample"],
+                     "modelled_cycles_per_group_sample": ij["modelled_cycles_per_group_sample"],
+                     "measured_ns_per_sample": round(ns, 1),
+                     "measured_cycles_per_sample_at_2.1_to_2.4_GHz": [round(ns * 2.1), round(ns * 2.4)],
+                     "source": ij["source"] + "; nanoseconds per sample from this run"}
+
     if rank == 0:
         line = {
             "metric": "Msamples/s demodulated (fused I/Q demod kernel, inputs resident in HBM)",
@@ -307,6 +322,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kernel_name, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                "issue_ceiling": issue,
                 "issue_ceiling_note": "the kernel is instruction-issue bound, not HBM bound: see DESIGN.md section 5 "
                                       "(profiles/r02_valu_probe_summary.md for the per-instruction costs it is priced with)",
             },
