@@ -44,6 +44,9 @@ WORKLOADS = {
     # BASELINE.json configs[4]: Bell-202 through AWGN at 10 dB (the demodulation half of the round trip)
     "c5": dict(cfg=dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200), payload=100, snr=10.0, num="5",
                desc="Bell-202 1200 baud @48 kHz + AWGN 10 dB"),
+    # BASELINE.json configs[3]: per-stream tone pairs (mark_s = 1000 + 10 (s mod 100), space_s = mark_s + 200), 300 baud
+    "c4": dict(cfg=dict(baudRate=300, markFrequency=1000, spaceFrequency=1200), payload=16, snr=None, num="4",
+               desc="300 baud, per-stream mark/space tone pairs @48 kHz", per_stream=True),
     "default": dict(cfg=dict(), payload=100, snr=None, num="-", desc="default 1650/1850 Hz 1200 baud @48 kHz"),
 }
 
@@ -123,7 +126,12 @@ def main():
     spb = sr // int(cfg.get("baudRate", 1200))
     seed = 0xF5C0DE + 0x1000 * rank
 
-    eng = wm.FSKEngine(S, cfg, device=local_rank, precision=prec)
+    if wl.get("per_stream"):   # config #4: every stream its own tone pair (per-stream constants in the kernels)
+        cfgs = [dict(cfg, markFrequency=1000 + 10 * ((first_stream + s) % 100), spaceFrequency=1200 + 10 * ((first_stream + s) % 100))
+                for s in range(S)]
+    else:
+        cfgs = None
+    eng = wm.FSKEngine(S, cfgs if cfgs is not None else cfg, device=local_rank, precision=prec)
     stream = torch.cuda.current_stream().cuda_stream
     x = torch.empty((S, pitch), dtype=torch.float32, device="cuda")
     out_pitch = eng.max_bytes(N)
@@ -158,7 +166,7 @@ def main():
         t0 = time.perf_counter()
         mism = 0
         for j, s in enumerate(rows):
-            o = po.OracleCore(cfg)
+            o = po.OracleCore(cfgs[int(s)] if cfgs is not None else cfg)
             ob, _ = o.demodulate(xs[j])
             gb = gpu_bytes[j, :first_counts[s]].tobytes()
             if ob != gb:
@@ -199,7 +207,7 @@ def main():
 
     # ---- side measurements (rank 0, one GPU): reported in `config`, never as `value` ------------------------------
     side = {}
-    if rank == 0 and world == 1 and not args.no_side and args.precision == "f32":
+    if rank == 0 and world == 1 and not args.no_side and args.precision == "f32" and cfgs is None:
         k_side = max(2, min(args.steps, 4))
         # (1) what exactness costs: the fp64 parity path (op for op with the reference) on the same batch, 1/10 of the length
         try:
