@@ -6,25 +6,43 @@ discriminator -> slicer -> sync -> UART framing) over ONE batch of synthetic 48 
 
 Default workload = BASELINE.json's metric configuration, configs[2] as SURVEY.md section 8 defines it (C3):
 65 536 Bell-202 1200-baud streams x 480 000 samples (10 s) per GPU = 126 GB resident.  Streams shard across GPUs with
-no collective:
-  weak scaling (default)          every rank holds its own --streams streams
-  strong scaling (--total-streams T)  T streams split over the ranks with sharding.stream_shard (C3: 8 192 per GPU at 8)
+no collective.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher (no WORLD_SIZE in the environment): this process starts its own N ranks -- BEFORE anything
+touches the GPU -- as a child `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+bench.py <same arguments>`, relays rank 0's JSON line and exits with the child's code.  Under a launcher (the driver's
+own torch.distributed.run) RANK / LOCAL_RANK / WORLD_SIZE come from the environment as usual.
+
+With N > 1 ONE line carries both shapes:
+  value                    weak scaling: every rank holds its own --streams streams (65 536 per GPU)
+  config.strong_scaling    BASELINE config #3 as written: --streams streams IN TOTAL, a contiguous block per rank
+                           (sharding.stream_shard: 8 192 per GPU at 8), measured right after the weak pass
+(--total-streams T measures only the strong shape of T streams and reports it as `value`, scaling "strong").
 
 Prints ONE JSON line on rank 0 (driver contract) with the extra objects
   roofline      achieved algorithmic HBM GB/s of the demod kernel (4 B per input sample) from HIP events
                 around every launch on the launch stream, against the 8 TB/s peak; `kernel` is what the library says it
-                launched (fskhip_last_kernel), not a literal
+                launched (fskhip_last_kernel).  `binding_bound` names the ceiling that actually binds and
+                `valu_issue` is the same run against it: vector instructions issued per second (committed PMC
+                instruction mix x this run's rate) against 1024 SIMDs x one wave64 instruction per 2 cycles at 2.4 GHz
   cpu_baseline  the CPU oracle (scalar fp64 C port of the reference, oracle/) timed on one host core on a bounded
                 sample of the same buffers; doubles as a parity check of that sample (GPU bytes == oracle bytes): a
-                mismatch sets parity_ok false and the exit code to 3
+                mismatch sets parity_ok false and the exit code of EVERY rank to 3
 and, at N = 1, side measurements in `config` (never the headline): the fp64 parity path on the same shape, a large
 batch (262 144 streams), and the PCIe-inclusive rate through fskhip_demodulate_host.
+
+--workload c5 is BASELINE config #5 as BASELINE.md defines it: every stream's frames come from fskhip_modulate_device
+(FSKCore.modulateData), Gaussian noise at 10 dB with the reference tests' power definition (mean square over the whole
+buffer incl. padding, fsk-demodulation.node.test.ts:1184-1205), and besides the throughput the line carries
+config.c5_quality: frame success rate, BER against the transmitted payloads, and the oracle comparison of a stream sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +51,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+SIMDS = 1024           # 256 CUs x 4 SIMD-32
+CLOCK_GHZ = 2.4        # max clock (MI355X_MICROARCH.md); one wave64 vector instruction per 2 cycles per SIMD
 
 WORKLOADS = {
     # BASELINE.json configs[2] (the one the metric is quoted on): Bell-202, 1200 baud
@@ -41,9 +61,9 @@ WORKLOADS = {
     # BASELINE.json configs[1]: 300 baud V.21 tones in the polarity the reference decodes
     "c2": dict(cfg=dict(baudRate=300, markFrequency=1070, spaceFrequency=1270), payload=32, snr=None, num="2",
                desc="V.21 300 baud (1070/1270 Hz) @48 kHz"),
-    # BASELINE.json configs[4]: Bell-202 through AWGN at 10 dB (the demodulation half of the round trip)
+    # BASELINE.json configs[4]: FSKCore.modulate -> AWGN 10 dB -> demodulate (TX through fskhip_modulate_device)
     "c5": dict(cfg=dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200), payload=100, snr=10.0, num="5",
-               desc="Bell-202 1200 baud @48 kHz + AWGN 10 dB"),
+               desc="Bell-202 1200 baud @48 kHz, modulateData frames + AWGN 10 dB", roundtrip=True),
     # BASELINE.json configs[3]: per-stream tone pairs (mark_s = 1000 + 10 (s mod 100), space_s = mark_s + 200), 300 baud
     "c4": dict(cfg=dict(baudRate=300, markFrequency=1000, spaceFrequency=1200), payload=16, snr=None, num="4",
                desc="300 baud, per-stream mark/space tone pairs @48 kHz", per_stream=True),
@@ -51,25 +71,15 @@ WORKLOADS = {
 }
 
 
-def timed_steps(torch, eng, step, steps):
-    """kernel-only time of `steps` calls: HIP events recorded by the library around every launch"""
-    torch.cuda.synchronize()
-    eng.timing_begin()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    return eng.timing_end()
-
-
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=65536, help="streams per GPU (weak scaling)")
+    ap.add_argument("--streams", type=int, default=65536, help="streams per GPU (weak scaling); with N > 1 also the TOTAL of the strong-scaling pass")
     ap.add_argument("--total-streams", type=int, default=0,
-                    help="strong scaling: this many streams in total, sharded over the ranks (0 = weak scaling)")
+                    help="strong scaling only: this many streams in total, sharded over the ranks (0 = weak + strong in one line)")
     ap.add_argument("--seconds", type=float, default=10.0, help="audio seconds per stream per step")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline leg (0 = skip)")
@@ -78,38 +88,224 @@ def main():
                     help="also launch the read-pattern probe kernel this many times (FETCH_SIZE calibration)")
     ap.add_argument("--pitch-pad", type=int, default=0, help="extra floats of row pitch (experiments)")
     ap.add_argument("--snr-db", type=float, default=None, help="add AWGN at this SNR (overrides the workload's)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-engine", action="store_true",
+                    help="launcher / aggregation test without a GPU: gloo backend and a stand-in engine that only sleeps "
+                         "(tests/test_bench_launcher_cpu.py); the line says so in `data`")
+    return ap
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves (fresh child processes; this process never touches the GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in p.stdout.splitlines():
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    elif p.returncode == 0:
+        print("bench.py: the ranks exited 0 without a JSON line", file=sys.stderr)
+        return 4
+    return p.returncode
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class DryEngine:
+    """--dry-engine: the engine's surface as far as the timed loop uses it; a step sleeps in proportion to its streams."""
+
+    def __init__(self, n_streams):
+        self.n_streams, self._n, self._ms = n_streams, 0, 0.0
+
+    def max_bytes(self, n):
+        return n // 400 + 8
+
+    def last_kernel(self):
+        return "dry_engine"
+
+    def demodulate_device(self, *a, **k):
+        dt = 1e-3 * (1 + self.n_streams / 65536.0)
+        time.sleep(dt)
+        self._n += 1
+        self._ms += dt * 1e3
+
+    def timing_begin(self):
+        self._n, self._ms = 0, 0.0
+
+    def timing_end(self):
+        return self._n, self._ms
+
+    def close(self):
+        pass
+
+
+def timed_steps(sync, eng, step, steps):
+    """kernel-only time of `steps` calls: HIP events recorded by the library around every launch"""
+    sync()
+    eng.timing_begin()
+    for _ in range(steps):
+        step()
+    sync()
+    return eng.timing_end()
+
+
+def measure(sync, dist, eng, step, steps, warmup, dev):
+    """the contract's timed region: W warm-ups, then K steps between barrier + synchronize on both sides, MAX over ranks"""
+    from webaudio_modem_amd.sharding import max_over_ranks
+    for _ in range(warmup):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    eng.timing_begin()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    n_launch, kernel_ms = eng.timing_end()
+    return max_over_ranks(elapsed, dist, dev), n_launch, kernel_ms
+
+
+def c5_build_and_score(torch, np, wm, eng, cfg, x, N, pitch, snr, seed, payload_len, stream, oracle_seconds, first_stream):
+    """BASELINE config #5: fill x with FSKCore.modulateData frames (fskhip_modulate_device), one per time slot, add AWGN
+    with the reference tests' power definition, demodulate slot by slot (the engine is a streaming state machine: any
+    cut of a stream gives the same bytes) so that every frame's bytes are attributed to it, and score them against the
+    transmitted payloads; a strided sample of streams is demodulated by the CPU oracle with the same cuts."""
+    S = x.shape[0]
+    frame_len = eng.modulated_length(payload_len)
+    slot = (frame_len + 1952 + 15) // 16 * 16           # frame + 1 952 samples of silence, whole 16-sample tiles
+    F = max(1, N // slot)
+    rng = np.random.RandomState((seed ^ 0xC5) & 0x7FFFFFFF)
+    payloads = rng.randint(0, 256, size=(F, S, payload_len)).astype(np.uint8)
+    x.zero_()
+    d_lens = torch.full((S,), payload_len, dtype=torch.int32, device="cuda")
+    d_olens = torch.empty(S, dtype=torch.int32, device="cuda")
+    t0 = time.perf_counter()
+    for f in range(F):
+        d_pay = torch.as_tensor(payloads[f], device="cuda")
+        eng.modulate_device(d_pay.data_ptr(), d_lens.data_ptr(), payload_len, x.data_ptr() + 4 * f * slot, pitch,
+                            d_olens.data_ptr(), stream)
+        torch.cuda.synchronize()
+    t_mod = time.perf_counter() - t0
+    eng.add_awgn_device(x.data_ptr(), N, pitch, snr, seed ^ 0xA36, stream)
+    torch.cuda.synchronize()
+    # ---- demodulate slot by slot
+    eng.reset()
+    op = eng.max_bytes(slot + N - F * slot)
+    out = torch.zeros((S, op), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(S, dtype=torch.int32, device="cuda")
+    got, got_n = [], []
+    for f in range(F):
+        n_f = slot if f + 1 < F else N - f * slot
+        eng.demodulate_device(x.data_ptr() + 4 * f * slot, n_f, pitch, out.data_ptr(), op, cnt.data_ptr(), 0, 0, stream)
+        torch.cuda.synchronize()
+        got.append(out.cpu().numpy().copy())
+        got_n.append(cnt.cpu().numpy().astype(np.int64))
+    eng.reset()
+    frames = F * S
+    ok = 0
+    len_match = 0
+    bit_err = 0
+    for f in range(F):
+        n_ok_len = got_n[f] == payload_len
+        len_match += int(n_ok_len.sum())
+        rx = got[f][:, :payload_len]
+        diff = np.bitwise_xor(rx[n_ok_len], payloads[f][n_ok_len])
+        errs = np.unpackbits(diff, axis=1).sum(axis=1)
+        bit_err += int(errs.sum())
+        ok += int((errs == 0).sum())
+    q = {
+        "tx": "fskhip_modulate_device (FSKCore.modulateData), %d frames of %d payload bytes per stream, one per %d-sample slot" % (F, payload_len, slot),
+        "noise": "Gaussian, sigma^2 = mean square of the stream's whole buffer (padding included) / 10^(SNR/10), SNR %.1f dB "
+                 "(power definition of fsk-demodulation.node.test.ts:1184-1205)" % snr,
+        "frames": frames, "frame_success_rate": round(ok / frames, 6), "frames_with_payload_length": len_match,
+        "ber_on_length_matched_frames": (bit_err / (8.0 * payload_len * len_match)) if len_match else None,
+        "bit_errors": bit_err,
+        "modulate_Msamples_per_s": round(F * S * frame_len / t_mod / 1e6, 1),
+    }
+    # ---- oracle on a strided sample, same cuts
+    if oracle_seconds > 0:
+        from oracle import pyoracle as po
+        n_cpu = int(max(1, min(S, oracle_seconds * 7.0e6 // N)))
+        rows = np.unique(np.linspace(0, S - 1, n_cpu).astype(np.int64))
+        xs = x.index_select(0, torch.as_tensor(rows, device="cuda"))[:, :N].cpu().numpy()
+        t0 = time.perf_counter()
+        same = 0
+        for j, s in enumerate(rows):
+            o = po.OracleCore(cfg)
+            good = True
+            for f in range(F):
+                n_f = slot if f + 1 < F else N - f * slot
+                ob, _ = o.demodulate(xs[j, f * slot:f * slot + n_f])
+                if ob != got[f][s, :got_n[f][s]].tobytes():
+                    good = False
+            same += good
+        dt = time.perf_counter() - t0
+        q.update({"oracle_streams_checked": int(len(rows)), "oracle_streams_byte_identical": int(same),
+                  "oracle_Msamples_per_s": round(len(rows) * N / dt / 1e6, 3)})
+    return q
+
+
+def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    dry = args.dry_engine
 
     import numpy as np
     import torch
     import __graft_entry__ as ge
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    if not dry:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+    dev = "cpu" if dry else "cuda"
+    sync = (lambda: None) if dry else torch.cuda.synchronize
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if dry and os.environ.get("BENCH_DRY_FAIL_RANK") == str(rank):   # launcher test: a rank that dies must fail the whole run
+        sys.exit(7)
     # one rank runs make (a no-op when the shipped libraries are current); the others must not race it in the same tree
-    if rank == 0:
+    if rank == 0 and not dry:
         ge.build()
     if dist is not None:
         dist.barrier()
-    import webaudio_modem_amd as wm
     from webaudio_modem_amd.sharding import max_over_ranks, stream_shard
+    wm = None
+    if not dry:
+        import webaudio_modem_amd as wm
 
     wl = WORKLOADS[args.workload]
     cfg = wl["cfg"]
     snr = args.snr_db if args.snr_db is not None else wl["snr"]
-    if args.total_streams:
+    strong_only = args.total_streams > 0
+    if strong_only:
         first_stream, S = stream_shard(args.total_streams, rank, world)
         total_streams = args.total_streams
         scaling = "strong"
@@ -122,39 +318,55 @@ def main():
     N = int(round(args.seconds * sr))
     N = (N + 31) // 32 * 32
     pitch = (N + 63) // 64 * 64 + args.pitch_pad  # 256-B row pitch
-    prec = wm.PRECISION_F32 if args.precision == "f32" else wm.PRECISION_F64
     spb = sr // int(cfg.get("baudRate", 1200))
     seed = 0xF5C0DE + 0x1000 * rank
 
-    if wl.get("per_stream"):   # config #4: every stream its own tone pair (per-stream constants in the kernels)
-        cfgs = [dict(cfg, markFrequency=1000 + 10 * ((first_stream + s) % 100), spaceFrequency=1200 + 10 * ((first_stream + s) % 100))
-                for s in range(S)]
-    else:
-        cfgs = None
-    eng = wm.FSKEngine(S, cfgs if cfgs is not None else cfg, device=local_rank, precision=prec)
-    stream = torch.cuda.current_stream().cuda_stream
-    x = torch.empty((S, pitch), dtype=torch.float32, device="cuda")
-    out_pitch = eng.max_bytes(N)
-    out = torch.empty((S, out_pitch), dtype=torch.uint8, device="cuda")
-    counts = torch.empty(S, dtype=torch.int32, device="cuda")
-    eod = torch.empty(S, dtype=torch.int32, device="cuda")
-    eng.synth_device(x.data_ptr(), N, pitch, wl["payload"], seed, 10 * spb, 0.1, 1.0, stream)
-    if snr is not None:
-        eng.add_awgn_device(x.data_ptr(), N, pitch, snr, seed ^ 0xA36, stream)
-    torch.cuda.synchronize()
+    def per_stream_cfgs(first, count):
+        if not wl.get("per_stream"):   # config #4: every stream its own tone pair (per-stream constants in the kernels)
+            return None
+        return [dict(cfg, markFrequency=1000 + 10 * ((first + s) % 100), spaceFrequency=1200 + 10 * ((first + s) % 100))
+                for s in range(count)]
 
-    def step():
-        eng.demodulate_device(x.data_ptr(), N, pitch, out.data_ptr(), out_pitch, counts.data_ptr(), eod.data_ptr(),
-                              0, stream)
+    cfgs = per_stream_cfgs(first_stream, S)
+    c5q = None
+    if dry:
+        eng = DryEngine(S)
+        x = out = counts = eod = None
+        out_pitch = eng.max_bytes(N)
+        stream = None
+
+        def step():
+            eng.demodulate_device()
+    else:
+        prec = wm.PRECISION_F32 if args.precision == "f32" else wm.PRECISION_F64
+        eng = wm.FSKEngine(S, cfgs if cfgs is not None else cfg, device=local_rank, precision=prec)
+        stream = torch.cuda.current_stream().cuda_stream
+        x = torch.empty((S, pitch), dtype=torch.float32, device="cuda")
+        out_pitch = eng.max_bytes(N)
+        out = torch.empty((S, out_pitch), dtype=torch.uint8, device="cuda")
+        counts = torch.empty(S, dtype=torch.int32, device="cuda")
+        eod = torch.empty(S, dtype=torch.int32, device="cuda")
+        if wl.get("roundtrip"):
+            c5q = c5_build_and_score(torch, np, wm, eng, cfg, x, N, pitch, snr, seed, wl["payload"], stream,
+                                     args.cpu_seconds if rank == 0 else 0, first_stream)
+        else:
+            eng.synth_device(x.data_ptr(), N, pitch, wl["payload"], seed, 10 * spb, 0.1, 1.0, stream)
+            if snr is not None:
+                eng.add_awgn_device(x.data_ptr(), N, pitch, snr, seed ^ 0xA36, stream)
+        torch.cuda.synchronize()
+
+        def step():
+            eng.demodulate_device(x.data_ptr(), N, pitch, out.data_ptr(), out_pitch, counts.data_ptr(), eod.data_ptr(),
+                                  0, stream)
 
     # ---- first pass doubles as the parity sample: copy its outputs before state moves on -------
     step()
-    torch.cuda.synchronize()
+    sync()
     kernel_name = eng.last_kernel()
-    first_counts = counts.cpu().numpy().astype(np.int64)
+    first_counts = np.zeros(S, np.int64) if dry else counts.cpu().numpy().astype(np.int64)
     cpu_obj = None
     parity_ok = True
-    if rank == 0 and args.cpu_seconds > 0:
+    if rank == 0 and args.cpu_seconds > 0 and not dry:
         est_rate = 7.0e6  # oracle samples/s/core
         n_cpu_streams = int(max(1, min(S, args.cpu_seconds * est_rate // N)))
         # a strided sample over the whole batch (first and last groups included)
@@ -180,34 +392,55 @@ def main():
             "parity_ok": parity_ok, "streams_byte_identical": int(len(rows) - mism), "streams_checked": int(len(rows)),
             "host_cpus": os.cpu_count(),
         }
+        if c5q is not None and c5q.get("oracle_streams_checked") is not None:
+            parity_ok = parity_ok and c5q["oracle_streams_checked"] == c5q["oracle_streams_byte_identical"]
 
-    if args.probe_reads:
+    if args.probe_reads and not dry:
         # counter calibration aid: the same buffer streamed with the kernel's read pattern and nothing else
         for _ in range(args.probe_reads):
             eng.probe_read_device(x.data_ptr(), N, pitch, stream)
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    elapsed, n_launch, kernel_ms = measure(sync, dist, eng, step, args.steps, args.warmup, dev)
+
+    # ---- N > 1: the strong-scaling shape of the same job (BASELINE config #3 as written), same line -------------------
+    strong = None
+    if world > 1 and not strong_only:
+        first2, S2 = stream_shard(args.streams, rank, world)
+        if dry:
+            e2 = DryEngine(S2)
+
+            def step2():
+                e2.demodulate_device()
+        else:
+            cfgs2 = per_stream_cfgs(first2, S2)
+            e2 = wm.FSKEngine(S2, cfgs2 if cfgs2 is not None else cfg, device=local_rank, precision=prec)
+
+            def step2():   # the first S2 rows of this rank's resident batch
+                e2.demodulate_device(x.data_ptr(), N, pitch, out.data_ptr(), out_pitch, counts.data_ptr(), eod.data_ptr(), 0, stream)
+        step2()
+        sync()
+        el2, nl2, kms2 = measure(sync, dist, e2, step2, args.steps, args.warmup, dev)
+        k2 = e2.last_kernel()
+        e2.close()
+        v2 = float(args.streams) * N * args.steps / el2 / 1e6
+        strong = {"total_streams": args.streams, "streams_per_gpu": S2, "Msamples_per_s": round(v2, 1),
+                  "ms_per_step": round(el2 / args.steps * 1e3, 3), "kernel": k2,
+                  "avg_kernel_ms_rank0": round(kms2 / max(1, nl2), 4),
+                  "frac_of_hbm_peak_per_gpu": round(v2 / world * 4 / 1e3 / HBM_PEAK_GBS, 4),
+                  "note": "BASELINE config #3 as written: %d streams in total, contiguous blocks of %d per GPU, no collective" % (args.streams, S2)}
+
+    # every rank reports what it processed: the aggregate is checked, not assumed
+    ranks_reported, streams_all = 1, S
     if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    eng.timing_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    n_launch, kernel_ms = eng.timing_end()
-    elapsed = max_over_ranks(elapsed, dist, "cuda")
+        t = torch.tensor([1.0, float(S), 0.0 if parity_ok else 1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ranks_reported, streams_all = int(t[0].item()), int(t[1].item())
+        parity_ok = parity_ok and t[2].item() == 0.0
 
     # ---- side measurements (rank 0, one GPU): reported in `config`, never as `value` ------------------------------
     side = {}
-    if rank == 0 and world == 1 and not args.no_side and args.precision == "f32" and cfgs is None:
+    if rank == 0 and world == 1 and not args.no_side and args.precision == "f32" and cfgs is None and not dry and c5q is None:
         k_side = max(2, min(args.steps, 4))
         # (1) what exactness costs: the fp64 parity path (op for op with the reference) on the same batch, 1/10 of the length
         try:
@@ -217,7 +450,7 @@ def main():
             def step64():
                 e64.demodulate_device(x.data_ptr(), n64, pitch, out.data_ptr(), out_pitch, counts.data_ptr(), eod.data_ptr(), 0, stream)
             step64()
-            nl, ms = timed_steps(torch, e64, step64, k_side)
+            nl, ms = timed_steps(sync, e64, step64, k_side)
             r = S * n64 * nl / (ms / 1e3) / 1e6
             side["f64_parity_path"] = {"streams": S, "samples_per_stream": n64, "kernel": e64.last_kernel(),
                                        "Msamples_per_s": round(r, 1), "frac_of_hbm_peak": round(r * 4 / 1e3 / HBM_PEAK_GBS, 4)}
@@ -239,7 +472,7 @@ def main():
             def step2():
                 e2.demodulate_device(x2.data_ptr(), n2, p2, o2.data_ptr(), o2.shape[1], c2.data_ptr(), 0, 0, stream)
             step2()
-            nl, ms = timed_steps(torch, e2, step2, k_side)
+            nl, ms = timed_steps(sync, e2, step2, k_side)
             r = S2 * n2 * nl / (ms / 1e3) / 1e6
             side["large_batch"] = {"streams": S2, "samples_per_stream": n2, "kernel": e2.last_kernel(),
                                    "Msamples_per_s": round(r, 1), "frac_of_hbm_peak": round(r * 4 / 1e3 / HBM_PEAK_GBS, 4)}
@@ -276,36 +509,47 @@ def main():
         except Exception as ex:
             side["pcie_inclusive"] = {"error": str(ex)}
 
-    total_samples = float(total_streams) * N * args.steps if args.total_streams else float(S) * N * args.steps * world
+    total_samples = float(total_streams) * N * args.steps if strong_only else float(streams_all) * N * args.steps
     value = total_samples / elapsed / 1e6
     alg_bytes_per_launch = 4.0 * S * N  # 4 B read per input sample
-    avg_kernel_s = kernel_ms / 1e3 / max(1, n_launch)
+    avg_kernel_s = max(1e-12, kernel_ms / 1e3 / max(1, n_launch))
     achieved = alg_bytes_per_launch / avg_kernel_s / 1e9
     decoded = int(first_counts.sum())
-    # HBM traffic per launch: only from a committed PMC pass of THIS round's kernel on this workload (tools/pmc.sh)
-    traffic, traffic_src = None, None
-    tr_path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if args.workload == "c3" and args.precision == "f32" and snr is None and os.path.exists(tr_path):
-        with open(tr_path) as fh:
-            tj = json.load(fh)
-        if tj.get("kernel", "") and tj["kernel"].split("<")[0] == kernel_name.split("<")[0]:
-            traffic = round(tj["hbm_bytes_per_input_sample"] * S * N / avg_kernel_s / 1e9, 1)
-            traffic_src = "profiles/r02_traffic.json (separate rocprofv3 --pmc passes of this kernel; bytes per input sample x this run's rate, not counters of this run)"
 
-    # the ceiling that actually binds (VERDICT r01 #2b): instruction issue.  The instruction mix and its pricing are a
-    # committed profile of this kernel (like the traffic figure); the nanoseconds per sample are this run's.
+    def committed(name):
+        """a committed profile of THIS kernel (profiles/<round>_<name>.json): the newest round that has one"""
+        for rnd in ("r03", "r02"):
+            pth = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
+            if os.path.exists(pth):
+                with open(pth) as fh:
+                    j = json.load(fh)
+                if j.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
+                    return j, "profiles/%s_%s.json" % (rnd, name)
+        return None, None
+
+    # HBM traffic per launch: only from a committed PMC pass of this kernel on this workload (tools/pmc.sh)
+    traffic, traffic_src = None, None
+    tj, tsrc = committed("traffic")
+    if tj is not None and args.workload == "c3" and args.precision == "f32" and snr is None:
+        traffic = round(tj["hbm_bytes_per_input_sample"] * S * N / avg_kernel_s / 1e9, 1)
+        traffic_src = tsrc + " (separate rocprofv3 --pmc passes of this kernel; bytes per input sample x this run's rate, not counters of this run)"
+
+    # the ceiling that actually binds: vector instruction issue.  The instruction mix is a committed PMC profile of this
+    # kernel (like the traffic figure); the rate is this run's.
     issue = None
-    is_path = os.path.join(ROOT, "profiles", "r02_issue.json")
-    if os.path.exists(is_path):
-        with open(is_path) as fh:
-            ij = json.load(fh)
-        if ij.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
-            ns = avg_kernel_s / N * 1e9
-            issue = {"insts_per_group_sample": ij["insts_per_group_sample"],
-                     "modelled_cycles_per_group_sample": ij["modelled_cycles_per_group_sample"],
-                     "measured_ns_per_sample": round(ns, 1),
-                     "measured_cycles_per_sample_at_2.1_to_2.4_GHz": [round(ns * 2.1), round(ns * 2.4)],
-                     "source": ij["source"] + "; nanoseconds per sample from this run"}
+    ij, isrc = committed("issue")
+    if ij is not None:
+        ns = avg_kernel_s / N * 1e9
+        groups = (S + 63) // 64
+        valu_per_s = ij["insts_per_group_sample"]["valu"] * groups * N / avg_kernel_s
+        peak = SIMDS * CLOCK_GHZ * 1e9 / 2.0
+        issue = {"bound": "valu_issue", "achieved": round(valu_per_s / 1e9, 1), "peak": round(peak / 1e9, 1), "unit": "Ginst/s",
+                 "frac": round(valu_per_s / peak, 4),
+                 "insts_per_group_sample": ij["insts_per_group_sample"],
+                 "measured_ns_per_sample": round(ns, 1),
+                 "peak_definition": "%d SIMD-32 x one wave64 vector instruction per 2 cycles at %.1f GHz" % (SIMDS, CLOCK_GHZ),
+                 "source": isrc + " (rocprofv3 --pmc SQ_INSTS_* pass of this kernel; instructions per 64-stream group and input "
+                                  "sample x this run's rate)"}
 
     if rank == 0:
         line = {
@@ -313,16 +557,20 @@ def main():
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
+            "dtype": args.precision, "data": "dry-run: no GPU, stand-in engine (launcher test)" if dry else "synthetic",
             "config": {
                 "workload": "BASELINE config #%s: %d streams%s x %d samples (%.2f s) %s, back-to-back %d-byte "
-                            "frames, random lead-in and amplitude" % (
-                                wl["num"], total_streams if args.total_streams else S,
-                                " in total" if args.total_streams else "/GPU", N, N / sr, wl["desc"], wl["payload"]),
-                "streams_per_gpu": S, "total_streams": total_streams, "samples_per_stream": N, "row_pitch_floats": pitch,
+                            "frames%s" % (
+                                wl["num"], total_streams if strong_only else S,
+                                " in total" if strong_only else "/GPU", N, N / sr, wl["desc"], wl["payload"],
+                                "" if wl.get("roundtrip") else ", random lead-in and amplitude"),
+                "streams_per_gpu": S, "total_streams": total_streams if strong_only else streams_all,
+                "ranks_reported": ranks_reported, "samples_per_stream": N, "row_pitch_floats": pitch,
                 "resident_input_GB_per_gpu": round(S * pitch * 4 / 1e9, 2),
                 "parallelism": "streams sharded across %d GPU(s) (%s scaling), no collective" % (world, scaling),
                 "decoded_bytes_first_pass_rank0": decoded,
+                **({"strong_scaling": strong} if strong is not None else {}),
+                **({"c5_quality": c5q} if c5q is not None else {}),
                 **side,
             },
             "roofline": {
@@ -330,19 +578,32 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kernel_name, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                "issue_ceiling": issue,
-                "issue_ceiling_note": "the kernel is instruction-issue bound, not HBM bound: see DESIGN.md section 5 "
-                                      "(profiles/r02_valu_probe_summary.md for the per-instruction costs it is priced with)",
+                "binding_bound": "valu_issue",
+                "valu_issue": issue,
+                "binding_note": "the kernel is bound by vector instruction issue, not by HBM (DESIGN.md section 5): `frac` is "
+                                "the HBM fraction BASELINE.json's metric asks for, `valu_issue.frac` is the same run against the "
+                                "ceiling that binds",
             },
             "cpu_baseline": cpu_obj,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if not parity_ok:
         sys.exit(3)
+
+
+def main():
+    argv = sys.argv[1:]
+    args = build_parser().parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        args.gpus = world
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -247,6 +247,56 @@ KERNEL_BEGIN(k_dsread_b32)
     asm volatile(REP8("ds_read_b32 %0, %1\n\t") "s_waitcnt lgkmcnt(0)\n\t" : "=&v"(v) : "v"(addr) : "memory"); a0 += v; }
 KERNEL_END
 
+
+// ---- third batch (round 3): what the back wave's per-sample control flow and memory operations cost a wave ----------
+// 8 independent v_fma as the background, plus ONE instance of the shape under test per 8: the difference to 9 plain fma
+// is the shape's price.
+#define FMA8 "v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\t" \
+             "v_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9\n\t"
+#define FMA8X "v_fma_f32 %0, %0, %9, %10\n\tv_fma_f32 %1, %1, %9, %10\n\tv_fma_f32 %2, %2, %9, %10\n\tv_fma_f32 %3, %3, %9, %10\n\t" \
+              "v_fma_f32 %4, %4, %9, %10\n\tv_fma_f32 %5, %5, %9, %10\n\tv_fma_f32 %6, %6, %9, %10\n\tv_fma_f32 %7, %7, %9, %10\n\t"
+#define RD_REGS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(v) : "v"(b), "v"(c), "v"(addr) : "memory"
+KERNEL_BEGIN(k_bg_fma8) asm volatile(REP4(FMA8) S_REGS); KERNEL_END
+// v_cmp -> vcc -> s_cbranch_vccnz, never taken (the rare-event test of the frame logic)
+KERNEL_BEGIN(k_br_vcc) asm volatile(REP4(FMA8 "v_cmp_gt_f32 vcc, 0, %8\n\ts_cbranch_vccnz 1f\n\t") "1:\n\t" S_REGS : "vcc"); KERNEL_END
+// v_cmp -> SGPR pair -> s_and_b64 vcc -> s_cbranch_vccz, always taken to the next line (the start/stop-bit test)
+KERNEL_BEGIN(k_br_sand) asm volatile(REP4(FMA8 "v_cmp_gt_f32 s[20:21], 0, %8\n\tv_cmp_gt_f32 vcc, 0, %9\n\ts_and_b64 vcc, s[20:21], vcc\n\ts_cbranch_vccnz 1f\n\t") "1:\n\t" S_REGS : "vcc", "s20", "s21", "scc"); KERNEL_END
+// a taken branch (jump over one instruction)
+KERNEL_BEGIN(k_br_taken) asm volatile(REP4(FMA8 "s_cbranch_vccz 2f\n\ts_nop 0\n\t2:\n\t") S_REGS : "vcc"); KERNEL_END
+// scalar compare + branch, never taken
+KERNEL_BEGIN(k_br_scc) asm volatile(REP4(FMA8 "s_cmp_eq_u32 s20, 12345\n\ts_cbranch_scc1 1f\n\t") "1:\n\t" S_REGS : "scc", "s20"); KERNEL_END
+// v_readfirstlane -> s_cmp -> branch (a wave-uniform decision taken from a VGPR)
+KERNEL_BEGIN(k_br_rfl) asm volatile(REP4(FMA8 "v_readfirstlane_b32 s20, %0\n\ts_cmp_eq_u32 s20, 12345\n\ts_cbranch_scc1 1f\n\t") "1:\n\t" S_REGS : "scc", "s20"); KERNEL_END
+// one global store of a dword per lane (the amplitude ring), never waited for
+KERNEL_BEGIN(k_gstore)
+  { const uint64_t addr = reinterpret_cast<uint64_t>(out) + (1u << 20) + ((uint64_t)(blockIdx.x * blockDim.x + threadIdx.x) * 4u);
+    asm volatile(REP4(FMA8 "global_store_dword %10, %0, off\n\t") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "v"(addr) : "memory"); }
+KERNEL_END
+// LDS: write a dword / read a dword and wait for it at once (exposed latency) / read and wait 8 instructions later
+KERNEL_BEGIN(k_ldsw32)
+  { const uint32_t addr = threadIdx.x * 4u;
+    asm volatile(REP4(FMA8 "ds_write_b32 %10, %0\n\t") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "v"(addr) : "memory"); }
+KERNEL_END
+KERNEL_BEGIN(k_ldsr32_wait)
+  { const uint32_t addr = threadIdx.x * 4u; float v;
+    asm volatile(REP4(FMA8X "ds_read_b32 %8, %11\n\ts_waitcnt lgkmcnt(0)\n\t") RD_REGS); a0 += v; }
+KERNEL_END
+KERNEL_BEGIN(k_ldsr128_wait)
+  { typedef float v4 __attribute__((ext_vector_type(4))); const uint32_t addr = threadIdx.x * 16u; v4 v;
+    asm volatile(REP4(FMA8X "ds_read_b128 %8, %11\n\ts_waitcnt lgkmcnt(0)\n\t") RD_REGS); a0 += v.x; }
+KERNEL_END
+KERNEL_BEGIN(k_ldsr128_late)
+  { typedef float v4 __attribute__((ext_vector_type(4))); const uint32_t addr = threadIdx.x * 16u; v4 v;
+    asm volatile(REP4("ds_read_b128 %8, %11\n\t" FMA8X "s_waitcnt lgkmcnt(0)\n\t") RD_REGS); a0 += v.x; }
+KERNEL_END
+// the hand-off poll as the kernels do it: ds_read_b32 -> wait -> v_readfirstlane
+KERNEL_BEGIN(k_lds_peek)
+  { const uint32_t addr = 0; float v;
+    asm volatile(REP4(FMA8X "ds_read_b32 %8, %11\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 s20, %8\n\t") RD_REGS, "s20"); a0 += v; }
+KERNEL_END
+// s_sleep 1
+KERNEL_BEGIN(k_sleep1) asm volatile(REP4(FMA8 "s_sleep 1\n\t") S_REGS); KERNEL_END
+
 typedef void (*kern_t)(Stamp *, int, float);
 struct Row { const char *name; kern_t k; int per_iter; const char *note; };
 
@@ -340,10 +390,23 @@ int main(int argc, char **argv) {
       {"v_fma + s_add alternating", k_fma_salu, 32, "per instruction (16 VALU + 16 SALU)"},
       {"ds_read_b128 x8 + wait", k_dsread_b128, 8, "per ds_read (conflict-free, 1 KiB/wave)"},
       {"ds_read_b32 x8 + wait", k_dsread_b32, 8, "per ds_read"},
+      {"r3 background: 8 v_fma", k_bg_fma8, 32, "per instruction"},
+      {"r3 8 fma + v_cmp>vcc + s_cbranch_vccnz (not taken)", k_br_vcc, 4, "per GROUP of 8 fma + shape"},
+      {"r3 8 fma + 2 v_cmp + s_and_b64 + s_cbranch (not taken)", k_br_sand, 4, "per group"},
+      {"r3 8 fma + taken branch over one s_nop", k_br_taken, 4, "per group"},
+      {"r3 8 fma + s_cmp + s_cbranch_scc1 (not taken)", k_br_scc, 4, "per group"},
+      {"r3 8 fma + v_readfirstlane + s_cmp + s_cbranch", k_br_rfl, 4, "per group"},
+      {"r3 8 fma + global_store_dword", k_gstore, 4, "per group"},
+      {"r3 8 fma + ds_write_b32", k_ldsw32, 4, "per group"},
+      {"r3 8 fma + ds_read_b32 + wait", k_ldsr32_wait, 4, "per group"},
+      {"r3 8 fma + ds_read_b128 + wait", k_ldsr128_wait, 4, "per group"},
+      {"r3 ds_read_b128, 8 fma, then wait", k_ldsr128_late, 4, "per group"},
+      {"r3 8 fma + lds peek (read, wait, readfirstlane)", k_lds_peek, 4, "per group"},
+      {"r3 8 fma + s_sleep 1", k_sleep1, 4, "per group"},
   };
   const int iters = 4096;
   Stamp *d_out;
-  CHECK(hipMalloc(&d_out, sizeof(Stamp) * cus * 32));
+  CHECK(hipMalloc(&d_out, (2u << 20) + (size_t)cus * 1024 * 4));   // stamps + the store target of k_gstore
   std::vector<Stamp> h(cus * 32);
   printf("%-44s %5s %10s %10s %8s  %s\n", "instruction pattern", "W", "per_wave", "per_simd", "GHz", "note");
   for (const Row &r : rows) {

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""variants.py (GPU box): kernel time of one batch shape with alternative builds of libfskhip.so and/or environment
+switches, one child process each, plus a checksum of the decoded bytes so that a variant that changes the result shows.
+
+  tools/variants.py S N spec [spec ...]      spec = label[@libtag][:ENV=VAL[,ENV=VAL...]]
+     libtag -> tools/build/libfskhip_<libtag>.so (tools/build_variant.sh); no tag = the shipped library
+Diagnostic aid, not part of the suite."""
+import os, sys, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import os, sys, zlib
+sys.path.insert(0, %r)
+import webaudio_modem_amd._lib as L
+if sys.argv[3] != "-": L.LIB_PATH = sys.argv[3]
+import torch
+import webaudio_modem_amd as wm
+S, N = int(sys.argv[1]), int(sys.argv[2])
+wl = os.environ.get("VAR_WORKLOAD", "c3")
+cfg = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200) if wl == "c3" else dict(baudRate=300, markFrequency=1070, spaceFrequency=1270)
+eng = wm.FSKEngine(S, cfg, precision=wm.PRECISION_F32)
+st = torch.cuda.current_stream().cuda_stream
+x = torch.empty((S, N), dtype=torch.float32, device="cuda")
+op = eng.max_bytes(N)
+out = torch.zeros((S, op), dtype=torch.uint8, device="cuda"); cnt = torch.empty(S, dtype=torch.int32, device="cuda")
+eng.synth_device(x.data_ptr(), N, N, 100 if wl == "c3" else 32, 0xF5C0DE, 400, 0.1, 1.0, st)
+torch.cuda.synchronize()
+def step():
+    eng.demodulate_device(x.data_ptr(), N, N, out.data_ptr(), op, cnt.data_ptr(), 0, 0, st)
+step(); torch.cuda.synchronize()     # first pass from the reset state: its bytes are the checksum
+crc = zlib.crc32(out.cpu().numpy().tobytes()) ^ zlib.crc32(cnt.cpu().numpy().tobytes())
+nb = int(cnt.sum().item())
+step(); torch.cuda.synchronize()
+eng.timing_begin()
+for _ in range(int(os.environ.get("VAR_STEPS", "4"))): step()   # back to back, state carried on (as bench.py does)
+torch.cuda.synchronize()
+n, ms = eng.timing_end()
+print("RESULT", ms / n, eng.last_kernel().replace(" ", ""), nb, "%%08x" %% crc)
+if os.environ.get("VAR_STAMPS"):
+    import ctypes, numpy as np
+    f = L.lib().fskdbg_read_stamps_blk if "blk" in eng.last_kernel() else L.lib().fskdbg_read_stamps
+    f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    a = np.zeros((3, 2048, 2), np.uint64)
+    assert f(a.ctypes.data, a.size) == 0
+    g = min(2048, (S + 63) // 64)
+    for w in range(3):
+        tot = a[w, :g, 1].astype(np.float64)
+        if tot.max() == 0: continue
+        wait = a[w, :g, 0].astype(np.float64)
+        print("STAMP wave %%d: loop %%.0f cycles/sample (min %%.0f max %%.0f over groups), waiting %%.1f %%%% of it (min %%.1f max %%.1f), busy %%.0f cycles/sample"
+              %% (w, tot.mean() / N, tot.min() / N, tot.max() / N, 100 * (wait / tot).mean(), 100 * (wait / tot).min(), 100 * (wait / tot).max(),
+                 (tot - wait).mean() / N))
+''' % ROOT
+S, N = int(sys.argv[1]), int(sys.argv[2])
+for spec in sys.argv[3:]:
+    head, _, envs = spec.partition(":")
+    label, _, tag = head.partition("@")
+    env = dict(os.environ)
+    for kv in filter(None, envs.split(",")):
+        k, _, v = kv.partition("=")
+        env[k] = v
+    lib = os.path.join(ROOT, "tools", "build", "libfskhip_%s.so" % tag) if tag else "-"
+    try:
+        r = subprocess.run([sys.executable, "-c", CHILD, str(S), str(N), lib], env=env, capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        print("%-28s TIMEOUT" % label, flush=True); continue
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    if not line:
+        print("%-28s FAILED %s" % (label, r.stderr[-400:].replace("\n", " | ")), flush=True); continue
+    f = line[0].split()
+    ms = float(f[1])
+    print("%-28s %9.3f ms %8.1f Gsamples/s  %s bytes=%s crc=%s" % (label, ms, S * N / ms / 1e6, f[2], f[3], f[4]), flush=True)
+    for l in r.stdout.splitlines():
+        if l.startswith("STAMP"):
+            print("    " + l, flush=True)

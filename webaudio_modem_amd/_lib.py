@@ -7,10 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfskhip.so")
-# measurement builds only (tools/stage_times.py loads the FSK_ABLATE build of the same sources)
-if os.environ.get("FSKHIP_LIB_OVERRIDE"):
-    LIB_PATH = os.environ["FSKHIP_LIB_OVERRIDE"]
+LIB_PATH = os.path.join(_HERE, "libfskhip.so")   # (measurement tools load other builds by setting this before lib() runs)
 
 MAX_PATTERN_BYTES = 16
 OK = 0

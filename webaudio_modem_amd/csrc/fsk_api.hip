@@ -37,6 +37,13 @@ hipError_t launch_demod_pipe3(bool writeback, bool append, const DemodParams &P,
                               size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts, uint32_t *eod_counts,
                               hipStream_t stream);
 size_t demod_fused_lds_bytes(const DemodParams &P);
+// fsk_blk.hip: three waves per group, block-batched back wave
+size_t demod_blk3_lds_bytes(const DemodParams &P);
+bool demod_blk3_applicable(const DemodParams &P);
+hipError_t set_blk3_lds_limit(const DemodParams &P);
+hipError_t launch_demod_blk3(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+                             size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
+                             uint32_t *eod_counts, hipStream_t stream);
 hipError_t set_pipe_lds_limit(size_t pipe_bytes);
 hipError_t set_demod_lds_limit(size_t lds_bytes);
 size_t demod_lds_bytes(const DemodParams &P);
@@ -163,6 +170,7 @@ struct fskhip_engine {
   uint32_t split_cus = 256;
   bool split_forced = false;     // FSKHIP_SPLIT was set: skip the residency check too
   bool use_split3 = false;       // three waves per group (demod_pipe3_kernel): at most two groups per CU
+  bool use_blk3 = false;         // three waves per group with the block-batched back wave (demod_blk3_kernel, fsk_blk.hip)
   bool gen_odd = false;          // fp32: the last generic-kernel launch left a decimator pair open (its partial sums are in
                                  // the reference's frame, the whole-tile kernels' in the free-running one)
   const char *last_kernel = "";  // what the last fskhip_demodulate_device call launched for its whole tiles
@@ -345,8 +353,9 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     // third instruction stream per group gives half the SIMDs a second wave (measured: 32 768 streams 245 -> 275
     // Gsamples/s; at one group per CU or fewer every wave is alone either way and the extra hand-off buys nothing)
     e->use_split3 = e->use_split && n_blocks > (uint32_t)cus && n_blocks <= (uint32_t)cus * 2u;
-    if (const char *sp = getenv("FSKHIP_SPLIT")) {    // tests / measurements: 0 = one wave, 1 = two, 3 = three per group
-      e->use_split = sp[0] == '1' || sp[0] == '3'; e->use_split3 = sp[0] == '3'; e->split_forced = true;
+    if (const char *sp = getenv("FSKHIP_SPLIT")) {    // tests / measurements: 0 = one wave, 1 = two, 3 = three per group, 4 = three with the block back
+      e->use_split = sp[0] == '1' || sp[0] == '3' || sp[0] == '4'; e->use_split3 = sp[0] == '3'; e->use_blk3 = sp[0] == '4';
+      e->split_forced = true;
     }
   }
 
@@ -579,6 +588,7 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   if (e->demod_ok && e->lds_bytes > 48 * 1024) CREATE_TRY(set_demod_lds_limit(e->lds_bytes));
   if (e->demod_ok && !P.wide && !P.frac && precision == FSKHIP_PRECISION_F32 && demod_pipe_lds_bytes(P) <= 160 * 1024)
     CREATE_TRY(set_pipe_lds_limit(demod_pipe_lds_bytes(P)));
+  if (e->demod_ok && precision == FSKHIP_PRECISION_F32 && demod_blk3_applicable(P)) CREATE_TRY(set_blk3_lds_limit(P));
   e->S.trace_stream = 0xFFFFFFFFu;
 #undef CREATE_TRY
   e->base_calls.assign(n_streams, 0);
@@ -667,7 +677,12 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
       }
       if (n_fast) {
         const size_t pipe3_lds = demod_pipe3_lds_bytes(e->P);
-        if (two_wave && e->use_split3 && pipe3_lds <= 160 * 1024 && (wgs_per_cu * pipe3_lds <= 160 * 1024 || e->split_forced)) {
+        const size_t blk3_lds = demod_blk3_lds_bytes(e->P);
+        if (e->use_blk3 && demod_blk3_applicable(e->P) && blk3_lds <= 160 * 1024 && (wgs_per_cu * blk3_lds <= 160 * 1024 || e->split_forced)) {
+          HIP_TRY(launch_demod_blk3(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+          e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_blk3_kernel<true, true>" : "fsk::demod_blk3_kernel<true, false>")
+                              : (e->P.uni_cfg ? "fsk::demod_blk3_kernel<false, true>" : "fsk::demod_blk3_kernel<false, false>");
+        } else if (two_wave && e->use_split3 && pipe3_lds <= 160 * 1024 && (wgs_per_cu * pipe3_lds <= 160 * 1024 || e->split_forced)) {
           HIP_TRY(launch_demod_pipe3(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
           e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_pipe3_kernel<true, true>" : "fsk::demod_pipe3_kernel<true, false>")
                               : (e->P.uni_cfg ? "fsk::demod_pipe3_kernel<false, true>" : "fsk::demod_pipe3_kernel<false, false>");

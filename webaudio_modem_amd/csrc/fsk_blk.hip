@@ -1,0 +1,521 @@
+// fsk_blk.hip -- round-3 whole-tile fp32 demodulator for gfx950 (MI355X): three waves per 64-stream group with a
+// BLOCK-BATCHED back wave.
+//
+// Why.  Round 2 priced the kernels by their vector instruction count.  Wave stamps (s_memtime around each wave's main loop
+// and its hand-off waits, profiles/r03_wave_stamps.txt) show what that misses: the back wave of demod_pipe_kernel is busy
+// 267-288 cycles per input sample even ALONE on its SIMD, for ~28 vector instructions per sample.  The probe rows of
+// profiles/r03_valu_probe_ctl.txt say why: besides its 4-cycle issue slot, every branch (taken or not), every LDS or
+// global memory instruction and every scalar compare-and-branch costs the issuing wave another 25-40 cycles -- and the
+// per-sample back executed three branches, an LDS write, a global store and two LDS reads per decimated sample.  Other
+// waves fill those cycles, so the SIMD does not care; the group does, because its pipeline runs at the pace of its
+// slowest wave.  (Removing the back wave's arithmetic piece by piece confirmed it: profiles/r03_back_cuts.txt.)
+//
+// What.  The back wave handles a half tile -- four decimated samples -- at a time (fsk.ts:278-375 restated per block):
+//   * per decimated sample only what is a recurrence: discriminator tail + post filter + slicer (disc_post, shared with
+//     the per-sample path), the sync correlator's running count, the silence run's last loud sample;
+//   * once per block: the bit clock.  A lane decides at most one bit per block (decisions are dsSPB >= 4 decimated
+//     samples apart), at sample jd = nextBitSampleIndex - k0 of the block, so the vote, the byte shift register and the
+//     start / stop-bit classification are evaluated once from the block's four slicer bits (popcounts of a 4-bit word);
+//   * ONE test per block for everything rare: 'eod' (bounded from above by the silence run at the block's end), a sync
+//     candidate (matched >= threshold at any of the four samples), a bad start or stop bit, a live ZIR correction, the
+//     amplitude ring about to wrap.  A block that trips it is redone sample by sample by back_pair (the round-2 code,
+//     unchanged arithmetic) from the block's entry state; the block path commits nothing before the test.
+//   * the polyphase sync registers live lane-major in LDS (four consecutive phases = one ds_read_b128 / ds_write_b128 per
+//     block instead of a read and a write per sample), rotated so that every block starts at a multiple of four;
+//   * the four amplitudes of a block are stored back to back at its end; completed bytes go to a four-byte queue per
+//     lane that is flushed every sixteen blocks (at most two bytes per lane can complete in between).
+// Bytes, counters and state are those of the per-sample kernels by construction: same float instruction sequence per
+// decimated sample, integer logic restated exactly (tests/test_gpu_parity.py runs every golden through this kernel).
+//
+// Waves: 0 loads + AGC + pre-filter -> y ring | 1 mixer + I/Q low-pass + speculative discriminator -> ring | 2 block back.
+// LDS: stage [4][65] v4f | yring [SL][2][64] v4f | ring [SL][4][64] v4f | fin [2][64] v4f | zt [2][8] v4f |
+//      poly [64][PS] u32 | counters [4] | zmail [64] u32          (SL = kPipeSlots half tiles)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "fsk_params.h"
+#include "fsk_dev.h"
+#include "fsk_pipe_dev.h"
+
+namespace fsk {
+
+static constexpr uint32_t kBlkSlotV4 = 4 * 64;     // v4f per ring slot: U[4 pairs x (I, Q)] | (phase, magnitude)[4 pairs]
+static constexpr uint32_t kFlushBlocks = 16;       // byte queues are flushed every this many blocks
+
+// lane stride of the polyphase registers in LDS: >= d, = 4 mod 8, so that the ds_read_b128 of 16 lanes at consecutive
+// strides touches 64 different banks (20 for 1200 baud, 84 for 300 baud)
+__host__ __device__ inline uint32_t blk_poly_stride(uint32_t d) {
+  uint32_t s = (d + 3u) & ~3u;
+  return (s & 4u) ? s : s + 4u;
+}
+
+struct BlkK {                    // block-level constants, VGPRs
+  uint32_t stop_m1;              // 2^stop_pos - 1: sreg > stop_m1 <=> all data bits in
+  uint32_t sh9;                  // stop_pos - 9: byte = (sreg >> sh9) & 0xFF
+  uint32_t ff;                   // 0xFF
+};
+
+// The fast path of one block (four decimated samples).  Works on copies (Bn, rp, bq, nq): the caller commits them only
+// if the returned flag word has its sign bit clear in every lane.  kv0 = pushes before the block.
+__device__ inline uint32_t blk_fast(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t kv0, const v4f pa0, const v4f pa1,
+                                    uint32_t (&rp)[4], float (&am)[4], uint32_t &bq, uint32_t &nq) {
+  const float phs[4] = {pa0.x, pa0.z, pa1.x, pa1.z};
+  am[0] = pa0.y; am[1] = pa0.w; am[2] = pa1.y; am[3] = pa1.w;
+  uint32_t w = 0, rare = 0;
+  const uint32_t ls0 = Bn.ls;
+  uint32_t kvj = kv0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    kvj += 1u;
+    const float f = disc_post(Bn, K, phs[j], am[j]);                        // fsk.ts:251-261
+    const uint32_t bit = sign_bit(__builtin_bit_cast(uint32_t, 0.0f - f));   // fsk.ts:264
+    const uint32_t rold = rp[j];
+    const uint32_t r = rold + rold + bit;                                    // syncSamplesBuffer.put(bit)
+    rp[j] = r;
+    Bn.matched += (uint32_t)__builtin_popcount((r ^ K.qn) & K.mask);
+    Bn.matched -= (uint32_t)__builtin_popcount((rold ^ K.qn) & K.mask);
+    rare |= ~(Bn.matched - Bn.thr_eff);                                      // sign set <=> matched >= thr_eff (sync candidate)
+    const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, am[j] - Bn.thr));   // fsk.ts:285
+    Bn.ls = (Bn.ls & silent) | (kvj & ~silent);
+    w = w + w + bit;                                                         // sample 1 ends up in bit 3
+  }
+  // 'eod' (fsk.ts:288): no silence run inside the block is longer than the one a wholly silent block would end with
+  rare |= K.eod_m1 - (kvj - ls0);
+  // ---- bit clock, once per block (fsk.ts:335-341): decision at sample jd of the block
+  uint32_t jd = Bn.T - kv0;                        // 1..4 in this block; 0 right after a sync (nextBitSampleIndex = k)
+  jd -= neg_mask(jd - 1u);                         // 0 -> 1
+  const uint32_t md = neg_mask(jd - 5u);           // all ones <=> a decision falls into this block
+  const uint32_t hi = w >> ((4u - jd) & 31u);      // the slicer bits of samples 1..jd (garbage without a decision: masked)
+  const uint32_t nhi = (uint32_t)__builtin_popcount(hi);
+  const uint32_t ones = nhi + Bn.acc;
+  const uint32_t tot = (uint32_t)__builtin_popcount(w);
+  const uint32_t kvd = kv0 + jd;
+  const uint32_t b = sign_bit((kvd - Bn.tlast) - ones - ones);               // 2 * bitAccumulator > bitAccumCount
+  const uint32_t s0 = Bn.sreg;
+  const uint32_t s1 = s0 + s0 + b;
+  // processByte (fsk.ts:346-375) at the decision
+  const uint32_t m_start = neg_mask(s0 - 2u);                                // waiting for the start bit
+  const uint32_t m_stop = neg_mask(Q.stop_m1 - s0);                          // all data bits in: stop (or parity) position
+  const uint32_t bm = 0u - b;
+  const uint32_t good = md & m_stop & bm;                                    // a byte completes
+  rare |= md & ((m_stop & ~bm) | (m_start & bm));                            // bad stop bit / bad start bit
+  Bn.acc = tot + (Bn.acc & ~md) - (nhi & md);
+  Bn.T += K.d & md;
+  Bn.tlast = (Bn.tlast & ~md) | (kvd & md);
+  Bn.sreg = (s0 & ~md) | (s1 & md & ~good) | (1u & good);
+  const uint32_t byte = (s0 >> Q.sh9) & Q.ff;
+  bq = (bq & ~good) | (((bq << 8) | byte) & good);
+  nq -= good;
+  return rare;
+}
+
+// completed bytes of the fast path -> out (oldest first); B.out_cnt counts them as the per-sample path does
+__device__ inline void blk_flush(BackLane &B, uint32_t &bq, uint32_t &nq, const FastMem &M, uint8_t *out, uint32_t out_pitch) {
+  while (__builtin_amdgcn_ballot_w64(nq != 0u)) {
+    if (nq != 0u) {
+      nq -= 1u;
+      const uint32_t byte = (bq >> (8u * nq)) & 0xFFu;
+      if (M.voff < 0xFFFFFFF0u && B.out_cnt < out_pitch) out[(size_t)(M.voff >> 2) * out_pitch + B.out_cnt] = (uint8_t)byte;
+      B.out_cnt++;
+    }
+  }
+}
+
+#ifdef FSK_STAMP
+extern "C" int fskdbg_read_stamps_blk(unsigned long long *out, size_t count);
+#endif
+
+template <bool WB, bool UNI>
+__global__ __launch_bounds__(192) void demod_blk3_kernel(
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch, int append,
+    uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
+    uint32_t *__restrict__ eod_counts) {
+  FSK_ABL_INIT
+  FSK_STAMP_DECL
+  extern __shared__ float4 lds[];
+  const uint32_t PS = blk_poly_stride(P.d);
+  v4f *stage = reinterpret_cast<v4f *>(lds);
+  v4f *yring = stage + 4 * kSlotStride;                   // wave 0 -> waves 1, 2: pre-filter outputs, [slot][quad][lane]
+  v4f *ring = yring + kPipeSlots * 2 * 64;                // wave 1 -> wave 2
+  v4f *fin = ring + kPipeSlots * kBlkSlotV4;
+  v4f *zt = fin + 2 * 64;
+  uint32_t *poly = reinterpret_cast<uint32_t *>(zt + 2 * 8);   // [lane][PS], index 0 = the phase of the launch's first push
+  uint32_t *ctr = poly + 64u * PS;                        // [0] wave 1 produced, [1] wave 2 consumed, [2] wave 0 produced
+  uint32_t *zmail = ctr + 4;
+  uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
+
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t stream = blockIdx.x * 64u + lane;
+  const PipeCtx C = pipe_ctx(P, S, stream);
+  const size_t n_tiles = n / kFastTile;
+  const uint32_t nh = 2u * (uint32_t)n_tiles;               // half tiles = blocks
+  const uint64_t inc = UNI ? (((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo) : S.nco_inc[C.row4 >> 2];
+  const uint64_t free0 = pipe_free0<UNI>(C);
+
+  if (threadIdx.x == 0) { ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; }
+  if (wave == 1) {
+    const FastMem &M = C.M;
+    const uint32_t fld = C.fld, row4 = C.row4;
+    zmail[lane] = zmail_init(PIPE_ILOAD(zr_dph));
+  }
+  __syncthreads();
+
+  if (wave == 0) {
+    // ------------------------------------------------------------------------------ loads, AGC, pre-filter
+    FrontLane F;
+    FrontK K;
+    front_load<UNI>(F, K, P, S, C);
+    const uint32_t sub_row = lane >> 2, chunk = lane & 3;
+    const uint32_t rows_here = P.n_streams - blockIdx.x * 64u < 64u ? P.n_streams - blockIdx.x * 64u : 64u;
+    v4i in_rsrc;
+    {
+      const uint64_t base = reinterpret_cast<uint64_t>(samples + (size_t)blockIdx.x * 64u * pitch);
+      in_rsrc.x = (int)(uint32_t)base;
+      in_rsrc.y = (int)(uint32_t)(base >> 32);
+      in_rsrc.z = (int)(uint32_t)(rows_here * pitch * 4u);
+      in_rsrc.w = 0x00020000;
+    }
+    const uint32_t in_voff = (uint32_t)((sub_row * pitch + 4u * chunk) * 4u);
+    const uint32_t in_row16 = (uint32_t)(16u * pitch * 4u);
+    const uint32_t st_slot = chunk * kSlotStride + sub_row;
+    // tile prefetch exactly as in demod_pipe_kernel (three register sets, hand-counted waits)
+#define BLK_BLOAD4(dst, rows16, soff)                                                                       \
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(in_voff + (rows16) * in_row16), \
+               "s"(in_rsrc), "s"(soff) : "memory")
+    auto load_tile = [&](size_t t, v4f &a, v4f &b, v4f &c, v4f &d) {
+      const uint32_t tn = (uint32_t)((t < n_tiles ? t : n_tiles - 1) * kFastTile * 4u);
+      BLK_BLOAD4(a, 0u, tn); BLK_BLOAD4(b, 1u, tn); BLK_BLOAD4(c, 2u, tn); BLK_BLOAD4(d, 3u, tn);
+    };
+    v4f a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the state loads above are complete, the count starts clean
+    load_tile(0, a0, a1, a2, a3);
+    load_tile(1, b0, b1, b2, b3);
+    load_tile(2, c0, c1, c2, c3);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+                 "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
+    uint32_t consumed = 0, slot_i = 0;
+    auto do_tile = [&](uint32_t t, v4f &r0, v4f &r1, v4f &r2, v4f &r3) {
+      if (WB) asm volatile("s_waitcnt vmcnt(16)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+      stage[st_slot] = r0; stage[st_slot + 16] = r1; stage[st_slot + 32] = r2; stage[st_slot + 48] = r3;
+      load_tile((size_t)t + 3, r0, r1, r2, r3);
+#pragma unroll 1
+      for (uint32_t hf = 0; hf < 2; hf++) {
+        const uint32_t hidx = 2u * t + hf;
+        if (hidx - consumed >= kPipeSlots) {
+          FSK_STAMP_W0
+          while (hidx - consumed >= kPipeSlots) {           // y ring full: the back wave (which may still need the slot's
+            consumed = lds_peek(&ctr[1]);                   // pre-filter outputs after a reset) has not released it
+            if (hidx - consumed >= kPipeSlots) __builtin_amdgcn_s_sleep(1);
+          }
+          FSK_STAMP_W1
+        }
+        v4f *slot = yring + slot_i * 2u * 64u;
+        slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
+#pragma unroll
+        for (uint32_t cc = 0; cc < 2; cc++) {
+          const uint32_t c = 2u * hf + cc;
+          const v4f x4 = stage[c * kSlotStride + lane];
+          const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
+          float xs[4], y[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) { if (FSK_ABL(0)) xs[j] = y[j] = xin[j]; else front_agc_bp(F, K, xin[j], xs[j], y[j]); }
+          slot[cc * 64u + lane] = (v4f){y[0], y[1], y[2], y[3]};
+          if (WB) {
+            if (C.valid)
+              *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + (size_t)t * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
+          }
+        }
+        lds_post(&ctr[2], hidx + 1u);
+      }
+    };
+    const uint32_t nt = (uint32_t)n_tiles;
+    FSK_STAMP_BEGIN
+    for (uint32_t t = 0; t < nt; t += 3) {
+      do_tile(t, a0, a1, a2, a3);
+      if (t + 1 < nt) do_tile(t + 1, b0, b1, b2, b3);
+      if (t + 2 < nt) do_tile(t + 2, c0, c1, c2, c3);
+    }
+    FSK_STAMP_END(0)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+                 "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
+#undef BLK_BLOAD4
+    {
+      const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
+      const FastMem &M = C.M;
+      const uint32_t fld = C.fld;
+      PIPE_RSTORE(agc_gain, F.g);
+      PIPE_RSTORE(bp_x1, F.bx1); PIPE_RSTORE(bp_x2, F.bx2); PIPE_RSTORE(bp_y1, F.by1); PIPE_RSTORE(bp_y2, F.by2);
+    }
+  } else if (wave == 1) {
+    // ------------------------------------------------------------------------------ mixer, I/Q low-pass, discriminator
+    FrontLane F;
+    FrontK K;
+    front_load<UNI>(F, K, P, S, C);
+    float wre = 1.f, wim = 0.f;
+    if (!UNI) {
+      const __amdgpu_buffer_rsrc_t cf_rsrc = C.cf_rsrc;
+      const uint32_t fld = C.fld, row4 = C.row4;
+      wre = (float)PIPE_CLOAD(CF_w1_re); wim = (float)PIPE_CLOAD(CF_w1_im);
+    }
+    uint64_t zacc = free0 + inc * (uint64_t)(lane & 15u);
+    uint64_t tacc = free0;
+    const uint64_t inc16 = inc * 16u;
+    uint32_t consumed = 0, produced = 0, slot_i = 0;
+    float zr = 1.f, zi = 0.f;
+    const v4f *ztile = zt;
+    FSK_STAMP_BEGIN
+    for (uint32_t hidx = 0; hidx < nh; hidx++) {
+      if (!(hidx & 1u)) {                                     // a new tile: its sixteen NCO phasors (see demod_pipe_kernel)
+        const uint32_t t = hidx >> 1;
+        ztile = zt + (t & 1u) * 8u;
+        if (UNI) {
+          float pc, ps;
+          nco_phasor(zacc, pc, ps);
+          reinterpret_cast<f2 *>(zt + (t & 1u) * 8u)[lane & 15u] = (f2){pc, ps};
+          zacc += inc16;
+        } else {
+          nco_phasor(tacc, zr, zi);
+          tacc += inc16;
+        }
+      }
+      if (produced <= hidx || hidx - consumed >= kPipeSlots) {
+        FSK_STAMP_W0
+        while (produced <= hidx) {                            // wave 0's half tile
+          produced = lds_peek(&ctr[2]);
+          if (produced <= hidx) __builtin_amdgcn_s_sleep(1);
+        }
+        while (hidx - consumed >= kPipeSlots) {               // ring full: wait for the back wave
+          consumed = lds_peek(&ctr[1]);
+          if (hidx - consumed >= kPipeSlots) __builtin_amdgcn_s_sleep(1);
+        }
+        FSK_STAMP_W1
+      }
+      const v4f *yslot = yring + slot_i * 2u * 64u;
+      v4f *slot = ring + slot_i * kBlkSlotV4;
+      slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
+      const uint32_t zj = zmail[lane];
+      const uint64_t zh = __builtin_amdgcn_ballot_w64(zj - 4u * hidx < 4u);
+#pragma unroll
+      for (uint32_t cc = 0; cc < 2; cc++) {
+        const uint32_t c = 2u * (hidx & 1u) + cc;
+        const v4f y4 = yslot[cc * 64u + lane];
+        const uint32_t pb = 4u * hidx + 2u * cc;
+        float zc[4], zs[4];
+        if (UNI) {
+          const v4f z01 = ztile[c * 2u], z23 = ztile[c * 2u + 1u];
+          zc[0] = z01.x; zs[0] = z01.y; zc[1] = z01.z; zs[1] = z01.w;
+          zc[2] = z23.x; zs[2] = z23.y; zc[3] = z23.z; zs[3] = z23.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            zc[j] = zr; zs[j] = zi;
+            const float nr = __builtin_fmaf(-zi, wim, zr * wre), ni = __builtin_fmaf(zi, wre, zr * wim);
+            zr = nr; zi = ni;
+          }
+        }
+        const float y[4] = {y4.x, y4.y, y4.z, y4.w};
+        float oi[4], oq[4];
+        if (FSK_ABL(1)) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) oi[j] = oq[j] = y[j] + zc[j];
+        } else if (__builtin_expect(zh != 0ull, 0)) {
+          asm volatile("s_nop 0");
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (!(j & 1)) front_zero(F, zj == pb + (uint32_t)(j >> 1));
+            front_mix_lp(F, K, y[j], zc[j], zs[j], oi[j], oq[j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) front_mix_lp(F, K, y[j], zc[j], zs[j], oi[j], oq[j]);
+        }
+        const float u0i = oi[0] + oi[1], u0q = oq[0] + oq[1], u1i = oi[2] + oi[3], u1q = oq[2] + oq[3];
+        float am0 = u0i, am1 = u1i, p0 = u0q, p1 = u1q;
+        if (!FSK_ABL(1)) {
+          p0 = atan2_amp_fma(u0q, u0i, am0, K.tiny, K.sgn);
+          p1 = atan2_amp_fma(u1q, u1i, am1, K.tiny, K.sgn);
+        }
+        slot[cc * 64u + lane] = (v4f){u0i, u0q, u1i, u1q};
+        slot[(2u + cc) * 64u + lane] = (v4f){p0, am0, p1, am1};
+      }
+      lds_post(&ctr[0], hidx + 1u);                           // for the back wave
+    }
+    FSK_STAMP_END(1)
+    fin[lane] = (v4f){F.ix1, F.ix2, F.iy, F.iv};
+    fin[64u + lane] = (v4f){F.qx1, F.qx2, F.qy, F.qv};
+    lds_post(&ctr[0], nh + 1u);
+  } else {
+    // ---------------------------------------------------------------------------------------------- block back
+    BackLane B;
+    BackK K;
+    back_load<UNI>(B, K, P, S, C, stream, out_counts, eod_counts, append);
+    BlkK Q;
+    Q.stop_m1 = (1u << P.stop_pos) - 1u; Q.sh9 = P.stop_pos - 9u; Q.ff = 0xFFu;
+    asm volatile("" : "+v"(Q.stop_m1), "+v"(Q.sh9), "+v"(Q.ff));
+    const FastMem &M = C.M;
+    const uint32_t fld = C.fld, row4 = C.row4;
+    const uint32_t phase0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
+    {
+      uint32_t ph = phase0;
+      for (uint32_t i = 0; i < P.d; i++) {                    // rotate: LDS index 0 = the register of the first push
+        poly[lane * PS + i] = gpoly[ph * 64u + lane];
+        ph = ph + 1u == P.d ? 0u : ph + 1u;
+      }
+    }
+    BackU X;
+    X.k = 0; X.kv = 0; X.free0 = free0; X.zmail = zmail; X.phase = 0;
+    X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) ? kDirectPairs : 0u;
+    X.zlive = __builtin_amdgcn_ballot_w64((B.dph < kDirectPairs) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
+    asm volatile("" : "+v"(X.kv));
+    const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
+    const uint32_t amp_row_bytes = P.n_streams * 4u;
+    X.amp_soff = amp_pos0 * amp_row_bytes;
+    const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
+    const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
+    uint32_t produced = 0, slot_i = 0;
+    uint32_t pidx = 0;                                        // LDS index of the block's first polyphase register
+    uint32_t bq = 0, nq = 0;                                  // completed bytes not yet stored (newest in the low byte)
+    uint32_t *prow = poly + lane * PS;
+    FSK_STAMP_BEGIN
+    for (uint32_t t0 = 0; t0 < nh; t0 += kFlushBlocks) {
+      const uint32_t t1 = t0 + kFlushBlocks < nh ? t0 + kFlushBlocks : nh;
+      for (uint32_t t = t0; t < t1; t++) {
+        if (produced <= t) {
+          FSK_STAMP_W0
+          while (produced <= t) {
+            produced = lds_peek(&ctr[0]);
+            if (produced <= t) __builtin_amdgcn_s_sleep(1);
+          }
+          FSK_STAMP_W1
+        }
+        const v4f *slot = ring + slot_i * kBlkSlotV4;
+        const v4f *yslot = yring + slot_i * 2u * 64u;
+        slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
+        const v4f pa0 = slot[2u * 64u + lane], pa1 = slot[3u * 64u + lane];
+        const uint4 rp4 = *reinterpret_cast<const uint4 *>(prow + pidx);
+        bool slow = X.zlive != 0u || X.amp_soff + 3u * amp_row_bytes >= amp_wrap;
+        if (FSK_ABL(2)) slow = false;
+        if (!slow && !FSK_ABL(2)) {
+          BackLane Bn = B;
+          uint32_t rp[4] = {rp4.x, rp4.y, rp4.z, rp4.w};
+          float am[4];
+          uint32_t bqn = bq, nqn = nq;
+          const uint32_t rare = blk_fast(Bn, K, Q, X.kv, pa0, pa1, rp, am, bqn, nqn);
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)rare < 0) != 0, 0)) {
+            slow = true;
+          } else {
+            B = Bn; bq = bqn; nq = nqn;
+            *reinterpret_cast<uint4 *>(prow + pidx) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
+#pragma unroll
+            for (int j = 0; j < 4; j++)                        // syncAmplitudeBuffer.put x 4 (no wrap inside: tested above)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, am[j]), amp_rsrc, M.voff, X.amp_soff + (uint32_t)j * amp_row_bytes, 0);
+            X.amp_soff += 4u * amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
+            X.k += 4u; X.kv += 4u;
+          }
+        }
+        if (__builtin_expect(slow, 0)) {
+          // something rare in this block: sample by sample from the block's entry state (the round-2 path)
+          blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
+#pragma unroll 1
+          for (uint32_t c = 0; c < 2; c++) {
+            const v4f u4 = slot[c * 64u + lane];
+            const v4f pa = c ? pa1 : pa0;
+            const float *yp = reinterpret_cast<const float *>(&yslot[c * 64u + lane]);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              X.k++;
+              X.kv += 1u;
+              uint32_t *ps = prow + pidx + 2u * c + (uint32_t)h;
+              const uint32_t r_old = *ps;
+              back_pair<UNI, true>(B, K, P, S, M, ps, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, h ? u4.z : u4.x,
+                                   h ? u4.w : u4.y, yp + 2 * h, r_old, inc, h ? pa.z : pa.x, h ? pa.w : pa.y);
+              X.amp_soff += amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
+            }
+          }
+        }
+        pidx = pidx + 4u >= P.d ? 0u : pidx + 4u;
+        lds_post(&ctr[1], t + 1u);                            // slot free (this wave's reads of it are complete)
+      }
+      blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
+    }
+    FSK_STAMP_END(2)
+    while (produced <= nh) {
+      produced = lds_peek(&ctr[0]);
+      if (produced <= nh) __builtin_amdgcn_s_sleep(1);
+    }
+    FrontLane F;
+    {
+      const v4f fi = fin[lane], fq = fin[64u + lane];
+      F.ix1 = fi.x; F.ix2 = fi.y; F.iy = fi.z; F.iv = fi.w;
+      F.qx1 = fq.x; F.qx2 = fq.y; F.qy = fq.z; F.qv = fq.w;
+      F.g = F.bx1 = F.bx2 = F.by1 = F.by2 = 0.f;
+    }
+    {
+      uint32_t ph = phase0;
+      for (uint32_t i = 0; i < P.d; i++) {
+        gpoly[ph * 64u + lane] = poly[lane * PS + i];
+        ph = ph + 1u == P.d ? 0u : ph + 1u;
+      }
+    }
+    const uint32_t phase_end = (phase0 + X.k) % P.d;
+    pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, phase_end, X.amp_soff / amp_row_bytes, inc, free0);
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+size_t demod_blk3_lds_bytes(const DemodParams &P) {
+  return sizeof(float4) * (4 * kSlotStride + kPipeSlots * 2 * 64 + kPipeSlots * kBlkSlotV4 + 2 * 64 + 2 * 8) +
+         sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 4u + 64u);
+}
+// the block path needs whole blocks of polyphase registers (dsSPB a multiple of 4) and at most one bit decision per block
+bool demod_blk3_applicable(const DemodParams &P) { return P.d >= 4u && (P.d & 3u) == 0u && !P.wide && !P.frac; }
+
+hipError_t set_blk3_lds_limit(const DemodParams &P) {
+  hipError_t e = hipSuccess;
+  const size_t bytes = demod_blk3_lds_bytes(P);
+  if (bytes > 160 * 1024) return hipSuccess;
+#define FSK_ATTR(WBV, UNIV)                                                                                      \
+  if (e == hipSuccess)                                                                                           \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk3_kernel<WBV, UNIV>),                       \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  FSK_ATTR(false, false) FSK_ATTR(false, true) FSK_ATTR(true, false) FSK_ATTR(true, true)
+#undef FSK_ATTR
+  return e;
+}
+
+#ifdef FSK_ABLATE
+static void set_ablate_blk() {
+  const char *a = getenv("FSK_ABLATE");
+  const int v = a ? atoi(a) : 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &v, sizeof(v));
+}
+#else
+static inline void set_ablate_blk() {}
+#endif
+
+hipError_t launch_demod_blk3(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+                             size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
+                             uint32_t *eod_counts, hipStream_t stream) {
+  const uint32_t blocks = (P.n_streams + 63u) / 64u;
+  const size_t lds = demod_blk3_lds_bytes(P);
+  set_ablate_blk();
+#define FSK_LAUNCH_BLK3(WBV, UNIV)                                                                          \
+  hipLaunchKernelGGL((demod_blk3_kernel<WBV, UNIV>), dim3(blocks), dim3(192), lds, stream, P, S, samples, n, pitch, \
+                     append ? 1 : 0, out, out_pitch, out_counts, eod_counts)
+  const bool uni = P.uni_cfg != 0;
+  if (writeback) { if (uni) FSK_LAUNCH_BLK3(true, true); else FSK_LAUNCH_BLK3(true, false); }
+  else { if (uni) FSK_LAUNCH_BLK3(false, true); else FSK_LAUNCH_BLK3(false, false); }
+#undef FSK_LAUNCH_BLK3
+  return hipGetLastError();
+}
+
+}  // namespace fsk
+
+#ifdef FSK_STAMP
+extern "C" int fskdbg_read_stamps_blk(unsigned long long *out, size_t count) {   // diagnostic builds only
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fsk::g_stamp), count * sizeof(unsigned long long));
+}
+#endif
