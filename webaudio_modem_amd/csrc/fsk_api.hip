@@ -37,11 +37,11 @@ hipError_t launch_demod_pipe3(bool writeback, bool append, const DemodParams &P,
                               size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts, uint32_t *eod_counts,
                               hipStream_t stream);
 size_t demod_fused_lds_bytes(const DemodParams &P);
-// fsk_blk.hip: three waves per group, block-batched back wave
-size_t demod_blk3_lds_bytes(const DemodParams &P);
-bool demod_blk3_applicable(const DemodParams &P);
-hipError_t set_blk3_lds_limit(const DemodParams &P);
-hipError_t launch_demod_blk3(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+// fsk_blk.hip: four waves per group, block-batched back wave
+size_t demod_blk_lds_bytes(const DemodParams &P);
+bool demod_blk_applicable(const DemodParams &P);
+hipError_t set_blk_lds_limit(const DemodParams &P);
+hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream);
 hipError_t set_pipe_lds_limit(size_t pipe_bytes);
@@ -107,7 +107,7 @@ __global__ void init_kernel(DemodState S, uint32_t n, uint32_t matched_zero) {
   rs[(size_t)RF_sil_thr * n + s] = (Real)0.01;
   S.is[(size_t)IF_matched * n + s] = matched_zero;
   S.is[(size_t)IF_bit_wait * n + s] = kBigWait;
-  S.is[(size_t)IF_zr_dph * n + s] = kDirectPairs;
+  S.is[(size_t)IF_zr_dph * n + s] = kHandPairs;
 }
 
 // reset() fsk.ts:464-469 = resetState() + syncSamplesBuffer.clear() (+ host-side counters).
@@ -134,7 +134,7 @@ __global__ void reset_kernel(DemodState S, uint32_t n, int64_t stream) {
     const int zz[] = {RF_zq_ai, RF_zq_aq, RF_zq_bi, RF_zq_bq, RF_zq_0i, RF_zq_0q, RF_zd_ix1, RF_zd_ix2, RF_zd_iy, RF_zd_iv,
                       RF_zd_qx1, RF_zd_qx2, RF_zd_qy, RF_zd_qv};
     for (int f : zz) rs[(size_t)f * n + s] = (Real)0;
-    S.is[(size_t)IF_zr_dph * n + s] = kDirectPairs;
+    S.is[(size_t)IF_zr_dph * n + s] = kHandPairs;
     double r = (double)fr0 * 5.42101086242752217e-20 * 6.283185307179586476925;
     r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
     for (int f : iz) S.is[(size_t)f * n + s] = 0u;
@@ -170,7 +170,7 @@ struct fskhip_engine {
   uint32_t split_cus = 256;
   bool split_forced = false;     // FSKHIP_SPLIT was set: skip the residency check too
   bool use_split3 = false;       // three waves per group (demod_pipe3_kernel): at most two groups per CU
-  bool use_blk3 = false;         // three waves per group with the block-batched back wave (demod_blk3_kernel, fsk_blk.hip)
+  bool use_blk = false;         // three waves per group with the block-batched back wave (demod_blk_kernel, fsk_blk.hip)
   bool gen_odd = false;          // fp32: the last generic-kernel launch left a decimator pair open (its partial sums are in
                                  // the reference's frame, the whole-tile kernels' in the free-running one)
   const char *last_kernel = "";  // what the last fskhip_demodulate_device call launched for its whole tiles
@@ -298,7 +298,7 @@ int fskhip_destroy(fskhip_engine *e) {
   (void)hipDeviceSynchronize();
   void *bufs[] = {e->S.rs, e->S.is, e->S.poly, e->S.amp_ring, (void *)e->S.coef, (void *)e->S.nco_inc, e->d_samples,
                   e->d_samples2, e->d_out, e->d_counts, e->d_eod, e->d_lens, e->d_payloads, e->d_status, e->d_sigma,
-                  e->S.trace_amp, e->S.trace_post, e->S.trace_bit, e->S.trace_n, e->S.poly_u};
+                  e->S.trace_amp, e->S.trace_post, e->S.trace_bit, e->S.trace_n, e->S.poly_u, e->S.cu_ctr};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (auto ev : e->ev) (void)hipEventDestroy(ev);
@@ -354,7 +354,7 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     // Gsamples/s; at one group per CU or fewer every wave is alone either way and the extra hand-off buys nothing)
     e->use_split3 = e->use_split && n_blocks > (uint32_t)cus && n_blocks <= (uint32_t)cus * 2u;
     if (const char *sp = getenv("FSKHIP_SPLIT")) {    // tests / measurements: 0 = one wave, 1 = two, 3 = three per group, 4 = three with the block back
-      e->use_split = sp[0] == '1' || sp[0] == '3' || sp[0] == '4'; e->use_split3 = sp[0] == '3'; e->use_blk3 = sp[0] == '4';
+      e->use_split = sp[0] == '1' || sp[0] == '3' || sp[0] == '4'; e->use_split3 = sp[0] == '3'; e->use_blk = sp[0] == '4';
       e->split_forced = true;
     }
   }
@@ -578,6 +578,8 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     CREATE_TRY(hipMemset(e->S.poly_u, 0, poly_bytes));
   }
   CREATE_TRY(hipMemset(e->S.amp_ring, 0, sizeof(float) * (size_t)P.amp_cap * n_streams));
+  CREATE_TRY(hipMalloc((void **)&e->S.cu_ctr, sizeof(uint32_t) * 2048));
+  CREATE_TRY(hipMemset(e->S.cu_ctr, 0, sizeof(uint32_t) * 2048));
   {
     dim3 g((n_streams + 255) / 256), b(256);
     if (precision == FSKHIP_PRECISION_F64) hipLaunchKernelGGL(init_kernel<double>, g, b, 0, 0, e->S, n_streams, matched_zero);
@@ -588,7 +590,7 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   if (e->demod_ok && e->lds_bytes > 48 * 1024) CREATE_TRY(set_demod_lds_limit(e->lds_bytes));
   if (e->demod_ok && !P.wide && !P.frac && precision == FSKHIP_PRECISION_F32 && demod_pipe_lds_bytes(P) <= 160 * 1024)
     CREATE_TRY(set_pipe_lds_limit(demod_pipe_lds_bytes(P)));
-  if (e->demod_ok && precision == FSKHIP_PRECISION_F32 && demod_blk3_applicable(P)) CREATE_TRY(set_blk3_lds_limit(P));
+  if (e->demod_ok && precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(P)) CREATE_TRY(set_blk_lds_limit(P));
   e->S.trace_stream = 0xFFFFFFFFu;
 #undef CREATE_TRY
   e->base_calls.assign(n_streams, 0);
@@ -677,11 +679,11 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
       }
       if (n_fast) {
         const size_t pipe3_lds = demod_pipe3_lds_bytes(e->P);
-        const size_t blk3_lds = demod_blk3_lds_bytes(e->P);
-        if (e->use_blk3 && demod_blk3_applicable(e->P) && blk3_lds <= 160 * 1024 && (wgs_per_cu * blk3_lds <= 160 * 1024 || e->split_forced)) {
-          HIP_TRY(launch_demod_blk3(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
-          e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_blk3_kernel<true, true>" : "fsk::demod_blk3_kernel<true, false>")
-                              : (e->P.uni_cfg ? "fsk::demod_blk3_kernel<false, true>" : "fsk::demod_blk3_kernel<false, false>");
+        const size_t blk_lds = demod_blk_lds_bytes(e->P);
+        if (e->use_blk && demod_blk_applicable(e->P) && blk_lds <= 160 * 1024 && (wgs_per_cu * blk_lds <= 160 * 1024 || e->split_forced)) {
+          HIP_TRY(launch_demod_blk(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
+          e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_blk_kernel<true, true>" : "fsk::demod_blk_kernel<true, false>")
+                              : (e->P.uni_cfg ? "fsk::demod_blk_kernel<false, true>" : "fsk::demod_blk_kernel<false, false>");
         } else if (two_wave && e->use_split3 && pipe3_lds <= 160 * 1024 && (wgs_per_cu * pipe3_lds <= 160 * 1024 || e->split_forced)) {
           HIP_TRY(launch_demod_pipe3(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
           e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_pipe3_kernel<true, true>" : "fsk::demod_pipe3_kernel<true, false>")

@@ -1,4 +1,4 @@
-// fsk_blk.hip -- round-3 whole-tile fp32 demodulator for gfx950 (MI355X): three waves per 64-stream group with a
+// fsk_blk.hip -- round-3 whole-tile fp32 demodulator for gfx950 (MI355X): FOUR waves per 64-stream group with a
 // BLOCK-BATCHED back wave.
 //
 // Why.  Round 2 priced the kernels by their vector instruction count.  Wave stamps (s_memtime around each wave's main loop
@@ -10,26 +10,39 @@
 // waves fill those cycles, so the SIMD does not care; the group does, because its pipeline runs at the pace of its
 // slowest wave.  (Removing the back wave's arithmetic piece by piece confirmed it: profiles/r03_back_cuts.txt.)
 //
-// What.  The back wave handles a half tile -- four decimated samples -- at a time (fsk.ts:278-375 restated per block):
+// What.  The chain is cut where nothing but a reset feeds back, into four waves of about equal length:
+//   0  tile loads, AGC, pre-filter                                   -> y ring   (what resetState() never touches)
+//   1  mixer + free-running I/Q low-pass + pair sums U               -> x ring   (zeroes a lane's filters kZeroLagPairs after a reset)
+//   2  ZIR correction (once it is this wave's) + discriminator       -> x ring, IN PLACE (phase, magnitude) over U
+//   3  post filter, slicer, sync correlator, frame state machine, a whole tile (eight decimated samples) at a time
+// and the back wave (3) restates fsk.ts:278-375 per block:
 //   * per decimated sample only what is a recurrence: discriminator tail + post filter + slicer (disc_post, shared with
 //     the per-sample path), the sync correlator's running count, the silence run's last loud sample;
-//   * once per block: the bit clock.  A lane decides at most one bit per block (decisions are dsSPB >= 4 decimated
+//   * once per block: the bit clock.  A lane decides at most one bit per block (decisions are dsSPB >= 8 decimated
 //     samples apart), at sample jd = nextBitSampleIndex - k0 of the block, so the vote, the byte shift register and the
-//     start / stop-bit classification are evaluated once from the block's four slicer bits (popcounts of a 4-bit word);
-//   * ONE test per block for everything rare: 'eod' (bounded from above by the silence run at the block's end), a sync
-//     candidate (matched >= threshold at any of the four samples), a bad start or stop bit, a live ZIR correction, the
-//     amplitude ring about to wrap.  A block that trips it is redone sample by sample by back_pair (the round-2 code,
-//     unchanged arithmetic) from the block's entry state; the block path commits nothing before the test.
-//   * the polyphase sync registers live lane-major in LDS (four consecutive phases = one ds_read_b128 / ds_write_b128 per
-//     block instead of a read and a write per sample), rotated so that every block starts at a multiple of four;
-//   * the four amplitudes of a block are stored back to back at its end; completed bytes go to a four-byte queue per
-//     lane that is flushed every sixteen blocks (at most two bytes per lane can complete in between).
+//     start / stop-bit classification are evaluated once from the block's eight slicer bits (popcounts of an 8-bit word);
+//   * ONE exit test per block for everything rare: 'eod' (bounded from above by the silence run at the block's end), a
+//     sync candidate (matched >= threshold at any of the eight samples), a bad start or stop bit, a correction or direct
+//     instance of this wave's own, the amplitude ring about to wrap.  A block that trips it is redone sample by sample by
+//     back_pair (the round-2 code, unchanged arithmetic) from the block's entry state; the block path commits nothing
+//     before the test.  ~3 % of the blocks of BASELINE config #3's signal.
+//   * the polyphase sync registers live lane-major in LDS (four consecutive phases = one ds_read_b128 / ds_write_b128),
+//     rotated so that every block starts at a multiple of four;
+//   * the amplitudes of a block are stored back to back at its end; completed bytes go to a four-byte queue per lane
+//     that is flushed every eight tiles (at most two bytes per lane can complete in between).
+// Who owns the ZIR correction.  After a reset the back wave runs the direct instance (kDirectPairs samples) and then keeps
+// the correction for kHandLag more samples, un-retired (fsk_params.h); its values at the hand-over sample follow from the
+// recurrence alone, so it posts them (cmail) to wave 2 -- which may be up to 24 decimated samples ahead -- when the direct
+// instance ends.  From the hand-over on wave 2 subtracts the correction before the discriminator and retires it by the
+// common rule, and the back wave's block path needs no discriminator of its own.  While a lane is inside the back wave's
+// span, wave 2 leaves its pair sums in the x ring instead of (phase, magnitude) (cmail[5] = where the span began).
 // Bytes, counters and state are those of the per-sample kernels by construction: same float instruction sequence per
 // decimated sample, integer logic restated exactly (tests/test_gpu_parity.py runs every golden through this kernel).
 //
-// Waves: 0 loads + AGC + pre-filter -> y ring | 1 mixer + I/Q low-pass + speculative discriminator -> ring | 2 block back.
-// LDS: stage [4][65] v4f | yring [SL][2][64] v4f | ring [SL][4][64] v4f | fin [2][64] v4f | zt [2][8] v4f |
-//      poly [64][PS] u32 | counters [4] | zmail [64] u32          (SL = kPipeSlots half tiles)
+// Which wave plays which part follows the SIMD it landed on, rotated by the workgroups the CU has started, so that every
+// SIMD hosts one wave of each part (see the kernel).
+// LDS: stage [4][65] v4f | yring [6][2][64] v4f | xring [6][2][64] v4f | fin [3][64] v4f | zt [2][8] v4f |
+//      poly [64][PS] u32 | counters [8] | zmail [64] u32 | cmail [6][64] u32
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -40,7 +53,9 @@
 
 namespace fsk {
 
-static constexpr uint32_t kBlkSlotV4 = 4 * 64;     // v4f per ring slot: U[4 pairs x (I, Q)] | (phase, magnitude)[4 pairs]
+static constexpr uint32_t kBlkSlots = 6;           // half tiles in the rings
+static_assert(4u * kBlkSlots <= kZeroLagPairs, "the wave that owns the I/Q low-pass must learn of a reset before it has passed the zeroing point");
+static constexpr uint32_t kBlkSlotV4 = 2 * 64;     // v4f per x-ring slot: four pair sums (I, Q) -- in place -> four (phase, magnitude)
 static constexpr uint32_t kFlushBlocks = 16;       // byte queues are flushed every this many blocks
 
 // lane stride of the polyphase registers in LDS: >= d, = 4 mod 8, so that the ds_read_b128 of 16 lanes at consecutive
@@ -56,17 +71,19 @@ struct BlkK {                    // block-level constants, VGPRs
   uint32_t ff;                   // 0xFF
 };
 
-// The fast path of one block (four decimated samples).  Works on copies (Bn, rp, bq, nq): the caller commits them only
-// if the returned flag word has its sign bit clear in every lane.  kv0 = pushes before the block.
-__device__ inline uint32_t blk_fast(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t kv0, const v4f pa0, const v4f pa1,
-                                    uint32_t (&rp)[4], float (&am)[4], uint32_t &bq, uint32_t &nq) {
-  const float phs[4] = {pa0.x, pa0.z, pa1.x, pa1.z};
-  am[0] = pa0.y; am[1] = pa0.w; am[2] = pa1.y; am[3] = pa1.w;
+// The fast path of one block (a tile: eight decimated samples).  Works on copies (Bn, rp, bq, nq): the caller commits
+// them only if the returned flag word has its sign bit clear in every lane.  kv0 = pushes before the block.
+static constexpr int kBlk = 8;                     // decimated samples per block
+__device__ inline uint32_t blk_fast(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t kv0, const v4f (&pa)[4],
+                                    uint32_t (&rp)[kBlk], float (&am)[kBlk], uint32_t &bq, uint32_t &nq) {
+  const float phs[kBlk] = {pa[0].x, pa[0].z, pa[1].x, pa[1].z, pa[2].x, pa[2].z, pa[3].x, pa[3].z};
+  am[0] = pa[0].y; am[1] = pa[0].w; am[2] = pa[1].y; am[3] = pa[1].w;
+  am[4] = pa[2].y; am[5] = pa[2].w; am[6] = pa[3].y; am[7] = pa[3].w;
   uint32_t w = 0, rare = 0;
   const uint32_t ls0 = Bn.ls;
   uint32_t kvj = kv0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < kBlk; j++) {
     kvj += 1u;
     const float f = disc_post(Bn, K, phs[j], am[j]);                        // fsk.ts:251-261
     const uint32_t bit = sign_bit(__builtin_bit_cast(uint32_t, 0.0f - f));   // fsk.ts:264
@@ -78,15 +95,15 @@ __device__ inline uint32_t blk_fast(BackLane &Bn, const BackK &K, const BlkK &Q,
     rare |= ~(Bn.matched - Bn.thr_eff);                                      // sign set <=> matched >= thr_eff (sync candidate)
     const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, am[j] - Bn.thr));   // fsk.ts:285
     Bn.ls = (Bn.ls & silent) | (kvj & ~silent);
-    w = w + w + bit;                                                         // sample 1 ends up in bit 3
+    w = w + w + bit;                                                         // sample 1 ends up in bit kBlk - 1
   }
   // 'eod' (fsk.ts:288): no silence run inside the block is longer than the one a wholly silent block would end with
   rare |= K.eod_m1 - (kvj - ls0);
   // ---- bit clock, once per block (fsk.ts:335-341): decision at sample jd of the block
-  uint32_t jd = Bn.T - kv0;                        // 1..4 in this block; 0 right after a sync (nextBitSampleIndex = k)
+  uint32_t jd = Bn.T - kv0;                        // 1..kBlk in this block; 0 right after a sync (nextBitSampleIndex = k)
   jd -= neg_mask(jd - 1u);                         // 0 -> 1
-  const uint32_t md = neg_mask(jd - 5u);           // all ones <=> a decision falls into this block
-  const uint32_t hi = w >> ((4u - jd) & 31u);      // the slicer bits of samples 1..jd (garbage without a decision: masked)
+  const uint32_t md = neg_mask(jd - (uint32_t)(kBlk + 1));   // all ones <=> a decision falls into this block
+  const uint32_t hi = w >> (((uint32_t)kBlk - jd) & 31u);    // the slicer bits of samples 1..jd (garbage without a decision: masked)
   const uint32_t nhi = (uint32_t)__builtin_popcount(hi);
   const uint32_t ones = nhi + Bn.acc;
   const uint32_t tot = (uint32_t)__builtin_popcount(w);
@@ -122,12 +139,12 @@ __device__ inline void blk_flush(BackLane &B, uint32_t &bq, uint32_t &nq, const 
   }
 }
 
-#ifdef FSK_STAMP
-extern "C" int fskdbg_read_stamps_blk(unsigned long long *out, size_t count);
-#endif
+// The discriminator wave's share of the ZIR correction (see back_pair for the arithmetic it restates op for op):
+// w = U - q, q advances by its recurrence and retires to exactly zero once below 2^-28 of the magnitude it corrects.
+struct QLane { float ai, aq, bi, bq; };
 
 template <bool WB, bool UNI>
-__global__ __launch_bounds__(192) void demod_blk3_kernel(
+__global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch, int append,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
     uint32_t *__restrict__ eod_counts) {
@@ -136,13 +153,15 @@ __global__ __launch_bounds__(192) void demod_blk3_kernel(
   extern __shared__ float4 lds[];
   const uint32_t PS = blk_poly_stride(P.d);
   v4f *stage = reinterpret_cast<v4f *>(lds);
-  v4f *yring = stage + 4 * kSlotStride;                   // wave 0 -> waves 1, 2: pre-filter outputs, [slot][quad][lane]
-  v4f *ring = yring + kPipeSlots * 2 * 64;                // wave 1 -> wave 2
-  v4f *fin = ring + kPipeSlots * kBlkSlotV4;
-  v4f *zt = fin + 2 * 64;
+  v4f *yring = stage + 4 * kSlotStride;                   // wave 0 -> wave 1 (and the back wave after a reset): pre-filter outputs
+  v4f *ring = yring + kBlkSlots * 2 * 64;                 // wave 1: pair sums U -> wave 2: (phase, magnitude) IN PLACE -> wave 3
+  v4f *fin = ring + kBlkSlots * kBlkSlotV4;               // [0..1] wave 1's final I/Q low-pass state, [2] wave 2's final correction
+  v4f *zt = fin + 3 * 64;
   uint32_t *poly = reinterpret_cast<uint32_t *>(zt + 2 * 8);   // [lane][PS], index 0 = the phase of the launch's first push
-  uint32_t *ctr = poly + 64u * PS;                        // [0] wave 1 produced, [1] wave 2 consumed, [2] wave 0 produced
-  uint32_t *zmail = ctr + 4;
+  uint32_t *ctr = poly + 64u * PS;                        // produced by wave 0, 1, 2 | consumed by wave 3
+  uint32_t *zmail = ctr + 8;                              // back -> wave 1: where to zero a lane's I/Q low-pass
+  uint32_t *cmail = zmail + 64;                           // back -> wave 2: [0] from which decimated sample, [1..4] the correction there,
+                                                          // [5] since which sample the back wave wants a lane's pair sums kept
   uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
 
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -154,15 +173,51 @@ __global__ __launch_bounds__(192) void demod_blk3_kernel(
   const uint64_t inc = UNI ? (((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo) : S.nco_inc[C.row4 >> 2];
   const uint64_t free0 = pipe_free0<UNI>(C);
 
-  if (threadIdx.x == 0) { ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; }
+  if (threadIdx.x == 0) {
+    ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0;
+    // Which wave plays which part.  A workgroup's four waves sit on the CU's four SIMDs (one each, in cyclic order from a
+    // varying start); four workgroups share a CU at BASELINE config #3's size.  If the part followed the wave index, some
+    // SIMDs would host three or four back waves and their groups would set the kernel's time (measured: 198 .. 295
+    // cycles per sample over the groups of one launch).  So the part follows the SIMD, rotated by how many workgroups
+    // this CU has started: every SIMD then hosts one wave of each part.
+    const uint32_t hw = __builtin_amdgcn_s_getreg(0xF804);        // HW_REG_HW_ID: simd 5:4, cu 11:8, sh 12, se 15:13
+    const uint32_t xcc = __builtin_amdgcn_s_getreg(0x1814) & 7u;  // HW_REG_XCC_ID
+    const uint32_t key = (xcc << 8) | ((hw >> 8) & 0xFFu);
+    ctr[4] = __hip_atomic_fetch_add(&S.cu_ctr[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (wave == 1) {
     const FastMem &M = C.M;
     const uint32_t fld = C.fld, row4 = C.row4;
     zmail[lane] = zmail_init(PIPE_ILOAD(zr_dph));
   }
+  if (wave == 3) {
+    // a correction still on its un-retired span when the launch starts: the back wave keeps it until zr_dph reaches
+    // kHandPairs, the discriminator wave takes it from decimated sample kHandPairs - zr_dph on
+    const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
+    const FastMem &M = C.M;
+    const uint32_t fld = C.fld, row4 = C.row4;
+    const uint32_t dph = PIPE_ILOAD(zr_dph);
+    uint32_t kq = 0xFFFFFFFFu;
+    float ai = 0.f, aq = 0.f, bi = 0.f, bq = 0.f;
+    if (dph >= kDirectPairs && dph < kHandPairs) {
+      ai = PIPE_RLOAD(zq_ai); aq = PIPE_RLOAD(zq_aq); bi = PIPE_RLOAD(zq_bi); bq = PIPE_RLOAD(zq_bq);
+      const float c1 = P.z_c1, c2 = P.z_c2;
+      for (uint32_t g = dph; g < kHandPairs; g++) {
+        const float ni = __builtin_fmaf(c1, bi, -(c2 * ai)), nq = __builtin_fmaf(c1, bq, -(c2 * aq));
+        ai = bi; aq = bq; bi = ni; bq = nq;
+      }
+      kq = kHandPairs - dph;
+    }
+    cmail[64u + lane] = __builtin_bit_cast(uint32_t, ai); cmail[128u + lane] = __builtin_bit_cast(uint32_t, aq);
+    cmail[192u + lane] = __builtin_bit_cast(uint32_t, bi); cmail[256u + lane] = __builtin_bit_cast(uint32_t, bq);
+    cmail[lane] = kq;
+    cmail[320u + lane] = 0u - dph;                          // (dph >= kHandPairs: the span is over)
+  }
   __syncthreads();
+  const uint32_t simd = (__builtin_amdgcn_s_getreg(0xF804) >> 4) & 3u;
+  const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)((simd + ctr[4]) & 3u));
 
-  if (wave == 0) {
+  if (role == 0) {
     // ------------------------------------------------------------------------------ loads, AGC, pre-filter
     FrontLane F;
     FrontK K;
@@ -204,16 +259,16 @@ __global__ __launch_bounds__(192) void demod_blk3_kernel(
 #pragma unroll 1
       for (uint32_t hf = 0; hf < 2; hf++) {
         const uint32_t hidx = 2u * t + hf;
-        if (hidx - consumed >= kPipeSlots) {
+        if (hidx - consumed >= kBlkSlots) {
           FSK_STAMP_W0
-          while (hidx - consumed >= kPipeSlots) {           // y ring full: the back wave (which may still need the slot's
-            consumed = lds_peek(&ctr[1]);                   // pre-filter outputs after a reset) has not released it
-            if (hidx - consumed >= kPipeSlots) __builtin_amdgcn_s_sleep(1);
+          while (hidx - consumed >= kBlkSlots) {           // ring full: the back wave (which may still need the slot's
+            consumed = lds_peek(&ctr[3]);                   // pre-filter outputs after a reset) has not released it
+            if (hidx - consumed >= kBlkSlots) __builtin_amdgcn_s_sleep(1);
           }
           FSK_STAMP_W1
         }
         v4f *slot = yring + slot_i * 2u * 64u;
-        slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
+        slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
 #pragma unroll
         for (uint32_t cc = 0; cc < 2; cc++) {
           const uint32_t c = 2u * hf + cc;
@@ -228,7 +283,7 @@ __global__ __launch_bounds__(192) void demod_blk3_kernel(
               *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + (size_t)t * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
           }
         }
-        lds_post(&ctr[2], hidx + 1u);
+        lds_post(&ctr[0], hidx + 1u);
       }
     };
     const uint32_t nt = (uint32_t)n_tiles;
@@ -249,8 +304,8 @@ __global__ __launch_bounds__(192) void demod_blk3_kernel(
       PIPE_RSTORE(agc_gain, F.g);
       PIPE_RSTORE(bp_x1, F.bx1); PIPE_RSTORE(bp_x2, F.bx2); PIPE_RSTORE(bp_y1, F.by1); PIPE_RSTORE(bp_y2, F.by2);
     }
-  } else if (wave == 1) {
-    // ------------------------------------------------------------------------------ mixer, I/Q low-pass, discriminator
+  } else if (role == 1) {
+    // ------------------------------------------------------------------------------ mixer, I/Q low-pass, pair sums
     FrontLane F;
     FrontK K;
     front_load<UNI>(F, K, P, S, C);
@@ -281,21 +336,21 @@ __global__ __launch_bounds__(192) void demod_blk3_kernel(
           tacc += inc16;
         }
       }
-      if (produced <= hidx || hidx - consumed >= kPipeSlots) {
+      if (produced <= hidx || hidx - consumed >= kBlkSlots) {
         FSK_STAMP_W0
         while (produced <= hidx) {                            // wave 0's half tile
-          produced = lds_peek(&ctr[2]);
+          produced = lds_peek(&ctr[0]);
           if (produced <= hidx) __builtin_amdgcn_s_sleep(1);
         }
-        while (hidx - consumed >= kPipeSlots) {               // ring full: wait for the back wave
-          consumed = lds_peek(&ctr[1]);
-          if (hidx - consumed >= kPipeSlots) __builtin_amdgcn_s_sleep(1);
+        while (hidx - consumed >= kBlkSlots) {               // ring full: wait for the back wave
+          consumed = lds_peek(&ctr[3]);
+          if (hidx - consumed >= kBlkSlots) __builtin_amdgcn_s_sleep(1);
         }
         FSK_STAMP_W1
       }
       const v4f *yslot = yring + slot_i * 2u * 64u;
       v4f *slot = ring + slot_i * kBlkSlotV4;
-      slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
+      slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
       const uint32_t zj = zmail[lane];
       const uint64_t zh = __builtin_amdgcn_ballot_w64(zj - 4u * hidx < 4u);
 #pragma unroll
@@ -332,26 +387,96 @@ __global__ __launch_bounds__(192) void demod_blk3_kernel(
 #pragma unroll
           for (int j = 0; j < 4; j++) front_mix_lp(F, K, y[j], zc[j], zs[j], oi[j], oq[j]);
         }
-        const float u0i = oi[0] + oi[1], u0q = oq[0] + oq[1], u1i = oi[2] + oi[3], u1q = oq[2] + oq[3];
-        float am0 = u0i, am1 = u1i, p0 = u0q, p1 = u1q;
-        if (!FSK_ABL(1)) {
-          p0 = atan2_amp_fma(u0q, u0i, am0, K.tiny, K.sgn);
-          p1 = atan2_amp_fma(u1q, u1i, am1, K.tiny, K.sgn);
-        }
-        slot[cc * 64u + lane] = (v4f){u0i, u0q, u1i, u1q};
-        slot[(2u + cc) * 64u + lane] = (v4f){p0, am0, p1, am1};
+        slot[cc * 64u + lane] = (v4f){oi[0] + oi[1], oq[0] + oq[1], oi[2] + oi[3], oq[2] + oq[3]};   // U (I, Q) x 2
       }
-      lds_post(&ctr[0], hidx + 1u);                           // for the back wave
+      lds_post(&ctr[1], hidx + 1u);                           // for the discriminator wave
     }
     FSK_STAMP_END(1)
     fin[lane] = (v4f){F.ix1, F.ix2, F.iy, F.iv};
     fin[64u + lane] = (v4f){F.qx1, F.qx2, F.qy, F.qv};
-    lds_post(&ctr[0], nh + 1u);
+    lds_post(&ctr[1], nh + 1u);
+  } else if (role == 2) {
+    // ------------------------------------------------------------------------------ ZIR correction + discriminator
+    const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
+    const FastMem &M = C.M;
+    const uint32_t fld = C.fld, row4 = C.row4;
+    QLane Qz = {0.f, 0.f, 0.f, 0.f};
+    if (PIPE_ILOAD(zr_dph) >= kHandPairs) {                   // this wave's from the first sample on
+      Qz.ai = PIPE_RLOAD(zq_ai); Qz.aq = PIPE_RLOAD(zq_aq); Qz.bi = PIPE_RLOAD(zq_bi); Qz.bq = PIPE_RLOAD(zq_bq);
+    }
+    float c1 = P.z_c1, c2 = P.z_c2, tiny = 0x1p-123f, rel = 3.7252902984619141e-09f;
+    uint32_t sgn = 0x80000000u;
+    asm volatile("" : "+v"(c1), "+v"(c2), "+v"(tiny), "+v"(rel), "+v"(sgn));
+    uint32_t qlive = __builtin_amdgcn_ballot_w64((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f)) ? 1u : 0u;
+    uint32_t produced = 0, slot_i = 0;
+    FSK_STAMP_BEGIN
+    for (uint32_t hidx = 0; hidx < nh; hidx++) {
+      if (produced <= hidx) {
+        FSK_STAMP_W0
+        while (produced <= hidx) {
+          produced = lds_peek(&ctr[1]);
+          if (produced <= hidx) __builtin_amdgcn_s_sleep(1);
+        }
+        FSK_STAMP_W1
+      }
+      v4f *slot = ring + slot_i * kBlkSlotV4;
+      slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
+      const v4f ua = slot[lane], ub = slot[64u + lane];
+      const uint32_t kq = cmail[lane];
+      const uint32_t ow = 4u * hidx - cmail[320u + lane];       // decimated samples since the back wave's own span began
+      const uint32_t hit = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(kq - 4u * hidx < 4u) != 0));
+      const uint32_t anyown = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(ow < kHandPairs) != 0));
+      const float ui[4] = {ua.x, ua.z, ub.x, ub.z}, uq[4] = {ua.y, ua.w, ub.y, ub.w};
+      float ph[4], am[4];
+      if (__builtin_expect((qlive | hit) != 0u, 0)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (hit) {
+            if (kq == 4u * hidx + (uint32_t)j) {              // the back wave's correction becomes this wave's here
+              Qz.ai = __builtin_bit_cast(float, cmail[64u + lane]); Qz.aq = __builtin_bit_cast(float, cmail[128u + lane]);
+              Qz.bi = __builtin_bit_cast(float, cmail[192u + lane]); Qz.bq = __builtin_bit_cast(float, cmail[256u + lane]);
+            }
+          }
+          const float wi = ui[j] - Qz.ai, wq = uq[j] - Qz.aq;
+          {
+            const float ni = __builtin_fmaf(c1, Qz.bi, -(c2 * Qz.ai)), nq = __builtin_fmaf(c1, Qz.bq, -(c2 * Qz.aq));
+            Qz.ai = Qz.bi; Qz.aq = Qz.bq; Qz.bi = ni; Qz.bq = nq;
+          }
+          ph[j] = atan2_amp_fma(wq, wi, am[j], tiny, sgn);
+          const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(Qz.ai), __builtin_fabsf(Qz.aq)),
+                                            __builtin_fmaxf(__builtin_fabsf(Qz.bi), __builtin_fabsf(Qz.bq)));
+          if (!(big > am[j] * rel)) { Qz.ai = 0.f; Qz.aq = 0.f; Qz.bi = 0.f; Qz.bq = 0.f; }
+        }
+        qlive = __builtin_amdgcn_ballot_w64((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f)) ? 1u : 0u;
+      } else if (FSK_ABL(2)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { ph[j] = ui[j]; am[j] = uq[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) ph[j] = atan2_amp_fma(uq[j], ui[j], am[j], tiny, sgn);
+      }
+      if (__builtin_expect(anyown != 0u, 0)) {
+        // lanes inside the back wave's own span (direct instance, then its own correction): it evaluates their
+        // discriminator itself and needs the pair sums for that, so they stay
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const bool own = ow + (uint32_t)j < kHandPairs;
+          ph[j] = own ? ui[j] : ph[j]; am[j] = own ? uq[j] : am[j];
+        }
+      }
+      slot[lane] = (v4f){ph[0], am[0], ph[1], am[1]};         // in place: wave 1 will not touch the slot before the back wave frees it
+      slot[64u + lane] = (v4f){ph[2], am[2], ph[3], am[3]};
+      lds_post(&ctr[2], hidx + 1u);
+    }
+    FSK_STAMP_END(2)
+    fin[128u + lane] = (v4f){Qz.ai, Qz.aq, Qz.bi, Qz.bq};
+    lds_post(&ctr[2], nh + 1u);
   } else {
     // ---------------------------------------------------------------------------------------------- block back
     BackLane B;
     BackK K;
     back_load<UNI>(B, K, P, S, C, stream, out_counts, eod_counts, append);
+    if (B.dph >= kHandPairs) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }   // the discriminator wave's
     BlkK Q;
     Q.stop_m1 = (1u << P.stop_pos) - 1u; Q.sh9 = P.stop_pos - 9u; Q.ff = 0xFFu;
     asm volatile("" : "+v"(Q.stop_m1), "+v"(Q.sh9), "+v"(Q.ff));
@@ -366,9 +491,9 @@ __global__ __launch_bounds__(192) void demod_blk3_kernel(
       }
     }
     BackU X;
-    X.k = 0; X.kv = 0; X.free0 = free0; X.zmail = zmail; X.phase = 0;
+    X.k = 0; X.kv = 0; X.free0 = free0; X.zmail = zmail; X.cmail = cmail; X.phase = 0;
     X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) ? kDirectPairs : 0u;
-    X.zlive = __builtin_amdgcn_ballot_w64((B.dph < kDirectPairs) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
+    X.zlive = __builtin_amdgcn_ballot_w64(B.dph < kHandPairs) ? 1u : 0u;
     asm volatile("" : "+v"(X.kv));
     const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
     const uint32_t amp_row_bytes = P.n_streams * 4u;
@@ -380,49 +505,63 @@ __global__ __launch_bounds__(192) void demod_blk3_kernel(
     uint32_t bq = 0, nq = 0;                                  // completed bytes not yet stored (newest in the low byte)
     uint32_t *prow = poly + lane * PS;
     FSK_STAMP_BEGIN
-    for (uint32_t t0 = 0; t0 < nh; t0 += kFlushBlocks) {
-      const uint32_t t1 = t0 + kFlushBlocks < nh ? t0 + kFlushBlocks : nh;
-      for (uint32_t t = t0; t < t1; t++) {
-        if (produced <= t) {
-          FSK_STAMP_W0
-          while (produced <= t) {
-            produced = lds_peek(&ctr[0]);
-            if (produced <= t) __builtin_amdgcn_s_sleep(1);
-          }
-          FSK_STAMP_W1
+    uint32_t t = 0;                                           // half tiles consumed (a block = a tile = two of them)
+    while (t < nh) {
+      if (produced < t + 2u) {
+        FSK_STAMP_W0
+        while (produced < t + 2u) {
+          produced = lds_peek(&ctr[2]);
+          if (produced < t + 2u) __builtin_amdgcn_s_sleep(1);
         }
-        const v4f *slot = ring + slot_i * kBlkSlotV4;
-        const v4f *yslot = yring + slot_i * 2u * 64u;
-        slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
-        const v4f pa0 = slot[2u * 64u + lane], pa1 = slot[3u * 64u + lane];
-        const uint4 rp4 = *reinterpret_cast<const uint4 *>(prow + pidx);
-        bool slow = X.zlive != 0u || X.amp_soff + 3u * amp_row_bytes >= amp_wrap;
-        if (FSK_ABL(2)) slow = false;
-        if (!slow && !FSK_ABL(2)) {
-          BackLane Bn = B;
-          uint32_t rp[4] = {rp4.x, rp4.y, rp4.z, rp4.w};
-          float am[4];
-          uint32_t bqn = bq, nqn = nq;
-          const uint32_t rare = blk_fast(Bn, K, Q, X.kv, pa0, pa1, rp, am, bqn, nqn);
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)rare < 0) != 0, 0)) {
-            slow = true;
-          } else {
-            B = Bn; bq = bqn; nq = nqn;
-            *reinterpret_cast<uint4 *>(prow + pidx) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
+        FSK_STAMP_W1
+      }
+      // every tile that is there, up to the next flush point
+      uint32_t lim = (t | (kFlushBlocks - 1u)) + 1u;
+      lim = lim < nh ? lim : nh;
+      lim = lim < (produced & ~1u) ? lim : (produced & ~1u);
+      // ---- the block loop: straight-line code with two branches, its back edge and the exit on anything rare (a branch
+      // costs a wave ~35 cycles whether taken or not)
+      bool rare_exit = false;
+      do {
+        const uint32_t slot_j = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
+        const uint32_t pidx2 = pidx + 4u >= P.d ? 0u : pidx + 4u;
+        const v4f *slot = ring + slot_i * kBlkSlotV4, *slot2 = ring + slot_j * kBlkSlotV4;
+        const v4f pa[4] = {slot[lane], slot[64u + lane], slot2[lane], slot2[64u + lane]};
+        const uint4 rpa = *reinterpret_cast<const uint4 *>(prow + pidx), rpb = *reinterpret_cast<const uint4 *>(prow + pidx2);
+        BackLane Bn = B;
+        uint32_t rp[kBlk] = {rpa.x, rpa.y, rpa.z, rpa.w, rpb.x, rpb.y, rpb.z, rpb.w};
+        float am[kBlk];
+        uint32_t bqn = bq, nqn = nq;
+        const uint32_t rare = blk_fast(Bn, K, Q, X.kv, pa, rp, am, bqn, nqn);
+        // (a live correction of this wave's, or the amplitude ring's wrap, make the block path void: ~3 % of the blocks)
+        const bool pre = (X.zlive != 0u) | (X.amp_soff + 7u * amp_row_bytes >= amp_wrap);
+        FSK_STAMP_COUNT(0)                                    // blocks
+        if (__builtin_expect(((__builtin_amdgcn_ballot_w64((int32_t)rare < 0) != 0) | pre) & !FSK_ABL(3), 0)) { rare_exit = true; break; }
+        B = Bn; bq = bqn; nq = nqn;
+        *reinterpret_cast<uint4 *>(prow + pidx) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
+        *reinterpret_cast<uint4 *>(prow + pidx2) = make_uint4(rp[4], rp[5], rp[6], rp[7]);
 #pragma unroll
-            for (int j = 0; j < 4; j++)                        // syncAmplitudeBuffer.put x 4 (no wrap inside: tested above)
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, am[j]), amp_rsrc, M.voff, X.amp_soff + (uint32_t)j * amp_row_bytes, 0);
-            X.amp_soff += 4u * amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
-            X.k += 4u; X.kv += 4u;
-          }
-        }
-        if (__builtin_expect(slow, 0)) {
-          // something rare in this block: sample by sample from the block's entry state (the round-2 path)
-          blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
+        for (int j = 0; j < kBlk; j++)                         // syncAmplitudeBuffer.put x 8 (no wrap inside: tested above)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, am[j]), amp_rsrc, M.voff, X.amp_soff + (uint32_t)j * amp_row_bytes, 0);
+        X.amp_soff += (uint32_t)kBlk * amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
+        X.k += (uint32_t)kBlk; X.kv += (uint32_t)kBlk;
+        slot_i = slot_j + 1u == kBlkSlots ? 0u : slot_j + 1u;
+        pidx = pidx2 + 4u >= P.d ? 0u : pidx2 + 4u;
+        t += 2u;
+        lds_post(&ctr[3], t);                                 // slots free (this wave's reads of them are complete)
+      } while (t < lim);
+      if (rare_exit) {
+        // something rare in the tile at t: sample by sample from its entry state (the round-2 path, unchanged)
+        if (X.zlive != 0u) { FSK_STAMP_COUNT(1) } else { FSK_STAMP_COUNT(3) }
+        blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
+#pragma unroll 1
+        for (uint32_t hh = 0; hh < 2; hh++) {
+          const v4f *slot = ring + slot_i * kBlkSlotV4;
+          const v4f *yslot = yring + slot_i * 2u * 64u;
 #pragma unroll 1
           for (uint32_t c = 0; c < 2; c++) {
-            const v4f u4 = slot[c * 64u + lane];
-            const v4f pa = c ? pa1 : pa0;
+            const v4f u4 = slot[c * 64u + lane];             // pair sums where this wave's own span covers the lane, else (phase, magnitude)
+            const v4f pa = u4;
             const float *yp = reinterpret_cast<const float *>(&yslot[c * 64u + lane]);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -430,28 +569,36 @@ __global__ __launch_bounds__(192) void demod_blk3_kernel(
               X.kv += 1u;
               uint32_t *ps = prow + pidx + 2u * c + (uint32_t)h;
               const uint32_t r_old = *ps;
-              back_pair<UNI, true>(B, K, P, S, M, ps, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, h ? u4.z : u4.x,
-                                   h ? u4.w : u4.y, yp + 2 * h, r_old, inc, h ? pa.z : pa.x, h ? pa.w : pa.y);
+              back_pair<UNI, true, false, true>(B, K, P, S, M, ps, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
+                                                h ? u4.z : u4.x, h ? u4.w : u4.y, yp + 2 * h, r_old, inc, h ? pa.z : pa.x, h ? pa.w : pa.y);
               X.amp_soff += amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
             }
           }
+          slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
+          pidx = pidx + 4u >= P.d ? 0u : pidx + 4u;
+          t++;
+          lds_post(&ctr[3], t);
         }
-        pidx = pidx + 4u >= P.d ? 0u : pidx + 4u;
-        lds_post(&ctr[1], t + 1u);                            // slot free (this wave's reads of it are complete)
       }
-      blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
+      if ((t & (kFlushBlocks - 1u)) == 0u) blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
     }
-    FSK_STAMP_END(2)
+    blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
+    FSK_STAMP_END(3)
     while (produced <= nh) {
-      produced = lds_peek(&ctr[0]);
+      produced = lds_peek(&ctr[2]);
       if (produced <= nh) __builtin_amdgcn_s_sleep(1);
     }
+    while (lds_peek(&ctr[1]) <= nh) __builtin_amdgcn_s_sleep(1);
     FrontLane F;
     {
       const v4f fi = fin[lane], fq = fin[64u + lane];
       F.ix1 = fi.x; F.ix2 = fi.y; F.iy = fi.z; F.iv = fi.w;
       F.qx1 = fq.x; F.qx2 = fq.y; F.qy = fq.z; F.qv = fq.w;
       F.g = F.bx1 = F.bx2 = F.by1 = F.by2 = 0.f;
+    }
+    if (B.dph >= kHandPairs) {                                // the correction as the discriminator wave left it
+      const v4f qz = fin[128u + lane];
+      B.qai = qz.x; B.qaq = qz.y; B.qbi = qz.z; B.qbq = qz.w;
     }
     {
       uint32_t ph = phase0;
@@ -466,20 +613,20 @@ __global__ __launch_bounds__(192) void demod_blk3_kernel(
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-size_t demod_blk3_lds_bytes(const DemodParams &P) {
-  return sizeof(float4) * (4 * kSlotStride + kPipeSlots * 2 * 64 + kPipeSlots * kBlkSlotV4 + 2 * 64 + 2 * 8) +
-         sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 4u + 64u);
+size_t demod_blk_lds_bytes(const DemodParams &P) {
+  return sizeof(float4) * (4 * kSlotStride + kBlkSlots * 2 * 64 + kBlkSlots * kBlkSlotV4 + 3 * 64 + 2 * 8) +
+         sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 8u + 64u + 6u * 64u);
 }
 // the block path needs whole blocks of polyphase registers (dsSPB a multiple of 4) and at most one bit decision per block
-bool demod_blk3_applicable(const DemodParams &P) { return P.d >= 4u && (P.d & 3u) == 0u && !P.wide && !P.frac; }
+bool demod_blk_applicable(const DemodParams &P) { return P.d >= 8u && (P.d & 3u) == 0u && !P.wide && !P.frac; }
 
-hipError_t set_blk3_lds_limit(const DemodParams &P) {
+hipError_t set_blk_lds_limit(const DemodParams &P) {
   hipError_t e = hipSuccess;
-  const size_t bytes = demod_blk3_lds_bytes(P);
+  const size_t bytes = demod_blk_lds_bytes(P);
   if (bytes > 160 * 1024) return hipSuccess;
 #define FSK_ATTR(WBV, UNIV)                                                                                      \
   if (e == hipSuccess)                                                                                           \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk3_kernel<WBV, UNIV>),                       \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk_kernel<WBV, UNIV>),                       \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   FSK_ATTR(false, false) FSK_ATTR(false, true) FSK_ATTR(true, false) FSK_ATTR(true, true)
 #undef FSK_ATTR
@@ -496,19 +643,19 @@ static void set_ablate_blk() {
 static inline void set_ablate_blk() {}
 #endif
 
-hipError_t launch_demod_blk3(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream) {
   const uint32_t blocks = (P.n_streams + 63u) / 64u;
-  const size_t lds = demod_blk3_lds_bytes(P);
+  const size_t lds = demod_blk_lds_bytes(P);
   set_ablate_blk();
-#define FSK_LAUNCH_BLK3(WBV, UNIV)                                                                          \
-  hipLaunchKernelGGL((demod_blk3_kernel<WBV, UNIV>), dim3(blocks), dim3(192), lds, stream, P, S, samples, n, pitch, \
+#define FSK_LAUNCH_BLK(WBV, UNIV)                                                                          \
+  hipLaunchKernelGGL((demod_blk_kernel<WBV, UNIV>), dim3(blocks), dim3(256), lds, stream, P, S, samples, n, pitch, \
                      append ? 1 : 0, out, out_pitch, out_counts, eod_counts)
   const bool uni = P.uni_cfg != 0;
-  if (writeback) { if (uni) FSK_LAUNCH_BLK3(true, true); else FSK_LAUNCH_BLK3(true, false); }
-  else { if (uni) FSK_LAUNCH_BLK3(false, true); else FSK_LAUNCH_BLK3(false, false); }
-#undef FSK_LAUNCH_BLK3
+  if (writeback) { if (uni) FSK_LAUNCH_BLK(true, true); else FSK_LAUNCH_BLK(true, false); }
+  else { if (uni) FSK_LAUNCH_BLK(false, true); else FSK_LAUNCH_BLK(false, false); }
+#undef FSK_LAUNCH_BLK
   return hipGetLastError();
 }
 

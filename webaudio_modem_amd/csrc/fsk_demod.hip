@@ -207,7 +207,7 @@ __device__ inline void actual_to_pipe(Lane<float> &L, const DemodState &S, size_
   L.last_phase = (float)r;
   S.is[(size_t)IF_fr_lo * n + row] = (uint32_t)off;
   S.is[(size_t)IF_fr_hi * n + row] = (uint32_t)(off >> 32);
-  S.is[(size_t)IF_zr_dph * n + row] = kDirectPairs;
+  S.is[(size_t)IF_zr_dph * n + row] = kHandPairs;
   const int zf[] = {RF_zq_ai, RF_zq_aq, RF_zq_bi, RF_zq_bq, RF_zq_0i, RF_zq_0q, RF_zd_ix1, RF_zd_ix2, RF_zd_iy, RF_zd_iv,
                     RF_zd_qx1, RF_zd_qx2, RF_zd_qy, RF_zd_qv};
   for (int f : zf) rs[(size_t)f * n + row] = 0.0f;

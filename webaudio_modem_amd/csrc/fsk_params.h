@@ -58,7 +58,8 @@ namespace fsk {
 #define FSK_INT_FIELDS_PIPE(X)                                                              \
   X(fr_lo) X(fr_hi)     /* fp32: NCO phase minus the free-running frame's phase (64-bit turns); */ \
                         /* changes only at resetState()                                     */      \
-  X(zr_dph)             /* fp32: decimated samples the direct instance has produced since resetState(); kDirectPairs = zq_* valid */
+  X(zr_dph)             /* fp32: decimated samples since resetState(), saturating at kHandPairs; < kDirectPairs: the direct instance runs, */ \
+                        /* from kDirectPairs on zq_* is valid, from kHandPairs on it may retire */
 
 enum RealField {
 #define X(n) RF_##n,
@@ -149,6 +150,7 @@ struct DemodState {
   uint32_t *trace_n;      // running count of decimated samples captured
   uint32_t trace_cap;
   uint32_t trace_stream;  // 0xFFFFFFFF = off
+  uint32_t *cu_ctr;       // u32 [2048]: workgroups started per compute unit (fsk_blk.hip spreads its waves' roles with it)
 };
 
 struct ModParams {
@@ -181,10 +183,17 @@ struct ProcState {
 };
 
 // fp32 free-running frame (fsk_pipe.hip): the front end zeroes a stream's I/Q low-pass kZeroLagPairs decimated samples
-// after a resetState() -- far enough for the two-wave kernel's front wave (at most kPipeSlots = 4 half tiles = 16
-// decimated samples ahead) to learn of the reset in time -- and a direct instance covers those plus two more.
-static constexpr uint32_t kZeroLagPairs = 16;
+// after a resetState() -- far enough for the wave that owns the low-pass (at most six half tiles = 24 decimated samples
+// ahead of the back wave in fsk_blk.hip, four in fsk_pipe.hip) to learn of the reset in time -- and a direct instance
+// covers those plus two more.
+static constexpr uint32_t kZeroLagPairs = 24;
 static constexpr uint32_t kDirectPairs = kZeroLagPairs + 2;
+// The zero-input response left by a reset is carried un-retired for another kHandLag decimated samples (zr_dph counts on
+// to kHandPairs).  That fixed span is what lets the four-wave kernel (fsk_blk.hip) move the correction from its back wave
+// to the discriminator wave running up to 16 decimated samples AHEAD of it: the values at the hand-over sample follow
+// from the two start values by the recurrence alone, so the back wave can post them 20 samples early.
+static constexpr uint32_t kHandLag = 20;
+static constexpr uint32_t kHandPairs = kDirectPairs + kHandLag;
 static constexpr uint32_t kBigWait = 0x40000000u;  // bit_wait while !started (12 h of decimated samples)
 #ifndef FSK_TILE
 #define FSK_TILE 32

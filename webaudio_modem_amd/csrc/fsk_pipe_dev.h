@@ -28,18 +28,24 @@ static __device__ int g_ablate;
 // the cycles it spends in its hand-off wait loops and in its whole main loop (s_memtime), and writes both to g_stamp at
 // the end: which wave paces the group and how much slack the others have.  Compiled out of the shipped library.
 #ifdef FSK_STAMP
-static __device__ unsigned long long g_stamp[3 * 2048 * 2];   // [wave][group][wait, total]
-#define FSK_STAMP_DECL unsigned long long st_wait = 0, st_t0 = 0, st_w0 = 0;
-#define FSK_STAMP_BEGIN st_t0 = __builtin_amdgcn_s_memtime();
+static __device__ unsigned long long g_stamp[4 * 2048 * 8];   // [wave][group][wait, total, HW_ID, four event counters, s_memrealtime at the loop's start]
+#define FSK_STAMP_DECL unsigned long long st_wait = 0, st_t0 = 0, st_w0 = 0, st_r0 = 0; unsigned st_c0 = 0, st_c1 = 0, st_c2 = 0, st_c3 = 0;
+#define FSK_STAMP_COUNT(i) st_c##i += 1u;
+#define FSK_STAMP_BEGIN st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime();
 #define FSK_STAMP_W0 st_w0 = __builtin_amdgcn_s_memtime();
 #define FSK_STAMP_W1 st_wait += __builtin_amdgcn_s_memtime() - st_w0;
 #define FSK_STAMP_END(w)                                                               \
   if (blockIdx.x < 2048 && lane == 0) {                                                \
-    g_stamp[((w) * 2048 + blockIdx.x) * 2] = st_wait;                                  \
-    g_stamp[((w) * 2048 + blockIdx.x) * 2 + 1] = __builtin_amdgcn_s_memtime() - st_t0; \
+    g_stamp[((w) * 2048 + blockIdx.x) * 8] = st_wait;                                  \
+    g_stamp[((w) * 2048 + blockIdx.x) * 8 + 1] = __builtin_amdgcn_s_memtime() - st_t0; \
+    g_stamp[((w) * 2048 + blockIdx.x) * 8 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)(__builtin_amdgcn_s_getreg(0x1814) & 7u) << 32); \
+    g_stamp[((w) * 2048 + blockIdx.x) * 8 + 3] = st_c0; g_stamp[((w) * 2048 + blockIdx.x) * 8 + 4] = st_c1; \
+    g_stamp[((w) * 2048 + blockIdx.x) * 8 + 5] = st_c2; g_stamp[((w) * 2048 + blockIdx.x) * 8 + 6] = st_c3; \
+    g_stamp[((w) * 2048 + blockIdx.x) * 8 + 7] = st_r0;                                \
   }
 #else
 #define FSK_STAMP_DECL
+#define FSK_STAMP_COUNT(i)
 #define FSK_STAMP_BEGIN
 #define FSK_STAMP_W0
 #define FSK_STAMP_W1
@@ -209,6 +215,8 @@ struct BackU {                   // wave-uniform context of one decimated sample
   uint32_t direct;               // decimated samples for which some lane still runs the direct instance (after a reset)
   uint32_t zlive;                // some lane carries a non-zero correction (or runs the direct instance)
   uint32_t *zmail;               // LDS [64]: decimated-sample index of this launch before which the front zeroes the lane's filters
+  uint32_t *cmail;               // LDS [6][64] or null (fsk_blk.hip): hand-over of the ZIR correction to the discriminator wave
+                                 // ([0] from which sample, [1..4] its value there), [5] the sample this wave's own span began at
   uint64_t free0;                // free-running frame: NCO phase (turns * 2^64) at the first sample of the launch
 };
 
@@ -230,6 +238,10 @@ __device__ inline void back_reset(BackLane &B, const DemodParams &P, const FastM
   }
   B.dph = 0;
   X.zmail[lane] = X.k + kZeroLagPairs;   // the next decimated sample is number X.k of this launch (0-based)
+  if (X.cmail) {
+    X.cmail[lane] = 0xFFFFFFFFu;               // a hand-over posted for an earlier reset is void
+    X.cmail[320u + lane] = X.k;                // from this sample on the pair sums themselves are wanted, not their phase
+  }
   B.dix1 = B.dix2 = B.diy = B.dvi = 0.f;
   B.dqx1 = B.dqx2 = B.dqy = B.dqv = 0.f;
   B.px1 = B.px2 = B.py = B.pv = 0.f;
@@ -289,7 +301,9 @@ __device__ inline float disc_post(BackLane &B, const BackK &K, float ph, float &
 // same function, same inputs where nothing changed, so the result does not depend on which wave computed it.
 // TRC: honour fskhip_trace_enable and fskhip_enable_signal_quality (the sample-granular kernel only; an engine with
 // either switched on runs entirely on it).
-template <bool UNI, bool PA = false, bool TRC = false>
+// HAND (fsk_blk.hip's back wave): the correction belongs to this wave only while zr_dph < kHandPairs; after that the
+// discriminator wave applies it and ph_u / amp_u already are the corrected pair sum's.
+template <bool UNI, bool PA = false, bool TRC = false, bool HAND = false>
 __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams &P, const DemodState &S, const FastMem &M,
                                  uint32_t *pslot, uint32_t lane, __amdgpu_buffer_rsrc_t amp_rsrc, uint8_t *out,
                                  uint32_t out_pitch, uint32_t *eod_counts, BackU &X, float Ui, float Uq,
@@ -303,6 +317,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   if (PA) { ph = ph_u; amp = amp_u; }
   else ph = atan2_amp_fma(Uq, Ui, amp, K.tiny, K.sgn);
   if (__builtin_expect(X.zlive != 0u, 0)) {
+    const uint32_t dph0 = B.dph;
     float wi = Ui - B.qai, wq = Uq - B.qaq;
     {
       const float ni = __builtin_fmaf(K.c1, B.qbi, -(K.c2 * B.qai));
@@ -348,22 +363,48 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
           B.qaq = __builtin_fmaf(K.c1, q1q, -(K.c2 * B.q0q));
           B.qbi = __builtin_fmaf(K.c1, B.qai, -(K.c2 * q1i));
           B.qbq = __builtin_fmaf(K.c1, B.qaq, -(K.c2 * q1q));
+          if (HAND) {
+            // the correction stays here for the next kHandLag decimated samples (numbers X.k .. X.k + kHandLag - 1 of this
+            // launch) and then moves to the discriminator wave: post what the recurrence makes of it by then
+            float ai = B.qai, aq = B.qaq, bi = B.qbi, bq = B.qbq;
+            for (uint32_t g = 0; g < kHandLag; g++) {
+              const float ni = __builtin_fmaf(K.c1, bi, -(K.c2 * ai)), nq = __builtin_fmaf(K.c1, bq, -(K.c2 * aq));
+              ai = bi; aq = bq; bi = ni; bq = nq;
+            }
+            X.cmail[64u + lane] = __builtin_bit_cast(uint32_t, ai); X.cmail[128u + lane] = __builtin_bit_cast(uint32_t, aq);
+            X.cmail[192u + lane] = __builtin_bit_cast(uint32_t, bi); X.cmail[256u + lane] = __builtin_bit_cast(uint32_t, bq);
+            X.cmail[lane] = X.k + kHandLag;
+          }
         }
         B.dph += 1u;
       }
     }
-    {
+    if (dph0 >= kDirectPairs && dph0 < kHandPairs) {          // the un-retired span after the direct instance
+      B.dph = dph0 + 1u;
+      if (HAND && B.dph == kHandPairs) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }   // handed over
+    }
+    if (HAND) {
+      // lanes whose correction (or direct instance) is this wave's own evaluate the discriminator here; the others keep
+      // the discriminator wave's result, which already carries their correction
+      const bool own = dph0 < kHandPairs;
+      if (__builtin_amdgcn_ballot_w64(own)) {
+        float a2;
+        const float p2 = atan2_amp_fma(wq, wi, a2, K.tiny, K.sgn);
+        ph = own ? p2 : ph; amp = own ? a2 : amp;
+      }
+      X.zlive = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(B.dph < kHandPairs) != 0));
+    } else {
       const uint32_t changed = (__builtin_bit_cast(uint32_t, wi) ^ __builtin_bit_cast(uint32_t, Ui)) |
                                (__builtin_bit_cast(uint32_t, wq) ^ __builtin_bit_cast(uint32_t, Uq));
       if (__builtin_amdgcn_ballot_w64(changed != 0u)) ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
     }
-    {
+    if (!HAND) {
       // a correction that has decayed below 2^-28 of the magnitude it corrects is retired to exactly zero (both decay at
       // the low-pass's own rate at least, so it stays negligible; a rule of the stream's own values only, so every kernel
       // and every chunking retires it at the same decimated sample)
       const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(B.qai), __builtin_fabsf(B.qaq)),
                                         __builtin_fmaxf(__builtin_fabsf(B.qbi), __builtin_fabsf(B.qbq)));
-      const bool steady = B.dph >= kDirectPairs;
+      const bool steady = dph0 >= kHandPairs;                       // (from the sample on that the discriminator wave would own it)
       const bool small = !(big > amp * 3.7252902984619141e-09f);   // (<=: a zero correction under the bare (0, 0) guard retires too)
       if (steady & small) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }
       X.zlive = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(!steady | !small) != 0));
