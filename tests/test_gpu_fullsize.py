@@ -180,7 +180,7 @@ def test_whole_tile_kernels_agree_on_ragged_batches(S, monkeypatch):
     gen.synchronize()
     digests = {}
     for name, env in (("split", {"FSKHIP_SPLIT": "1"}), ("one_wave", {"FSKHIP_SPLIT": "0"}), ("three_wave", {"FSKHIP_SPLIT": "3"}),
-                      ("generic", {"FSKHIP_FORCE_GENERIC": "1"})):
+                      ("four_wave", {"FSKHIP_SPLIT": "4"}), ("generic", {"FSKHIP_FORCE_GENERIC": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
@@ -189,13 +189,13 @@ def test_whole_tile_kernels_agree_on_ragged_batches(S, monkeypatch):
         rows, eod = _demod_schedule(eng, d_x, N, N, [4096, 16, 1000, 48, 20000])
         digests[name] = (_digest(rows, eod), sum(len(r) for r in rows))
         eng.close()
-    assert digests["split"] == digests["one_wave"] == digests["three_wave"] == digests["generic"], digests
+    assert digests["split"] == digests["one_wave"] == digests["three_wave"] == digests["four_wave"] == digests["generic"], digests
     assert digests["split"][1] >= 12 * S * 0.5
     gen.device_free(d_x)
     gen.close()
 
 
-@pytest.mark.parametrize("split", ["0", "1", "3"])
+@pytest.mark.parametrize("split", ["0", "1", "3", "4"])
 def test_partial_wave_lanes_stay_out_of_rare_paths(split, monkeypatch):
     """Regression (found by tools/soak.py): one stream in a 64-lane wave, lowered syncThreshold, a chunk schedule that
     hands a synced state to the whole-tile kernels.  The 63 lanes beyond the batch used to reach the sync path, whose
@@ -241,7 +241,10 @@ def test_config2_v21_300_baud_batch(monkeypatch):
     results = {}
     for name, env, schedule in (("pipe_one_call", {"FSKHIP_SPLIT": "1"}, [N]), ("pipe_quanta", {"FSKHIP_SPLIT": "1"}, [128]),
                                 ("pipe3_one_call", {"FSKHIP_SPLIT": "3"}, [N]), ("pipe3_ragged", {"FSKHIP_SPLIT": "3"}, [4096, 19, 128, 48000, 7]),
-                                ("fused_ragged", {"FSKHIP_SPLIT": "0"}, [30000, 17, 4096, 3, 128, 2049])):
+                                ("fused_ragged", {"FSKHIP_SPLIT": "0"}, [30000, 17, 4096, 3, 128, 2049]),
+                                ("blk_one_call", {"FSKHIP_SPLIT": "4"}, [N]), ("blk_quanta", {"FSKHIP_SPLIT": "4"}, [128]),
+                                ("blk_ragged", {"FSKHIP_SPLIT": "4"}, [4096, 19, 128, 48000, 7, 30000, 17, 3, 2049]),
+                                ("auto_ragged", {}, [16, 4096, 21, 128, 48000, 5, 1024])):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = wm.FSKEngine(S, V21, precision=wm.PRECISION_F32)
@@ -250,6 +253,8 @@ def test_config2_v21_300_baud_batch(monkeypatch):
         results[name] = _demod_schedule(eng, d_x, N, N, schedule)
         if name == "pipe_one_call":
             assert "demod_pipe_kernel" in eng.last_kernel()
+        if name == "blk_one_call":
+            assert "demod_blk_kernel" in eng.last_kernel()
         eng.close()
     base = _digest(*results["pipe_one_call"])
     for name, r in results.items():
@@ -284,7 +289,7 @@ def test_config3_full_length_480000_samples():
     gen.synchronize()
     eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
     rows, eod = _demod_schedule(eng, d_x, N, N, [N])
-    assert "demod_pipe_kernel" in eng.last_kernel()
+    assert "demod_blk_kernel" in eng.last_kernel()
     eng.close()
     eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
     rows2, eod2 = _demod_schedule(eng, d_x, N, N, [48000])

@@ -34,10 +34,11 @@ def _check_status(st, ref, tol, agc_gain):
         assert st["agcGain"] == pytest.approx(agc_gain, rel=max(tol, 1e-12) * 10)
 
 
-# the fp32 path has three kernels for whole tiles: one wave per 64 streams (large batches), two waves (fewer than two
-# waves per SIMD) and three waves per group (at most two groups per CU, i.e. every small test).  FSKHIP_SPLIT pins one of
-# them at engine creation.
-GOLDEN_VARIANTS = PRECISIONS + [("f32-one-wave", 0, 1e-5), ("f32-three-wave", 0, 1e-5)]
+# the fp32 path has four kernels for whole tiles: four waves per 64 streams with a block-batched back wave (round 3, the
+# default wherever dsSPB is a multiple of 4), and the round-2 kernels with one, two and three waves per group, which stay
+# for the other configurations and as the per-sample reference of the block path.  FSKHIP_SPLIT pins one of them at
+# engine creation.
+GOLDEN_VARIANTS = PRECISIONS + [("f32-one-wave", 0, 1e-5), ("f32-three-wave", 0, 1e-5), ("f32-four-wave", 0, 1e-5)]
 
 
 @pytest.mark.parametrize("pname,prec,tol", GOLDEN_VARIANTS)
@@ -48,6 +49,8 @@ def test_demod_matches_reference_golden(name, pname, prec, tol, monkeypatch):
         monkeypatch.setenv("FSKHIP_SPLIT", "0")
     elif pname == "f32-three-wave":
         monkeypatch.setenv("FSKHIP_SPLIT", "3")
+    elif pname == "f32-four-wave":
+        monkeypatch.setenv("FSKHIP_SPLIT", "4")
     elif pname == "f32":
         monkeypatch.setenv("FSKHIP_SPLIT", "1")
     g = golden()

@@ -76,7 +76,7 @@ def main(budget=None, seed=None, max_rounds=None):
         if target and os.environ.get("SOAK_FORCE_PREC"):
             prec = int(os.environ["SOAK_FORCE_PREC"])
         S = int(rng.choice([1, 2, 63, 64, 65, 100, 130, 192, 257]))
-        os.environ["FSKHIP_SPLIT"] = "013"[int(rng.integers(3))]   # one / two / three waves per 64-stream group
+        os.environ["FSKHIP_SPLIT"] = "0134"[int(rng.integers(4))]   # one / two / three / four waves per 64-stream group
         if target and os.environ.get("SOAK_FORCE_SPLIT"):
             os.environ["FSKHIP_SPLIT"] = os.environ["SOAK_FORCE_SPLIT"]
         os.environ["FSKHIP_SPLIT_LAST"] = os.environ["FSKHIP_SPLIT"]

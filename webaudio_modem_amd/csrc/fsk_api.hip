@@ -170,7 +170,9 @@ struct fskhip_engine {
   uint32_t split_cus = 256;
   bool split_forced = false;     // FSKHIP_SPLIT was set: skip the residency check too
   bool use_split3 = false;       // three waves per group (demod_pipe3_kernel): at most two groups per CU
-  bool use_blk = false;         // three waves per group with the block-batched back wave (demod_blk_kernel, fsk_blk.hip)
+  bool use_blk = true;          // four waves per group with the block-batched back wave (demod_blk_kernel, fsk_blk.hip): the default
+                                 // wherever it applies (dsSPB a multiple of 4, >= 8); FSKHIP_SPLIT = 0 / 1 / 3 pins an older kernel
+  uint64_t pushes = 0;           // decimated samples since create (lock-step engines): the amplitude ring's write position
   bool gen_odd = false;          // fp32: the last generic-kernel launch left a decimator pair open (its partial sums are in
                                  // the reference's frame, the whole-tile kernels' in the free-running one)
   const char *last_kernel = "";  // what the last fskhip_demodulate_device call launched for its whole tiles
@@ -356,6 +358,7 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     if (const char *sp = getenv("FSKHIP_SPLIT")) {    // tests / measurements: 0 = one wave, 1 = two, 3 = three per group, 4 = three with the block back
       e->use_split = sp[0] == '1' || sp[0] == '3' || sp[0] == '4'; e->use_split3 = sp[0] == '3'; e->use_blk = sp[0] == '4';
       e->split_forced = true;
+      if (sp[0] == 'a') { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < (uint32_t)cus * 8u; }   // 'auto' spelled out
     }
   }
 
@@ -680,7 +683,10 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
       if (n_fast) {
         const size_t pipe3_lds = demod_pipe3_lds_bytes(e->P);
         const size_t blk_lds = demod_blk_lds_bytes(e->P);
-        if (e->use_blk && demod_blk_applicable(e->P) && blk_lds <= 160 * 1024 && (wgs_per_cu * blk_lds <= 160 * 1024 || e->split_forced)) {
+        // the block kernel stores amplitudes a quad at a time: the ring's write position at its first sample must be a
+        // multiple of four (it is unless earlier calls had odd lengths: those calls then stay with the per-sample kernels)
+        const bool quad_aligned = ((e->pushes + ((p0 + head) >> 1)) & 3u) == 0u;
+        if (e->use_blk && demod_blk_applicable(e->P) && blk_lds <= 160 * 1024 && (quad_aligned || e->split_forced)) {
           HIP_TRY(launch_demod_blk(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
           e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_blk_kernel<true, true>" : "fsk::demod_blk_kernel<true, false>")
                               : (e->P.uni_cfg ? "fsk::demod_blk_kernel<false, true>" : "fsk::demod_blk_kernel<false, false>");
@@ -717,6 +723,7 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
   }
   e->calls += count_call ? 1 : 0;
   e->total_samples += n;
+  e->pushes += (e->ds_parity + n) >> 1;
   e->ds_parity = (e->ds_parity + (uint32_t)(n & 1)) & 1u;
   return FSKHIP_OK;
 }

@@ -41,7 +41,7 @@
 //
 // Which wave plays which part follows the SIMD it landed on, rotated by the workgroups the CU has started, so that every
 // SIMD hosts one wave of each part (see the kernel).
-// LDS: stage [4][65] v4f | yring [6][2][64] v4f | xring [6][2][64] v4f | fin [3][64] v4f | zt [2][8] v4f |
+// LDS: stage [4][65] v4f | yring [6][2][64] v4f | xring [6][2][64] v4f | fin [3][64] v4f | zt [4][8] v4f |
 //      poly [64][PS] u32 | counters [8] | zmail [64] u32 | cmail [6][64] u32
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -53,8 +53,12 @@
 
 namespace fsk {
 
-static constexpr uint32_t kBlkSlots = 6;           // half tiles in the rings
+#ifndef FSK_BLK_SLOTS
+#define FSK_BLK_SLOTS 6
+#endif
+static constexpr uint32_t kBlkSlots = FSK_BLK_SLOTS;   // half tiles in the rings
 static_assert(4u * kBlkSlots <= kZeroLagPairs, "the wave that owns the I/Q low-pass must learn of a reset before it has passed the zeroing point");
+static_assert(4u * kBlkSlots <= kHandLag, "the discriminator wave (up to 4 * kBlkSlots - 1 samples beyond the start of the back wave's tile) must not have reached the hand-over sample when it is posted");
 static constexpr uint32_t kBlkSlotV4 = 2 * 64;     // v4f per x-ring slot: four pair sums (I, Q) -- in place -> four (phase, magnitude)
 static constexpr uint32_t kFlushBlocks = 16;       // byte queues are flushed every this many blocks
 
@@ -142,6 +146,27 @@ __device__ inline void blk_flush(BackLane &B, uint32_t &bq, uint32_t &nq, const 
 // The discriminator wave's share of the ZIR correction (see back_pair for the arithmetic it restates op for op):
 // w = U - q, q advances by its recurrence and retires to exactly zero once below 2^-28 of the magnitude it corrects.
 struct QLane { float ai, aq, bi, bq; };
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+// Time-sliced priority.  With equal priorities a SIMD issues from its OLDEST wave first: the four groups sharing a CU then
+// finish one after the other (185 .. 284 cycles per sample, profiles/r03_blk4_stamps.txt), the last one largely alone
+// and at a single group's latency-bound pace.  Rotating four priority levels over the CU's workgroups every 64 half
+// tiles gives each group every level a quarter of the time.  (s_setprio takes an immediate.)
+#ifndef FSK_BLK_PRIO
+#define FSK_BLK_PRIO 1
+#endif
+__device__ inline void blk_prio(uint32_t hidx, uint32_t wgj) {
+#if FSK_BLK_PRIO
+  if ((hidx & 63u) == 0u) {
+    switch (((hidx >> 6) + wgj) & 3u) {
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
+  }
+#endif
+}
 
 template <bool WB, bool UNI>
 __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
@@ -157,7 +182,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
   v4f *ring = yring + kBlkSlots * 2 * 64;                 // wave 1: pair sums U -> wave 2: (phase, magnitude) IN PLACE -> wave 3
   v4f *fin = ring + kBlkSlots * kBlkSlotV4;               // [0..1] wave 1's final I/Q low-pass state, [2] wave 2's final correction
   v4f *zt = fin + 3 * 64;
-  uint32_t *poly = reinterpret_cast<uint32_t *>(zt + 2 * 8);   // [lane][PS], index 0 = the phase of the launch's first push
+  uint32_t *poly = reinterpret_cast<uint32_t *>(zt + 4 * 8);   // [lane][PS], index 0 = the phase of the launch's first push
   uint32_t *ctr = poly + 64u * PS;                        // produced by wave 0, 1, 2 | consumed by wave 3
   uint32_t *zmail = ctr + 8;                              // back -> wave 1: where to zero a lane's I/Q low-pass
   uint32_t *cmail = zmail + 64;                           // back -> wave 2: [0] from which decimated sample, [1..4] the correction there,
@@ -216,6 +241,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
   __syncthreads();
   const uint32_t simd = (__builtin_amdgcn_s_getreg(0xF804) >> 4) & 3u;
   const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)((simd + ctr[4]) & 3u));
+  const uint32_t wgj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ctr[4] & 3u));
 
   if (role == 0) {
     // ------------------------------------------------------------------------------ loads, AGC, pre-filter
@@ -251,22 +277,35 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
                  "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
     uint32_t consumed = 0, slot_i = 0;
+    // NCO phasors of the free-running frame (uniform configuration): lane j & 15 evaluates sample j of the tile from the
+    // exact accumulator (v_cos / v_sin take turns), the sixteen (cos, sin) pairs go to the tile's zt slot and wave 1 reads
+    // them back as broadcasts.  (They are this wave's work because it has the slack: profiles/r03_blk4_stamps.txt.)
+    uint64_t zacc = free0 + inc * (uint64_t)(lane & 15u);
+    const uint64_t inc16 = inc * 16u;
     auto do_tile = [&](uint32_t t, v4f &r0, v4f &r1, v4f &r2, v4f &r3) {
       if (WB) asm volatile("s_waitcnt vmcnt(16)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
       else asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
       stage[st_slot] = r0; stage[st_slot + 16] = r1; stage[st_slot + 32] = r2; stage[st_slot + 48] = r3;
       load_tile((size_t)t + 3, r0, r1, r2, r3);
-#pragma unroll 1
-      for (uint32_t hf = 0; hf < 2; hf++) {
-        const uint32_t hidx = 2u * t + hf;
-        if (hidx - consumed >= kBlkSlots) {
-          FSK_STAMP_W0
-          while (hidx - consumed >= kBlkSlots) {           // ring full: the back wave (which may still need the slot's
-            consumed = lds_peek(&ctr[3]);                   // pre-filter outputs after a reset) has not released it
-            if (hidx - consumed >= kBlkSlots) __builtin_amdgcn_s_sleep(1);
-          }
-          FSK_STAMP_W1
+      const uint32_t hidx = 2u * t;
+      v4u32 cv;
+      lds_peek4_begin(ctr, cv);                             // (read now, looked at after the tile: see lds_peek4_begin)
+      if (hidx + 1u - consumed >= kBlkSlots) {              // both of the tile's slots must be free
+        FSK_STAMP_W0
+        while (hidx + 1u - consumed >= kBlkSlots) {         // ring full: the back wave (which may still need the slots'
+          consumed = lds_peek(&ctr[3]);                     // pre-filter outputs after a reset) has not released them
+          if (hidx + 1u - consumed >= kBlkSlots) __builtin_amdgcn_s_sleep(1);
         }
+        FSK_STAMP_W1
+      }
+      if (UNI) {
+        float pc, ps;
+        nco_phasor(zacc, pc, ps);
+        reinterpret_cast<f2 *>(zt + (t & 3u) * 8u)[lane & 15u] = (f2){pc, ps};
+        zacc += inc16;
+      }
+#pragma unroll
+      for (uint32_t hf = 0; hf < 2; hf++) {
         v4f *slot = yring + slot_i * 2u * 64u;
         slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
 #pragma unroll
@@ -283,15 +322,20 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
               *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + (size_t)t * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
           }
         }
-        lds_post(&ctr[0], hidx + 1u);
+        lds_post(&ctr[0], hidx + hf + 1u);
       }
+      consumed = lds_peek4_get(cv, 3);
     };
     const uint32_t nt = (uint32_t)n_tiles;
     FSK_STAMP_BEGIN
-    for (uint32_t t = 0; t < nt; t += 3) {
-      do_tile(t, a0, a1, a2, a3);
-      if (t + 1 < nt) do_tile(t + 1, b0, b1, b2, b3);
-      if (t + 2 < nt) do_tile(t + 2, c0, c1, c2, c3);
+    for (uint32_t t0 = 0; t0 < nt; t0 += 96u) {             // (a multiple of three tiles and of 64 half tiles)
+      blk_prio(2u * t0, wgj);
+      const uint32_t te = t0 + 96u < nt ? t0 + 96u : nt;
+      for (uint32_t t = t0; t < te; t += 3) {
+        do_tile(t, a0, a1, a2, a3);
+        if (t + 1 < te) do_tile(t + 1, b0, b1, b2, b3);
+        if (t + 2 < te) do_tile(t + 2, c0, c1, c2, c3);
+      }
     }
     FSK_STAMP_END(0)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
@@ -315,27 +359,14 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
       const uint32_t fld = C.fld, row4 = C.row4;
       wre = (float)PIPE_CLOAD(CF_w1_re); wim = (float)PIPE_CLOAD(CF_w1_im);
     }
-    uint64_t zacc = free0 + inc * (uint64_t)(lane & 15u);
     uint64_t tacc = free0;
     const uint64_t inc16 = inc * 16u;
     uint32_t consumed = 0, produced = 0, slot_i = 0;
     float zr = 1.f, zi = 0.f;
-    const v4f *ztile = zt;
     FSK_STAMP_BEGIN
-    for (uint32_t hidx = 0; hidx < nh; hidx++) {
-      if (!(hidx & 1u)) {                                     // a new tile: its sixteen NCO phasors (see demod_pipe_kernel)
-        const uint32_t t = hidx >> 1;
-        ztile = zt + (t & 1u) * 8u;
-        if (UNI) {
-          float pc, ps;
-          nco_phasor(zacc, pc, ps);
-          reinterpret_cast<f2 *>(zt + (t & 1u) * 8u)[lane & 15u] = (f2){pc, ps};
-          zacc += inc16;
-        } else {
-          nco_phasor(tacc, zr, zi);
-          tacc += inc16;
-        }
-      }
+    uint32_t hidx = 0;
+    while (hidx < nh) {
+      if ((hidx & 63u) == 0u) blk_prio(hidx, wgj);
       if (produced <= hidx || hidx - consumed >= kBlkSlots) {
         FSK_STAMP_W0
         while (produced <= hidx) {                            // wave 0's half tile
@@ -348,48 +379,67 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         }
         FSK_STAMP_W1
       }
-      const v4f *yslot = yring + slot_i * 2u * 64u;
-      v4f *slot = ring + slot_i * kBlkSlotV4;
-      slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
-      const uint32_t zj = zmail[lane];
-      const uint64_t zh = __builtin_amdgcn_ballot_w64(zj - 4u * hidx < 4u);
-#pragma unroll
-      for (uint32_t cc = 0; cc < 2; cc++) {
-        const uint32_t c = 2u * (hidx & 1u) + cc;
-        const v4f y4 = yslot[cc * 64u + lane];
-        const uint32_t pb = 4u * hidx + 2u * cc;
-        float zc[4], zs[4];
-        if (UNI) {
-          const v4f z01 = ztile[c * 2u], z23 = ztile[c * 2u + 1u];
-          zc[0] = z01.x; zs[0] = z01.y; zc[1] = z01.z; zs[1] = z01.w;
-          zc[2] = z23.x; zs[2] = z23.y; zc[3] = z23.z; zs[3] = z23.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            zc[j] = zr; zs[j] = zi;
-            const float nr = __builtin_fmaf(-zi, wim, zr * wre), ni = __builtin_fmaf(zi, wre, zr * wim);
-            zr = nr; zi = ni;
-          }
+      // as far as the rings allow, up to the next priority point: the back edge is the loop's only branch besides the
+      // (rare) zeroing of a lane's filters
+      uint32_t lim0 = (hidx | 63u) + 1u;
+      lim0 = lim0 < nh ? lim0 : nh;
+      uint32_t lim = lim0 < produced ? lim0 : produced;
+      lim = lim < consumed + kBlkSlots ? lim : consumed + kBlkSlots;
+      do {
+        v4u32 cv;
+        lds_peek4_begin(ctr, cv);
+        const v4f *ztile = zt + ((hidx >> 1) & 3u) * 8u;
+        if (!UNI && !(hidx & 1u)) {                           // per-stream tones: the tile's first phasor from the exact accumulator
+          nco_phasor(tacc, zr, zi);
+          tacc += inc16;
         }
-        const float y[4] = {y4.x, y4.y, y4.z, y4.w};
-        float oi[4], oq[4];
-        if (FSK_ABL(1)) {
+        const v4f *yslot = yring + slot_i * 2u * 64u;
+        v4f *slot = ring + slot_i * kBlkSlotV4;
+        slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
+        const uint32_t zj = zmail[lane];
+        const uint64_t zh = __builtin_amdgcn_ballot_w64(zj - 4u * hidx < 4u);
 #pragma unroll
-          for (int j = 0; j < 4; j++) oi[j] = oq[j] = y[j] + zc[j];
-        } else if (__builtin_expect(zh != 0ull, 0)) {
-          asm volatile("s_nop 0");
+        for (uint32_t cc = 0; cc < 2; cc++) {
+          const uint32_t c = 2u * (hidx & 1u) + cc;
+          const v4f y4 = yslot[cc * 64u + lane];
+          const uint32_t pb = 4u * hidx + 2u * cc;
+          float zc[4], zs[4];
+          if (UNI) {
+            const v4f z01 = ztile[c * 2u], z23 = ztile[c * 2u + 1u];
+            zc[0] = z01.x; zs[0] = z01.y; zc[1] = z01.z; zs[1] = z01.w;
+            zc[2] = z23.x; zs[2] = z23.y; zc[3] = z23.z; zs[3] = z23.w;
+          } else {
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (!(j & 1)) front_zero(F, zj == pb + (uint32_t)(j >> 1));
-            front_mix_lp(F, K, y[j], zc[j], zs[j], oi[j], oq[j]);
+            for (int j = 0; j < 4; j++) {
+              zc[j] = zr; zs[j] = zi;
+              const float nr = __builtin_fmaf(-zi, wim, zr * wre), ni = __builtin_fmaf(zi, wre, zr * wim);
+              zr = nr; zi = ni;
+            }
           }
-        } else {
+          const float y[4] = {y4.x, y4.y, y4.z, y4.w};
+          float oi[4], oq[4];
+          if (FSK_ABL(1)) {
 #pragma unroll
-          for (int j = 0; j < 4; j++) front_mix_lp(F, K, y[j], zc[j], zs[j], oi[j], oq[j]);
+            for (int j = 0; j < 4; j++) oi[j] = oq[j] = y[j] + zc[j];
+          } else if (__builtin_expect(zh != 0ull, 0)) {
+            asm volatile("s_nop 0");
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (!(j & 1)) front_zero(F, zj == pb + (uint32_t)(j >> 1));
+              front_mix_lp(F, K, y[j], zc[j], zs[j], oi[j], oq[j]);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) front_mix_lp(F, K, y[j], zc[j], zs[j], oi[j], oq[j]);
+          }
+          slot[cc * 64u + lane] = (v4f){oi[0] + oi[1], oq[0] + oq[1], oi[2] + oi[3], oq[2] + oq[3]};   // U (I, Q) x 2
         }
-        slot[cc * 64u + lane] = (v4f){oi[0] + oi[1], oq[0] + oq[1], oi[2] + oi[3], oq[2] + oq[3]};   // U (I, Q) x 2
-      }
-      lds_post(&ctr[1], hidx + 1u);                           // for the discriminator wave
+        hidx++;
+        lds_post(&ctr[1], hidx);                              // for the discriminator wave
+        produced = lds_peek4_get(cv, 0); consumed = lds_peek4_get(cv, 3);
+        lim = lim0 < produced ? lim0 : produced;
+        lim = lim < consumed + kBlkSlots ? lim : consumed + kBlkSlots;
+      } while (hidx < lim);
     }
     FSK_STAMP_END(1)
     fin[lane] = (v4f){F.ix1, F.ix2, F.iy, F.iv};
@@ -410,7 +460,9 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     uint32_t qlive = __builtin_amdgcn_ballot_w64((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f)) ? 1u : 0u;
     uint32_t produced = 0, slot_i = 0;
     FSK_STAMP_BEGIN
-    for (uint32_t hidx = 0; hidx < nh; hidx++) {
+    uint32_t hidx = 0;
+    while (hidx < nh) {
+      if ((hidx & 63u) == 0u) blk_prio(hidx, wgj);
       if (produced <= hidx) {
         FSK_STAMP_W0
         while (produced <= hidx) {
@@ -419,54 +471,57 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         }
         FSK_STAMP_W1
       }
-      v4f *slot = ring + slot_i * kBlkSlotV4;
-      slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
-      const v4f ua = slot[lane], ub = slot[64u + lane];
-      const uint32_t kq = cmail[lane];
-      const uint32_t ow = 4u * hidx - cmail[320u + lane];       // decimated samples since the back wave's own span began
-      const uint32_t hit = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(kq - 4u * hidx < 4u) != 0));
-      const uint32_t anyown = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(ow < kHandPairs) != 0));
-      const float ui[4] = {ua.x, ua.z, ub.x, ub.z}, uq[4] = {ua.y, ua.w, ub.y, ub.w};
-      float ph[4], am[4];
-      if (__builtin_expect((qlive | hit) != 0u, 0)) {
+      uint32_t lim0 = (hidx | 63u) + 1u;
+      lim0 = lim0 < nh ? lim0 : nh;
+      uint32_t lim = lim0 < produced ? lim0 : produced;
+      do {
+        v4u32 cv;
+        lds_peek4_begin(ctr, cv);
+        v4f *slot = ring + slot_i * kBlkSlotV4;
+        slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
+        const v4f ua = slot[lane], ub = slot[64u + lane];
+        const uint32_t kq = cmail[lane];
+        const uint32_t ow = 4u * hidx - cmail[320u + lane];     // decimated samples since the back wave's own span began
+        const float ui[4] = {ua.x, ua.z, ub.x, ub.z}, uq[4] = {ua.y, ua.w, ub.y, ub.w};
+        float ph[4], am[4];
+        // one test for everything that is not the plain discriminator: a hand-over due in this half tile, a lane inside
+        // the back wave's own span, a live correction
+        if (__builtin_expect((__builtin_amdgcn_ballot_w64((kq - 4u * hidx < 4u) | (ow < kHandPairs)) != 0) | (qlive != 0u), 0)) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (hit) {
+          for (int j = 0; j < 4; j++) {
             if (kq == 4u * hidx + (uint32_t)j) {              // the back wave's correction becomes this wave's here
               Qz.ai = __builtin_bit_cast(float, cmail[64u + lane]); Qz.aq = __builtin_bit_cast(float, cmail[128u + lane]);
               Qz.bi = __builtin_bit_cast(float, cmail[192u + lane]); Qz.bq = __builtin_bit_cast(float, cmail[256u + lane]);
             }
+            const float wi = ui[j] - Qz.ai, wq = uq[j] - Qz.aq;
+            {
+              const float ni = __builtin_fmaf(c1, Qz.bi, -(c2 * Qz.ai)), nq = __builtin_fmaf(c1, Qz.bq, -(c2 * Qz.aq));
+              Qz.ai = Qz.bi; Qz.aq = Qz.bq; Qz.bi = ni; Qz.bq = nq;
+            }
+            ph[j] = atan2_amp_fma(wq, wi, am[j], tiny, sgn);
+            const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(Qz.ai), __builtin_fabsf(Qz.aq)),
+                                              __builtin_fmaxf(__builtin_fabsf(Qz.bi), __builtin_fabsf(Qz.bq)));
+            if (!(big > am[j] * rel)) { Qz.ai = 0.f; Qz.aq = 0.f; Qz.bi = 0.f; Qz.bq = 0.f; }
+            // lanes inside the back wave's own span (direct instance, then its own correction): it evaluates their
+            // discriminator itself and needs the pair sums for that, so they stay
+            const bool own = ow + (uint32_t)j < kHandPairs;
+            ph[j] = own ? ui[j] : ph[j]; am[j] = own ? uq[j] : am[j];
           }
-          const float wi = ui[j] - Qz.ai, wq = uq[j] - Qz.aq;
-          {
-            const float ni = __builtin_fmaf(c1, Qz.bi, -(c2 * Qz.ai)), nq = __builtin_fmaf(c1, Qz.bq, -(c2 * Qz.aq));
-            Qz.ai = Qz.bi; Qz.aq = Qz.bq; Qz.bi = ni; Qz.bq = nq;
-          }
-          ph[j] = atan2_amp_fma(wq, wi, am[j], tiny, sgn);
-          const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(Qz.ai), __builtin_fabsf(Qz.aq)),
-                                            __builtin_fmaxf(__builtin_fabsf(Qz.bi), __builtin_fabsf(Qz.bq)));
-          if (!(big > am[j] * rel)) { Qz.ai = 0.f; Qz.aq = 0.f; Qz.bi = 0.f; Qz.bq = 0.f; }
+          qlive = __builtin_amdgcn_ballot_w64((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f)) ? 1u : 0u;
+        } else if (FSK_ABL(2)) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { ph[j] = ui[j]; am[j] = uq[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) ph[j] = atan2_amp_fma(uq[j], ui[j], am[j], tiny, sgn);
         }
-        qlive = __builtin_amdgcn_ballot_w64((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f)) ? 1u : 0u;
-      } else if (FSK_ABL(2)) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) { ph[j] = ui[j]; am[j] = uq[j]; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) ph[j] = atan2_amp_fma(uq[j], ui[j], am[j], tiny, sgn);
-      }
-      if (__builtin_expect(anyown != 0u, 0)) {
-        // lanes inside the back wave's own span (direct instance, then its own correction): it evaluates their
-        // discriminator itself and needs the pair sums for that, so they stay
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const bool own = ow + (uint32_t)j < kHandPairs;
-          ph[j] = own ? ui[j] : ph[j]; am[j] = own ? uq[j] : am[j];
-        }
-      }
-      slot[lane] = (v4f){ph[0], am[0], ph[1], am[1]};         // in place: wave 1 will not touch the slot before the back wave frees it
-      slot[64u + lane] = (v4f){ph[2], am[2], ph[3], am[3]};
-      lds_post(&ctr[2], hidx + 1u);
+        slot[lane] = (v4f){ph[0], am[0], ph[1], am[1]};       // in place: wave 1 will not touch the slot before the back wave frees it
+        slot[64u + lane] = (v4f){ph[2], am[2], ph[3], am[3]};
+        hidx++;
+        lds_post(&ctr[2], hidx);
+        produced = lds_peek4_get(cv, 1);
+        lim = lim0 < produced ? lim0 : produced;
+      } while (hidx < lim);
     }
     FSK_STAMP_END(2)
     fin[128u + lane] = (v4f){Qz.ai, Qz.aq, Qz.bi, Qz.bq};
@@ -496,9 +551,13 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     X.zlive = __builtin_amdgcn_ballot_w64(B.dph < kHandPairs) ? 1u : 0u;
     asm volatile("" : "+v"(X.kv));
     const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
-    const uint32_t amp_row_bytes = P.n_streams * 4u;
-    X.amp_soff = amp_pos0 * amp_row_bytes;
-    const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
+    const uint32_t amp_quad_bytes = P.n_streams * 16u;
+    X.amp_soff = amp_soff_of(amp_pos0, amp_quad_bytes);
+    const uint32_t amp_wrap = (P.amp_cap >> 2) * amp_quad_bytes;
+    // the block path stores a tile's amplitudes as two whole quads: the launch must start on a quad boundary (it does
+    // unless earlier calls had odd lengths; the host then launches the per-sample kernels, fsk_api.hip) -- otherwise every
+    // block takes the per-sample path
+    const bool amp_misaligned = (amp_pos0 & 3u) != 0u;
     const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
     uint32_t produced = 0, slot_i = 0;
     uint32_t pidx = 0;                                        // LDS index of the block's first polyphase register
@@ -507,6 +566,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     FSK_STAMP_BEGIN
     uint32_t t = 0;                                           // half tiles consumed (a block = a tile = two of them)
     while (t < nh) {
+      blk_prio(t & ~15u, wgj);                               // (t advances in steps of two; the outer loop sees every multiple of 16)
       if (produced < t + 2u) {
         FSK_STAMP_W0
         while (produced < t + 2u) {
@@ -516,13 +576,15 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         FSK_STAMP_W1
       }
       // every tile that is there, up to the next flush point
-      uint32_t lim = (t | (kFlushBlocks - 1u)) + 1u;
-      lim = lim < nh ? lim : nh;
-      lim = lim < (produced & ~1u) ? lim : (produced & ~1u);
+      uint32_t lim0 = (t | (kFlushBlocks - 1u)) + 1u;
+      lim0 = lim0 < nh ? lim0 : nh;
+      uint32_t lim = lim0 < (produced & ~1u) ? lim0 : (produced & ~1u);
       // ---- the block loop: straight-line code with two branches, its back edge and the exit on anything rare (a branch
       // costs a wave ~35 cycles whether taken or not)
       bool rare_exit = false;
       do {
+        v4u32 cv;
+        lds_peek4_begin(ctr, cv);
         const uint32_t slot_j = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
         const uint32_t pidx2 = pidx + 4u >= P.d ? 0u : pidx + 4u;
         const v4f *slot = ring + slot_i * kBlkSlotV4, *slot2 = ring + slot_j * kBlkSlotV4;
@@ -534,21 +596,29 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         uint32_t bqn = bq, nqn = nq;
         const uint32_t rare = blk_fast(Bn, K, Q, X.kv, pa, rp, am, bqn, nqn);
         // (a live correction of this wave's, or the amplitude ring's wrap, make the block path void: ~3 % of the blocks)
-        const bool pre = (X.zlive != 0u) | (X.amp_soff + 7u * amp_row_bytes >= amp_wrap);
+        const bool pre = (X.zlive != 0u) | amp_misaligned;
         FSK_STAMP_COUNT(0)                                    // blocks
         if (__builtin_expect(((__builtin_amdgcn_ballot_w64((int32_t)rare < 0) != 0) | pre) & !FSK_ABL(3), 0)) { rare_exit = true; break; }
         B = Bn; bq = bqn; nq = nqn;
         *reinterpret_cast<uint4 *>(prow + pidx) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
         *reinterpret_cast<uint4 *>(prow + pidx2) = make_uint4(rp[4], rp[5], rp[6], rp[7]);
-#pragma unroll
-        for (int j = 0; j < kBlk; j++)                         // syncAmplitudeBuffer.put x 8 (no wrap inside: tested above)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, am[j]), amp_rsrc, M.voff, X.amp_soff + (uint32_t)j * amp_row_bytes, 0);
-        X.amp_soff += (uint32_t)kBlk * amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
+        {                                                      // syncAmplitudeBuffer.put x 8 = two quads
+          uint32_t q2 = X.amp_soff + amp_quad_bytes; q2 = q2 == amp_wrap ? 0u : q2;
+          __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, am[0]), __builtin_bit_cast(uint32_t, am[1]),
+                                                        __builtin_bit_cast(uint32_t, am[2]), __builtin_bit_cast(uint32_t, am[3])},
+                                                 amp_rsrc, M.avoff, X.amp_soff, 0);
+          __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, am[4]), __builtin_bit_cast(uint32_t, am[5]),
+                                                        __builtin_bit_cast(uint32_t, am[6]), __builtin_bit_cast(uint32_t, am[7])},
+                                                 amp_rsrc, M.avoff, q2, 0);
+          X.amp_soff = q2 + amp_quad_bytes; X.amp_soff = X.amp_soff == amp_wrap ? 0u : X.amp_soff;
+        }
         X.k += (uint32_t)kBlk; X.kv += (uint32_t)kBlk;
         slot_i = slot_j + 1u == kBlkSlots ? 0u : slot_j + 1u;
         pidx = pidx2 + 4u >= P.d ? 0u : pidx2 + 4u;
         t += 2u;
         lds_post(&ctr[3], t);                                 // slots free (this wave's reads of them are complete)
+        produced = lds_peek4_get(cv, 2);
+        lim = lim0 < (produced & ~1u) ? lim0 : (produced & ~1u);
       } while (t < lim);
       if (rare_exit) {
         // something rare in the tile at t: sample by sample from its entry state (the round-2 path, unchanged)
@@ -571,7 +641,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
               const uint32_t r_old = *ps;
               back_pair<UNI, true, false, true>(B, K, P, S, M, ps, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
                                                 h ? u4.z : u4.x, h ? u4.w : u4.y, yp + 2 * h, r_old, inc, h ? pa.z : pa.x, h ? pa.w : pa.y);
-              X.amp_soff += amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
+              amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
             }
           }
           slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
@@ -608,13 +678,13 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
       }
     }
     const uint32_t phase_end = (phase0 + X.k) % P.d;
-    pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, phase_end, X.amp_soff / amp_row_bytes, inc, free0);
+    pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, phase_end, amp_pos_of(X.amp_soff, amp_quad_bytes), inc, free0);
   }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 size_t demod_blk_lds_bytes(const DemodParams &P) {
-  return sizeof(float4) * (4 * kSlotStride + kBlkSlots * 2 * 64 + kBlkSlots * kBlkSlotV4 + 3 * 64 + 2 * 8) +
+  return sizeof(float4) * (4 * kSlotStride + kBlkSlots * 2 * 64 + kBlkSlots * kBlkSlotV4 + 3 * 64 + 4 * 8) +
          sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 8u + 64u + 6u * 64u);
 }
 // the block path needs whole blocks of polyphase registers (dsSPB a multiple of 4) and at most one bit decision per block

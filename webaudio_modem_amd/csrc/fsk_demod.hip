@@ -414,7 +414,7 @@ __device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
       L.matched -= (uint32_t)((u >> 1) & 1u);
     }
     // ---- syncAmplitudeBuffer.put(amp): Float32Array store
-    if (valid) S.amp_ring[(size_t)R.amp_pos * P.n_streams + row] = (float)amp;
+    if (valid) S.amp_ring[amp_index(R.amp_pos, row, P.n_streams)] = (float)amp;
     R.phase = (R.phase + 1 == P.d) ? 0u : R.phase + 1;
     R.amp_pos = (R.amp_pos + 1 == P.amp_cap) ? 0u : R.amp_pos + 1;
     R.k++;
@@ -468,7 +468,7 @@ __device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
       const uint32_t slen = __shfl(my_len, src, 64);
       double part = 0.0;
       for (uint32_t i = lane; i < slen; i += 64) {
-        const float *p = S.amp_ring + (size_t)i * P.n_streams + srow;
+        const float *p = S.amp_ring + amp_index(i, srow, P.n_streams);
         part += (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L1 bypass
       }
       const double sum = wave_sum(part);

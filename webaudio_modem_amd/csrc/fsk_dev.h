@@ -75,7 +75,23 @@ struct FastMem {
   __amdgpu_buffer_rsrc_t is_rsrc;    // integer state [IF_COUNT][n_streams]
   uint32_t fld;                      // bytes per field
   uint32_t voff;                     // row*4, or 0xFFFFFFF0 for lanes beyond the batch
+  uint32_t avoff;                    // row*16 (the stream's quad in an amplitude-ring row), or 0xFFFFFFF0
 };
+
+// syncAmplitudeBuffer storage (fsk.ts:150): [slot / 4][stream][slot % 4] floats -- four consecutive ring slots of a
+// stream are one 16-byte quad, so that the block kernel stores a tile's eight amplitudes with two 16-byte stores per lane
+// (a store instruction costs the issuing wave ~35 cycles whatever its width).  amp_cap = 8 dsSPB is a multiple of four
+// for every integer dsSPB.
+__host__ __device__ inline size_t amp_index(uint32_t pos, uint32_t row, uint32_t n_streams) {
+  return ((size_t)(pos >> 2) * n_streams + row) * 4u + (pos & 3u);
+}
+// the same as a byte offset split into the scalar part (quad row + slot within the quad) the whole-tile kernels carry
+__device__ inline uint32_t amp_soff_of(uint32_t pos, uint32_t quad_bytes) { return (pos >> 2) * quad_bytes + (pos & 3u) * 4u; }
+__device__ inline uint32_t amp_pos_of(uint32_t soff, uint32_t quad_bytes) { return (soff / quad_bytes) * 4u + ((soff % quad_bytes) >> 2); }
+__device__ inline void amp_advance(uint32_t &soff, uint32_t quad_bytes, uint32_t wrap) {
+  soff += 4u;
+  if ((soff & 12u) == 0u) { soff += quad_bytes - 16u; if (soff == wrap) soff = 0u; }
+}
 __device__ inline uint32_t ist_load(const FastMem &M, uint32_t field) {
   return __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, M.voff, field * M.fld, 0);
 }
@@ -138,7 +154,7 @@ __device__ inline void quality_on_eod(const DemodParams &P, const DemodState &S,
     double part = 0.0;
     for (uint32_t i = lane; i < cnt; i += 64) {
       const uint32_t pos = snew >= i ? snew - i : snew + P.amp_cap - i;
-      const float *p = S.amp_ring + (size_t)pos * n + srow;
+      const float *p = S.amp_ring + amp_index(pos, srow, n);
       part += (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const double sum = wave_sum(part);

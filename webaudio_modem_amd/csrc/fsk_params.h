@@ -186,13 +186,17 @@ struct ProcState {
 // after a resetState() -- far enough for the wave that owns the low-pass (at most six half tiles = 24 decimated samples
 // ahead of the back wave in fsk_blk.hip, four in fsk_pipe.hip) to learn of the reset in time -- and a direct instance
 // covers those plus two more.
-static constexpr uint32_t kZeroLagPairs = 24;
+#ifndef FSK_ZLAG
+#define FSK_ZLAG 24
+#endif
+static constexpr uint32_t kZeroLagPairs = FSK_ZLAG;
 static constexpr uint32_t kDirectPairs = kZeroLagPairs + 2;
 // The zero-input response left by a reset is carried un-retired for another kHandLag decimated samples (zr_dph counts on
 // to kHandPairs).  That fixed span is what lets the four-wave kernel (fsk_blk.hip) move the correction from its back wave
-// to the discriminator wave running up to 16 decimated samples AHEAD of it: the values at the hand-over sample follow
-// from the two start values by the recurrence alone, so the back wave can post them 20 samples early.
-static constexpr uint32_t kHandLag = 20;
+// to the discriminator wave running up to 23 decimated samples AHEAD of the tile the back wave is in: the values at the
+// hand-over sample follow from the two start values by the recurrence alone, so the back wave can post them 24 samples
+// early -- and the discriminator wave, whatever its lead, has not reached the hand-over sample when they are posted.
+static constexpr uint32_t kHandLag = 24;
 static constexpr uint32_t kHandPairs = kDirectPairs + kHandLag;
 static constexpr uint32_t kBigWait = 0x40000000u;  // bit_wait while !started (12 h of decimated samples)
 #ifndef FSK_TILE

@@ -271,9 +271,9 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
     asm volatile("" : "+v"(X.kv));
     X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
     const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
-    const uint32_t amp_row_bytes = P.n_streams * 4u;
-    X.amp_soff = amp_pos0 * amp_row_bytes;
-    const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
+    const uint32_t amp_quad_bytes = P.n_streams * 16u;
+    X.amp_soff = amp_soff_of(amp_pos0, amp_quad_bytes);
+    const uint32_t amp_wrap = (P.amp_cap >> 2) * amp_quad_bytes;
     const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
     uint32_t produced = 0, slot_i = 0;
     const uint32_t nh = 2u * (uint32_t)n_tiles;             // half tiles
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
           if (!FSK_ABL(1))
             back_pair<UNI, true>(B, K, P, S, M, &poly[X.phase * 64u + lane], lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, h ? u4.z : u4.x,
                                  h ? u4.w : u4.y, yp + 2 * h, h ? r1 : r0, inc, h ? pa.z : pa.x, h ? pa.w : pa.y);
-          X.amp_soff += amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
+          amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
         }
         X.phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
       }
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
       F.g = F.bx1 = F.bx2 = F.by1 = F.by2 = 0.f;
     }
     for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
-    pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
+    pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, X.phase, amp_pos_of(X.amp_soff, amp_quad_bytes), inc, free0);
   }
 }
 
@@ -578,9 +578,9 @@ __global__ __launch_bounds__(192) void demod_pipe3_kernel(
     asm volatile("" : "+v"(X.kv));
     X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
     const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
-    const uint32_t amp_row_bytes = P.n_streams * 4u;
-    X.amp_soff = amp_pos0 * amp_row_bytes;
-    const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
+    const uint32_t amp_quad_bytes = P.n_streams * 16u;
+    X.amp_soff = amp_soff_of(amp_pos0, amp_quad_bytes);
+    const uint32_t amp_wrap = (P.amp_cap >> 2) * amp_quad_bytes;
     const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
     uint32_t produced = 0, slot_i = 0;
     FSK_STAMP_BEGIN
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(192) void demod_pipe3_kernel(
           if (!FSK_ABL(2))
             back_pair<UNI, true>(B, K, P, S, M, &poly[X.phase * 64u + lane], lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, h ? u4.z : u4.x,
                                  h ? u4.w : u4.y, yp + 2 * h, h ? r1 : r0, inc, h ? pa.z : pa.x, h ? pa.w : pa.y);
-          X.amp_soff += amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
+          amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
         }
         X.phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
       }
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(192) void demod_pipe3_kernel(
       F.g = F.bx1 = F.bx2 = F.by1 = F.by2 = 0.f;
     }
     for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
-    pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
+    pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, X.phase, amp_pos_of(X.amp_soff, amp_quad_bytes), inc, free0);
   }
 }
 
@@ -677,9 +677,9 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
   asm volatile("" : "+v"(X.kv));
   X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
   const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
-  const uint32_t amp_row_bytes = P.n_streams * 4u;
-  X.amp_soff = amp_pos0 * amp_row_bytes;
-  const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
+  const uint32_t amp_quad_bytes = P.n_streams * 16u;
+  X.amp_soff = amp_soff_of(amp_pos0, amp_quad_bytes);
+  const uint32_t amp_wrap = (P.amp_cap >> 2) * amp_quad_bytes;
   const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
 
   // tile prefetch as in the r01 kernel: inline-asm loads with a hand-counted vmcnt (each tile issues at least 8
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
         const float ypr[2] = {y0, y1};
         back_pair<UNI>(B, BK, P, S, M, &poly[X.phase * 64u + lane], lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, oi0 + oi1, oq0 + oq1,
                        ypr, h ? r1 : r0, inc);
-        X.amp_soff += amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
+        amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
       }
       X.phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
       if (WB) {
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre0), "+v"(pre1), "+v"(pre2), "+v"(pre3) : : "memory");
 #undef FSK_BLOAD4
   for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
-  pipe_store<UNI>(F, true, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
+  pipe_store<UNI>(F, true, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, X.phase, amp_pos_of(X.amp_soff, amp_quad_bytes), inc, free0);
 }
 
 // ================================================================================================================
@@ -833,9 +833,9 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
   asm volatile("" : "+v"(X.kv));
   X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
   const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
-  const uint32_t amp_row_bytes = P.n_streams * 4u;
-  X.amp_soff = amp_pos0 * amp_row_bytes;
-  const uint32_t amp_wrap = P.amp_cap * amp_row_bytes;
+  const uint32_t amp_quad_bytes = P.n_streams * 16u;
+  X.amp_soff = amp_soff_of(amp_pos0, amp_quad_bytes);
+  const uint32_t amp_wrap = (P.amp_cap >> 2) * amp_quad_bytes;
   const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
   float acc_i = parity0 ? PIPE_RLOAD(acc_i) : 0.f, acc_q = parity0 ? PIPE_RLOAD(acc_q) : 0.f;
   float *xrow = samples + (size_t)(C.row4 >> 2) * pitch;
@@ -859,13 +859,13 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
       const float ypr[2] = {F.by2, F.by1};               // the pair's two pre-filter outputs
       back_pair<UNI, false, true>(B, BK, P, S, M, &poly[X.phase * 64u + lane], lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, acc_i + oi,
                                   acc_q + oq, ypr, r_old, inc);
-      X.amp_soff += amp_row_bytes; if (X.amp_soff == amp_wrap) X.amp_soff = 0;
+      amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
       X.phase = (X.phase + 1 == P.d) ? 0u : X.phase + 1;
       acc_i = 0.f; acc_q = 0.f;
     }
   }
   for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
-  pipe_store<UNI>(F, true, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, X.phase, X.amp_soff / amp_row_bytes, inc, free0);
+  pipe_store<UNI>(F, true, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, X.phase, amp_pos_of(X.amp_soff, amp_quad_bytes), inc, free0);
   PIPE_RSTORE(acc_i, acc_i); PIPE_RSTORE(acc_q, acc_q);
   PIPE_ISTORE(ds_cnt, par);
 }

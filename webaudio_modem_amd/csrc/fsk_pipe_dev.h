@@ -211,7 +211,7 @@ struct BackU {                   // wave-uniform context of one decimated sample
   uint32_t k;                    // pushes of this launch including this one
   uint32_t kv;                   // the same in a VGPR (operand of the per-lane selects and differences)
   uint32_t phase;                // polyphase slot of this push
-  uint32_t amp_soff;             // byte offset of the amplitude-ring row
+  uint32_t amp_soff;             // amplitude ring: byte offset of the push slot (quad row + slot within the quad, fsk_dev.h)
   uint32_t direct;               // decimated samples for which some lane still runs the direct instance (after a reset)
   uint32_t zlive;                // some lane carries a non-zero correction (or runs the direct instance)
   uint32_t *zmail;               // LDS [64]: decimated-sample index of this launch before which the front zeroes the lane's filters
@@ -430,7 +430,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   *pslot = r;                                                  // (the polyphase register of this push slot)
   B.matched += (uint32_t)__builtin_popcount((r ^ qn) & mask);
   B.matched -= (uint32_t)__builtin_popcount((r_old ^ qn) & mask);
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, M.voff, X.amp_soff, 0);  // syncAmplitudeBuffer.put
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, M.avoff, X.amp_soff, 0);  // syncAmplitudeBuffer.put
   {
     const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, amp - B.thr));   // amp < threshold (fsk.ts:285)
     B.ls = (B.ls & silent) | (X.kv & ~silent);                 // silence run = k - ls (fsk.ts:285-295)
@@ -449,7 +449,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
     if (__builtin_amdgcn_ballot_w64(eod)) {                    // fsk.ts:288-291
       if (TRC && P.quality) {   // opt-in estimates (sample-granular kernel only): the noise floor of the silence behind the first 'eod' after a sync
         const uint32_t pushes = ist_load(M, IF_amp_len) + X.k;
-        quality_on_eod<float>(P, S, lane, M.voff >> 2, eod & (M.voff < 0xFFFFFFF0u), X.amp_soff / (P.n_streams * 4u),
+        quality_on_eod<float>(P, S, lane, M.voff >> 2, eod & (M.voff < 0xFFFFFFF0u), amp_pos_of(X.amp_soff, P.n_streams * 16u),
                               pushes < P.amp_cap ? pushes : P.amp_cap);
       }
       if (eod) {
@@ -484,7 +484,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
         const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slen, src);
         double part = 0.0;
         for (uint32_t i = lane; i < sl; i += 64) {
-          const float *p = S.amp_ring + (size_t)i * P.n_streams + srow;
+          const float *p = S.amp_ring + amp_index(i, srow, P.n_streams);
           part += (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const double sum = wave_sum(part);
@@ -562,6 +562,7 @@ __device__ inline PipeCtx pipe_ctx(const DemodParams &P, const DemodState &S, ui
   C.M.is_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.is, 0, (int)(C.fld * IF_COUNT), 0x00020000);
   C.M.fld = C.fld;
   C.M.voff = C.valid ? row * 4u : 0xFFFFFFF0u;
+  C.M.avoff = C.valid ? row * 16u : 0xFFFFFFF0u;
   C.row4 = row * 4u;
   return C;
 }
@@ -715,6 +716,17 @@ __device__ inline uint32_t lds_peek(const uint32_t *p) {
   uint32_t v;
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+// All four hand-off counters with ONE LDS read whose latency hides behind the caller's own work: issue it first in an
+// iteration; the wait inside the iteration's lds_post covers it (LDS operations of a wave return in order), after which
+// lds_peek4_get hands out the values.  They are up to one iteration old -- counters only grow, so stale is safe.
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+__device__ inline void lds_peek4_begin(const uint32_t *ctr, v4u32 &c) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(c) : "v"((uint32_t)(uintptr_t)ctr) : "memory");
+}
+__device__ inline uint32_t lds_peek4_get(v4u32 &c, int i) {
+  asm volatile("" : "+v"(c));
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)(i == 0 ? c.x : i == 1 ? c.y : i == 2 ? c.z : c.w));
 }
 __device__ inline void lds_post(uint32_t *p, uint32_t v) {
   asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" : : "v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
