@@ -465,3 +465,72 @@ def test_single_stream_reset_at_odd_decimator_phase(pname, prec, tol):
     assert got == want == b"Hello"
     _check_status(eng.get_status(0), o.status(), tol, o.status()["agcGain"])
     eng.close()
+
+
+@pytest.mark.parametrize("after_reset", [5, 32, 60], ids=["direct_instance", "unretired_correction", "steady"])
+def test_pipe_state_handed_to_generic_kernel_mid_pair(after_reset):
+    """fskhip_reset(stream) on a multi-stream fp32 engine whose /2 decimators are mid-pair takes the
+    batch out of lock step, so the NEXT call runs on the generic kernel -- which has to rebuild the reference's own state
+    from the free-running representation with an open decimator pair.  While a stream is within kDirectPairs decimated
+    samples of an internal resetState() the direct instance has not seen the pair's first sample yet, and a live ZIR
+    correction sits one sample further along: both used to be ignored.  Stream 0 / 2: a frame, digital silence until the
+    reference's 'eod', then a second frame right behind it, in light noise; the call is cut `after_reset` decimated samples
+    and one input sample after that 'eod'."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(77)
+    o0 = po.OracleCore({})
+    f1, f2 = o0.modulate(b"AB"), o0.modulate(b"Hello, generic kernel")
+    S = 3
+    xs = []
+    for s in range(S):
+        lead = 40 + 64 * s
+        x = np.concatenate([np.zeros(lead, np.float32), f1 * np.float32(0.8), np.zeros(90, np.float32), f2 * np.float32(0.6), np.zeros(800, np.float32)])
+        xs.append(x)
+    N = max(len(x) for x in xs)
+    x = np.zeros((S, N), np.float32)
+    for s in range(S):
+        x[s, :len(xs[s])] = xs[s]
+    x += (rng.standard_normal(x.shape) * 2e-3).astype(np.float32)
+    # where does the reference raise stream 0's first 'eod'?
+    probe = po.OracleCore({})
+    n_e = None
+    for i in range(0, N, 2):
+        _, oe = probe.demodulate(x[0, i:i + 2])
+        if oe:
+            n_e = i + 2
+            break
+    assert n_e is not None and n_e % 2 == 0
+    cut = n_e + 2 * after_reset + 1
+    assert cut % 2 == 1 and cut < N - 2000
+    eng = _engine({}, 0, S)
+    oracles = [po.OracleCore({}) for _ in range(S)]
+    oracles[0].enable_trace(N, 16)
+    got = [b""] * S
+    want = [b""] * S
+    for a, b, reset in ((0, cut, True), (cut, cut + 1001, False), (cut + 1001, N, False)):
+        out, eod = eng.demodulate_data(np.ascontiguousarray(x[:, a:b]))
+        for s in range(S):
+            ob, oe = oracles[s].demodulate(x[s, a:b])
+            got[s] += out[s]
+            want[s] += ob
+            assert int(eod[s]) == oe, (s, a)
+        if reset:
+            eng.reset(1)          # odd decimator phase -> the batch leaves lock step -> generic kernel from here on
+            oracles[1].reset()
+            assert "demod_kernel" not in eng.last_kernel()
+            eng.trace_enable(0, N)   # stream 0's I/Q magnitudes from the hand-over on
+    assert "demod_kernel<float" in eng.last_kernel()
+    # the decimated samples right behind the hand-over are where a wrong pair / a shifted correction shows: magnitudes within
+    # 1e-5 of the reference's (relative, floored at 1e-4 of the peak as in test_intermediates_match_reference)
+    tr, ref = eng.trace_read()["amp"], oracles[0].trace()["amp"]
+    ref_tail = ref[cut // 2:]
+    assert tr.size == ref_tail.size and tr.size > 1000
+    rel = np.abs(tr - ref_tail) / np.maximum(ref_tail, 1.0e-4 * ref.max())
+    assert rel[:200].max() <= 1e-5, (int(np.argmax(rel[:200])), rel[:200].max())
+    for s in range(S):
+        assert got[s] == want[s], (s, got[s], want[s])
+        st, ost = eng.get_status(s), oracles[s].status()
+        for k in STATUS_EXACT_KEYS:
+            assert st[k] == ost[k], (s, k)
+    assert b"Hello, generic kernel" in got[0]
+    eng.close()

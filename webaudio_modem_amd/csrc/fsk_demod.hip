@@ -147,7 +147,7 @@ __device__ inline void rot2(double c, double s, double a, double b, float &ra, f
   rb = (float)(b * c + a * s);
 }
 __device__ inline void pipe_to_actual(Lane<float> &L, const DemodParams &P, const DemodState &S, size_t n, uint32_t row,
-                                      PipeFrame &fr) {
+                                      PipeFrame &fr, uint64_t inc) {
   const float *rs = (const float *)S.rs;
 #define RQ(f) rs[(size_t)RF_##f * n + row]
 #define IQ(f) S.is[(size_t)IF_##f * n + row]
@@ -157,16 +157,38 @@ __device__ inline void pipe_to_actual(Lane<float> &L, const DemodParams &P, cons
   const double th = (double)off * 5.42101086242752217e-20 * 6.283185307179586476925;   // 2^-64 turns -> radians
   const double c = cos(th), sn = sin(th);
   double x1i, x1q, x2i, x2q, yi, yq, vi, vq;
+  double ai = L.acc_i, aq = L.acc_q;               // an open decimator pair's first low-pass outputs (free-running frame)
+  const bool open_pair = L.ds_cnt == 1u;           // the previous call ended between the two samples of a decimator pair
+  const double a2 = P.lp_a2, delta = 1.0 + P.lp_a1 + P.lp_a2;
   if (IQ(zr_dph) < kDirectPairs) {   // the direct instance IS the state
     x1i = RQ(zd_ix1); x1q = RQ(zd_qx1); x2i = RQ(zd_ix2); x2q = RQ(zd_qx2);
     yi = RQ(zd_iy); yq = RQ(zd_qy); vi = RQ(zd_iv); vq = RQ(zd_qv);
+    if (open_pair) {
+      // ... but back_pair feeds it a pair's two samples when the pair closes: the open pair's first sample (pre-filter
+      // output bp_y1, mixed with the free-running NCO one step back) is still missing, and the pair's partial sums must be
+      // this instance's, not the free-running filters' (a stream handed to this kernel mid-pair within
+      // kDirectPairs decimated samples of a resetState() got a wrong I/Q pair and a lasting low-pass state error)
+      const double tp = (double)(fr.free0 - inc) * 5.42101086242752217e-20 * 6.283185307179586476925;
+      const double y = (double)L.bp_y1, mi = y * cos(tp), mq = y * sin(tp);
+      const double ti = 2.0 * x1i + mi + x2i, tq = 2.0 * x1q + mq + x2q;
+      vi = a2 * vi + (ti - delta * yi); vq = a2 * vq + (tq - delta * yq);
+      yi += vi; yq += vq;
+      x2i = x1i; x1i = mi; x2q = x1q; x1q = mq;
+      ai = yi; aq = yq;
+    }
   } else {                 // free-running state minus the zero-input response (its x history is zero by now)
     const float qai = RQ(zq_ai), qaq = RQ(zq_aq), qbi = RQ(zq_bi), qbq = RQ(zq_bq);
     x1i = L.li_x1; x1q = L.lq_x1; x2i = L.li_x2; x2q = L.lq_x2;
-    yi = L.li_y1 - __builtin_fmaf(P.z_yb, qbi, P.z_ya * qai);
-    yq = L.lq_y1 - __builtin_fmaf(P.z_yb, qbq, P.z_ya * qaq);
-    vi = L.li_y2 - __builtin_fmaf(P.z_vb, qbi, P.z_va * qai);
-    vq = L.lq_y2 - __builtin_fmaf(P.z_vb, qbq, P.z_va * qaq);
+    // (y, v) of the response at the even sample in front of the upcoming pair ...
+    double zyi = __builtin_fmaf(P.z_yb, qbi, P.z_ya * qai), zyq = __builtin_fmaf(P.z_yb, qbq, P.z_ya * qaq);
+    double zvi = __builtin_fmaf(P.z_vb, qbi, P.z_va * qai), zvq = __builtin_fmaf(P.z_vb, qbq, P.z_va * qaq);
+    if (open_pair) {       // ... one homogeneous step later when that pair's first sample has been taken already; its
+      zvi = a2 * zvi - delta * zyi; zvq = a2 * zvq - delta * zyq;   // output there also sits in the pair's partial sums
+      zyi += zvi; zyq += zvq;
+      ai -= zyi; aq -= zyq;
+    }
+    yi = L.li_y1 - zyi; yq = L.lq_y1 - zyq;
+    vi = L.li_y2 - zvi; vq = L.lq_y2 - zvq;
   }
   // fsk_pipe.hip runs the branch from the pre-filter output on 2^60 times the reference's size (kIqScale there)
   const double un = 8.67361737988403547e-19;       // 2^-60
@@ -175,10 +197,7 @@ __device__ inline void pipe_to_actual(Lane<float> &L, const DemodParams &P, cons
   rot2(c, sn, x2i * un, x2q * un, L.li_x2, L.lq_x2);
   rot2(c, sn, yi * un, yq * un, L.li_y1, L.lq_y1);
   rot2(c, sn, vi * un, vq * un, L.li_y2, L.lq_y2);
-  {
-    const double ai = L.acc_i, aq = L.acc_q;       // an open decimator pair's first low-pass outputs
-    rot2(c, sn, ai * un, aq * un, L.acc_i, L.acc_q);
-  }
+  rot2(c, sn, ai * un, aq * un, L.acc_i, L.acc_q);
   double r = (double)L.last_phase + th;            // th in [0, 2 pi)
   r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
   L.last_phase = (float)r;
@@ -212,7 +231,7 @@ __device__ inline void actual_to_pipe(Lane<float> &L, const DemodState &S, size_
                     RF_zd_qx1, RF_zd_qx2, RF_zd_qy, RF_zd_qv};
   for (int f : zf) rs[(size_t)f * n + row] = 0.0f;
 }
-__device__ inline void pipe_to_actual(Lane<double> &, const DemodParams &, const DemodState &, size_t, uint32_t, PipeFrame &) {}
+__device__ inline void pipe_to_actual(Lane<double> &, const DemodParams &, const DemodState &, size_t, uint32_t, PipeFrame &, uint64_t) {}
 __device__ inline void actual_to_pipe(Lane<double> &, const DemodState &, size_t, uint32_t, const PipeFrame &, uint64_t, size_t) {}
 
 // ---- fp64: op-for-op with the reference's double arithmetic (this TU is built with
@@ -553,7 +572,7 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
   Lane<Real> L;
   load_lane(L, S, ns, row);
   PipeFrame frame{0};
-  if (n > 0) pipe_to_actual(L, P, S, ns, row, frame);
+  if (n > 0) pipe_to_actual(L, P, S, ns, row, frame, S.nco_inc[row]);
   L.thr_eff = L.started ? 0xFFFFFFFFu : P.matched_min;
   Consts<Real> C;
   C.init(P, S, row);
