@@ -627,7 +627,7 @@ long fsko_demodulate(fsko_core *c, float *samples, size_t n, uint8_t *out, size_
     process_sample(c, (double)pre);
   }
   produced = (long)c->out_n;
-  if (out && out_cap) memcpy(out, c->out, c->out_n < out_cap ? c->out_n : out_cap);
+  if (out && out_cap && c->out_n) memcpy(out, c->out, c->out_n < out_cap ? c->out_n : out_cap);   /* (c->out is NULL until the first byte: memcpy from NULL is undefined even for 0 bytes -- found by the UBSan run) */
   c->out_n = 0;
   if (eod_count) *eod_count = (uint32_t)(c->eod_count - eod0);
   return produced;

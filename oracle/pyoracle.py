@@ -48,10 +48,17 @@ class Trace(C.Structure):
 
 
 def build(force=False):
-    """Compile the oracle with gcc (building the checker is not using it)."""
+    """Compile the oracle with gcc (building the checker is not using it).  FSK_ORACLE_SANITIZE=1 selects the
+    AddressSanitizer + UndefinedBehaviorSanitizer build (`make asan`); the process must then run with libasan preloaded
+    (tests/test_oracle_sanitizers.py does: LD_PRELOAD=$(gcc -print-file-name=libasan.so))."""
+    global _LIB_PATH
     src = os.path.join(_HERE, "fsk_oracle.c")
+    target = "libfsk_oracle.so"
+    if os.environ.get("FSK_ORACLE_SANITIZE") == "1":
+        target = "libfsk_oracle_asan.so"
+        _LIB_PATH = os.path.join(_HERE, target)
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "libfsk_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "asan" if target.endswith("_asan.so") else target], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

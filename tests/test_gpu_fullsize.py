@@ -14,7 +14,10 @@ own allocator), so the host never holds more than the sampled rows.
 import zlib
 
 import numpy as np
+import os
 import pytest
+
+from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -454,3 +457,84 @@ def test_host_entry_point_pipelined_over_time_slabs_gives_the_one_shot_result(wr
         assert np.array_equal(got[3], ref[3])  # the input, or the AGC-scaled samples when written back
     if writeback:
         assert not np.array_equal(ref[3], x)
+
+
+def _full_length_check(S, cfg_of, N, payload, lead_max, oracle_streams, chunk):
+    """one call over N samples vs the same buffer in `chunk`-sample calls (checksum of per-stream checksums), and the oracle on
+    a strided sample of the one-call result"""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    per_stream = not isinstance(cfg_of, dict)
+    cfgs = [cfg_of(s) for s in range(S)] if per_stream else cfg_of
+    gen = wm.FSKEngine(S, cfgs, precision=wm.PRECISION_F32)
+    try:
+        d_x = gen.device_malloc(S * N * 4)
+    except Exception as ex:  # a smaller GPU than the one the metric is defined on
+        pytest.skip("cannot hold %.0f GB: %s" % (S * N * 4 / 1e9, ex))
+    gen.synth_device(d_x, N, N, payload, SEED + 11, lead_max, 0.1, 1.0)
+    gen.synchronize()
+    eng = wm.FSKEngine(S, cfgs, precision=wm.PRECISION_F32)
+    rows, eod = _demod_schedule(eng, d_x, N, N, [N])
+    kernel = eng.last_kernel()
+    eng.close()
+    eng = wm.FSKEngine(S, cfgs, precision=wm.PRECISION_F32)
+    rows2, eod2 = _demod_schedule(eng, d_x, N, N, [chunk])
+    eng.close()
+    assert _digest(rows, eod) == _digest(rows2, eod2)
+    row = np.empty(N, np.float32)
+    hit = 0
+    sample = list(range(0, S, max(1, S // oracle_streams))) + [S - 1]
+    for s in sample:
+        gen.d2h(row, d_x + s * N * 4)
+        ob, oe = po.OracleCore(cfgs[s] if per_stream else cfgs).demodulate(row)
+        assert rows[s] == ob and int(eod[s]) == oe, s
+        hit += gen.synth_payload(SEED + 11, s, 0, payload) in rows[s]
+    assert hit >= len(sample) * 0.6
+    gen.device_free(d_x)
+    gen.close()
+    return kernel, sum(len(r) for r in rows)
+
+
+def test_config2_full_length_480000_samples():
+    """BASELINE config #2 as written: 4 096 V.21-tone 300-baud streams x 480 000 samples (10 s) in ONE call, against the oracle
+    on a strided sample, and against the same buffer in 1 s calls (VERDICT r02 #7)."""
+    kernel, nbytes = _full_length_check(4096, V21, 480000, 32, 1600, 12, 48000)
+    assert "demod_blk_kernel" in kernel
+    assert nbytes >= 4096 * 32 * 4          # eight 32-byte frames fit into 10 s; most of them decode
+
+
+def test_config4_full_length_480000_samples():
+    """BASELINE config #4 at full length: 32 768 streams with per-stream tone pairs (mark_s = 1000 + 10 (s mod 100), space_s
+    = mark_s + 200, 300 baud) x 480 000 samples = 63 GB resident, one call vs 1 s calls, oracle (each stream its own
+    configuration) on a strided sample (VERDICT r02 #7)."""
+    kernel, nbytes = _full_length_check(
+        32768, lambda s: dict(baudRate=300, markFrequency=1000 + 10 * (s % 100), spaceFrequency=1200 + 10 * (s % 100)),
+        480000, 16, 1600, 12, 48000)
+    assert "demod_blk_kernel<false, false>" in kernel      # the per-stream-constant instantiation
+    assert nbytes >= 32768 * 16 * 6
+
+
+def test_config5_roundtrip_modulate_awgn_demodulate_full_length():
+    """BASELINE config #5 as BASELINE.md defines it, at 16 384 streams x 480 000 samples: every frame comes from
+    fskhip_modulate_device (FSKCore.modulateData), Gaussian noise at 10 dB with the reference tests' power definition
+    (fsk-demodulation.node.test.ts:1184-1205), demodulated frame slot by frame slot; reports frame success rate and BER
+    against the transmitted payloads, and requires the strided oracle sample to be byte-identical slot by slot.  Runs
+    `bench.py --workload c5` itself (VERDICT r02 #6) in a child interpreter: bench.py holds its buffers in torch tensors."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--streams", "16384", "--steps", "1",
+                        "--warmup", "0", "--cpu-seconds", "4"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]      # (exit 3 = a sampled stream differed from the oracle)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    q = line["config"]["c5_quality"]
+    print("config #5:", q)
+    assert line["config"]["samples_per_stream"] == 480000 and line["config"]["streams_per_gpu"] == 16384
+    assert q["oracle_streams_checked"] >= 8 and q["oracle_streams_byte_identical"] == q["oracle_streams_checked"]
+    assert line["cpu_baseline"]["parity_ok"]
+    assert q["frames"] == 11 * 16384
+    # what the reference's own algorithm delivers at this SNR with noise everywhere (gaps included: its AGC opens up in
+    # them and false syncs add bytes to about four slots in ten): measured frame_success_rate 0.61, delivery 0.71, no bit
+    # error in any length-matched frame.  The parity claim is the oracle comparison above; these are sanity floors.
+    assert q["frame_success_rate"] >= 0.4 and q["frame_delivery_rate"] >= q["frame_success_rate"], q
+    assert q["ber_on_length_matched_frames"] <= 1e-4, q

@@ -534,3 +534,31 @@ def test_pipe_state_handed_to_generic_kernel_mid_pair(after_reset):
             assert st[k] == ost[k], (s, k)
     assert b"Hello, generic kernel" in got[0]
     eng.close()
+
+
+def test_host_calls_after_an_odd_length_call_stay_on_whole_tiles():
+    """after one odd-length call the /2 decimators are mid-pair; an aligned staging buffer then needs an odd head
+    for the parity and a multiple of four for the alignment, so every later even-length host call used to run sample by
+    sample.  fskhip_demodulate_host now stages such calls three floats into the row (a head of one sample closes the pair AND
+    reaches the 16-byte boundary)."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    g = golden()
+    base = g.array("d_default_Hello_c128.in")
+    S = 64
+    x = np.zeros((S, 12000), np.float32)
+    for s in range(S):
+        x[s, 100 + 3 * s:100 + 3 * s + base.size] = base
+    eng = wm.FSKEngine(S, {}, precision=wm.PRECISION_F32)
+    oracles = [po.OracleCore({}) for _ in range(S)]
+    got = [b""] * S
+    for a, b in ((0, 333), (333, 333 + 4096), (333 + 4096, 12000)):
+        out, eod = eng.demodulate_data(np.ascontiguousarray(x[:, a:b]))
+        if a == 333:
+            assert "tail" not in eng.last_kernel(), eng.last_kernel()     # whole tiles although the call started mid-pair
+        for s in range(S):
+            ob, oe = oracles[s].demodulate(x[s, a:b])
+            got[s] += out[s]
+            assert out[s] == ob and int(eod[s]) == oe, (s, a)
+    assert all(g_ == b"Hello" for g_ in got)
+    eng.close()

@@ -201,6 +201,9 @@ def main(budget=None, seed=None, max_rounds=None):
         eng.close()
         rounds += 1
         streams += S
+    # an excused stream stops being checked for the rest of its round, so excuses must stay the rare exception they were
+    # measured to be (round 2: two in 1.1 M stream-runs): more than one per 100 000 stream-runs fails the soak
+    assert SOFT["marginal"] <= 1 + streams // 100000, ("too many fp32 divergences excused as marginal", SOFT["marginal"], SOFT["marginal_first"])
     print("soak ok: %d rounds, %d stream-runs, seed %#x; fp32 timing differences with identical bytes: %d %s; fp32 streams "
           "diverging after a slicer decision within 1e-6 of zero: %d %s"
           % (rounds, streams, seed, SOFT["n"], SOFT["first"] or "", SOFT["marginal"], SOFT["marginal_first"] or ""))

@@ -755,19 +755,25 @@ int fskhip_demodulate_host(fskhip_engine *e, float *samples, size_t n, size_t pi
   if (env) slab = (size_t)strtoull(env, nullptr, 10) & ~(size_t)15;
   const bool piped = slab > 0 && n > slab + slab / 2;
   const size_t len0 = piped ? slab + slab / 2 : n;    // (the last slab of a pipelined call takes the remainder, < 1.5 slabs)
-  // device copies keep a row pitch that is a multiple of 4 floats so the 16-B tile loads apply
-  const size_t dpitch = ((len0 + 3) & ~(size_t)3) ? ((len0 + 3) & ~(size_t)3) : 4;
+  // device copies keep a row pitch that is a multiple of 4 floats so the 16-B tile loads apply.  A stream whose /2
+  // decimator is mid-pair (an earlier call had an odd length) is staged THREE floats into its row: the one sample that
+  // closes the pair then also reaches the next 16-byte boundary, and the rest of the call runs on whole tiles -- staged
+  // at the row start it would need an odd head for the parity and a multiple of four for the alignment, i.e. every
+  // later even-length call would run sample by sample (fsk_api.hip's silent performance cliff).
+  const size_t dpitch = ((len0 + 3 + 3) & ~(size_t)3) ? ((len0 + 3 + 3) & ~(size_t)3) : 4;
+  auto shift = [&]() -> size_t { return (e->precision == FSKHIP_PRECISION_F32 && e->ds_uniform && (e->ds_parity & 1u)) ? 3 : 0; };
   int rc;
   if ((rc = ensure(e->d_samples, e->d_samples_cap, dpitch * S)) != FSKHIP_OK) return rc;
   if ((rc = ensure(e->d_out, e->d_out_cap, (out_pitch ? out_pitch : 1) * S)) != FSKHIP_OK) return rc;
   if (!piped) {
+    float *stg = e->d_samples + shift();
     if (n > 0)
-      HIP_TRY(hipMemcpy2DAsync(e->d_samples, dpitch * sizeof(float), samples, pitch * sizeof(float), n * sizeof(float), S,
+      HIP_TRY(hipMemcpy2DAsync(stg, dpitch * sizeof(float), samples, pitch * sizeof(float), n * sizeof(float), S,
                                hipMemcpyHostToDevice, e->stream));
-    rc = fskhip_demodulate_device(e, e->d_samples, n, dpitch, e->d_out, out_pitch, e->d_counts, e->d_eod, flags, e->stream);
+    rc = fskhip_demodulate_device(e, stg, n, dpitch, e->d_out, out_pitch, e->d_counts, e->d_eod, flags, e->stream);
     if (rc != FSKHIP_OK) return rc;
     if (wb && n > 0)
-      HIP_TRY(hipMemcpy2DAsync(samples, pitch * sizeof(float), e->d_samples, dpitch * sizeof(float), n * sizeof(float), S,
+      HIP_TRY(hipMemcpy2DAsync(samples, pitch * sizeof(float), stg, dpitch * sizeof(float), n * sizeof(float), S,
                                hipMemcpyDeviceToHost, e->stream));
   } else {
     if ((rc = ensure(e->d_samples2, e->d_samples2_cap, dpitch * S)) != FSKHIP_OK) return rc;
@@ -792,18 +798,19 @@ int fskhip_demodulate_host(fskhip_engine *e, float *samples, size_t n, size_t pi
     for (size_t j = 0; off < n; j++) {
       // the last slab takes the remainder (up to 1.5 slabs would not be worth another round trip)
       const size_t len = (n - off > slab + slab / 2) ? slab : n - off;
-      if (len > dpitch) return fail(FSKHIP_E_INVALID, "internal: slab %zu exceeds staging pitch %zu", len, dpitch);
+      if (len + 3 > dpitch) return fail(FSKHIP_E_INVALID, "internal: slab %zu exceeds staging pitch %zu", len, dpitch);
       const int b = (int)(j & 1);
+      float *stg = buf[b] + shift();               // (the parity at this slab's start: slabs are multiples of 16 samples)
       if (j >= 2) PIPE_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_used_up[b], 0));   // its previous user has finished
-      PIPE_TRY(hipMemcpy2DAsync(buf[b], dpitch * sizeof(float), samples + off, pitch * sizeof(float), len * sizeof(float), S,
+      PIPE_TRY(hipMemcpy2DAsync(stg, dpitch * sizeof(float), samples + off, pitch * sizeof(float), len * sizeof(float), S,
                                hipMemcpyHostToDevice, e->copy_stream));
       PIPE_TRY(hipEventRecord(e->ev_copied[b], e->copy_stream));
       PIPE_TRY(hipStreamWaitEvent(e->stream, e->ev_copied[b], 0));
-      rc = demod_device_impl(e, buf[b], len, dpitch, e->d_out, out_pitch, e->d_counts, e->d_eod, flags, e->stream,
+      rc = demod_device_impl(e, stg, len, dpitch, e->d_out, out_pitch, e->d_counts, e->d_eod, flags, e->stream,
                              /*append_first=*/j > 0, /*count_call=*/j == 0);
       if (rc != FSKHIP_OK) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamSynchronize(e->stream); return rc; }
       if (wb)
-        PIPE_TRY(hipMemcpy2DAsync(samples + off, pitch * sizeof(float), buf[b], dpitch * sizeof(float), len * sizeof(float), S,
+        PIPE_TRY(hipMemcpy2DAsync(samples + off, pitch * sizeof(float), stg, dpitch * sizeof(float), len * sizeof(float), S,
                                  hipMemcpyDeviceToHost, e->stream));
       PIPE_TRY(hipEventRecord(e->ev_used_up[b], e->stream));
       off += len;

@@ -25,8 +25,11 @@ class FSKEngineSharded:
 
     def __init__(self, n_streams, configs=None, devices=None, precision=PRECISION_F32, engine_factory=None):
         if devices is None:
+            if engine_factory is not None:
+                # a stand-in engine (CPU tests of the sharding / gather logic): the HIP library is not touched at all
+                raise ValueError("pass `devices` together with an engine_factory")
             n_dev = int(_lib.lib().fskhip_device_count())
-            if n_dev <= 0 and engine_factory is None:
+            if n_dev <= 0:
                 # same loud failure as FSKEngine on a box without a GPU: there is no CPU path
                 FSKEngine(1, configs if not isinstance(configs, (list, tuple)) else configs[0])
             devices = list(range(max(n_dev, 1)))
