@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     float c1 = P.z_c1, c2 = P.z_c2, tiny = 0x1p-123f, rel = 3.7252902984619141e-09f;
     uint32_t sgn = 0x80000000u;
     asm volatile("" : "+v"(c1), "+v"(c2), "+v"(tiny), "+v"(rel), "+v"(sgn));
-    uint32_t qlive = __builtin_amdgcn_ballot_w64((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f)) ? 1u : 0u;
+    uint64_t qlive = __builtin_amdgcn_ballot_w64((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f));   // (raw masks: no bool round trips)
     uint32_t produced = 0, slot_i = 0;
     FSK_STAMP_BEGIN
     uint32_t hidx = 0;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         float ph[4], am[4];
         // one test for everything that is not the plain discriminator: a hand-over due in this half tile, a lane inside
         // the back wave's own span, a live correction
-        if (__builtin_expect((__builtin_amdgcn_ballot_w64((kq - 4u * hidx < 4u) | (ow < kHandPairs)) != 0) | (qlive != 0u), 0)) {
+        if (__builtin_expect((__builtin_amdgcn_ballot_w64((kq - 4u * hidx < 4u) | (ow < kHandPairs)) | qlive) != 0ull, 0)) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             if (kq == 4u * hidx + (uint32_t)j) {              // the back wave's correction becomes this wave's here
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
             const bool own = ow + (uint32_t)j < kHandPairs;
             ph[j] = own ? ui[j] : ph[j]; am[j] = own ? uq[j] : am[j];
           }
-          qlive = __builtin_amdgcn_ballot_w64((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f)) ? 1u : 0u;
+          qlive = __builtin_amdgcn_ballot_w64((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f));
         } else if (FSK_ABL(2)) {
 #pragma unroll
           for (int j = 0; j < 4; j++) { ph[j] = ui[j]; am[j] = uq[j]; }
@@ -596,9 +596,9 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         uint32_t bqn = bq, nqn = nq;
         const uint32_t rare = blk_fast(Bn, K, Q, X.kv, pa, rp, am, bqn, nqn);
         // (a live correction of this wave's, or the amplitude ring's wrap, make the block path void: ~3 % of the blocks)
-        const bool pre = (X.zlive != 0u) | amp_misaligned;
+        const uint64_t pre = (uint64_t)(X.zlive | (amp_misaligned ? 1u : 0u));
         FSK_STAMP_COUNT(0)                                    // blocks
-        if (__builtin_expect(((__builtin_amdgcn_ballot_w64((int32_t)rare < 0) != 0) | pre) & !FSK_ABL(3), 0)) { rare_exit = true; break; }
+        if (__builtin_expect(((__builtin_amdgcn_ballot_w64((int32_t)rare < 0) | pre) != 0ull) & !FSK_ABL(3), 0)) { rare_exit = true; break; }
         B = Bn; bq = bqn; nq = nqn;
         *reinterpret_cast<uint4 *>(prow + pidx) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
         *reinterpret_cast<uint4 *>(prow + pidx2) = make_uint4(rp[4], rp[5], rp[6], rp[7]);
