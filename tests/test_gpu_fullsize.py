@@ -62,7 +62,7 @@ def _digest(rows, eod):
     return zlib.crc32(per_stream.tobytes() + eod.astype(np.int64).tobytes())
 
 
-@pytest.mark.parametrize("S,seconds", [(65536, 1.0), (262144, 0.25)], ids=["c3_65536", "bench_262144"])
+@pytest.mark.parametrize("S,seconds", [(65536, 1.0), (81920, 0.5), (262144, 0.25)], ids=["c3_65536", "one_and_a_quarter_rounds_81920", "bench_262144"])
 def test_full_size_chunking_invariance_and_oracle_sample(S, seconds, monkeypatch):
     import webaudio_modem_amd as wm
     from oracle import pyoracle as po
@@ -78,7 +78,18 @@ def test_full_size_chunking_invariance_and_oracle_sample(S, seconds, monkeypatch
             schedule = [256]
         eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
         results[name] = _demod_schedule(eng, d_x, N, pitch, schedule)
+        if name == "one_call":
+            assert eng.last_kernel().endswith("true>" if S > 65536 else "false>"), eng.last_kernel()
         eng.close()
+    if S > 65536:
+        # beyond one round of resident workgroups the one-call launch is persistent and time-sliced (fsk_blk.hip); the same
+        # call with slicing off must give the same bytes
+        monkeypatch.setenv("FSKHIP_SLICE_TILES", "off")
+        eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+        results["one_call_unsliced"] = _demod_schedule(eng, d_x, N, pitch, [N])
+        assert eng.last_kernel().endswith("false>"), eng.last_kernel()
+        eng.close()
+        monkeypatch.delenv("FSKHIP_SLICE_TILES")
     base_rows, base_eod = results["one_call"]
     base_digest = _digest(base_rows, base_eod)
     for name, (rows, eod) in results.items():
@@ -194,6 +205,44 @@ def test_whole_tile_kernels_agree_on_ragged_batches(S, monkeypatch):
         eng.close()
     assert digests["split"] == digests["one_wave"] == digests["three_wave"] == digests["four_wave"] == digests["generic"], digests
     assert digests["split"][1] >= 12 * S * 0.5
+    gen.device_free(d_x)
+    gen.close()
+
+
+@pytest.mark.parametrize("S,resident,slice_tiles", [(1000, 5, 1), (1000, 3, 7), (4096, 16, 64), (4096, 63, 3)])
+def test_time_sliced_persistent_launch_matches_one_workgroup_per_group(S, resident, slice_tiles, monkeypatch):
+    """Batches beyond one round of resident workgroups run demod_blk_kernel persistently over (group, time slice) items
+    (fsk_blk.hip, BlkSched).  With the device "shrunk" to a few resident workgroups and slices as short as one tile (16
+    samples: shorter than every lag of the ZIR hand-over), bytes and eod counts must equal the plain launch's for every
+    stream, under a ragged call schedule, and the state handed to the next call must be the same (the second half of the
+    buffer goes through the per-sample kernels of an odd-length schedule)."""
+    import webaudio_modem_amd as wm
+    N = 48000
+    gen = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    d_x = gen.device_malloc(S * N * 4)
+    gen.synth_device(d_x, N, N, 12, SEED + 7, 300, 0.1, 1.0)
+    gen.synchronize()
+    digests = {}
+    for name, env in (("plain", {"FSKHIP_SLICE_TILES": "off"}),
+                      ("sliced", {"FSKHIP_BLK_RESIDENT": str(resident), "FSKHIP_SLICE_TILES": str(slice_tiles)})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+        for k in env:
+            monkeypatch.delenv(k)
+        d_out = eng.device_malloc(S * eng.max_bytes(20000))
+        d_cnt = eng.device_malloc(S * 4)
+        d_eod = eng.device_malloc(S * 4)
+        eng.demodulate_device(d_x, 1600, N, d_out, eng.max_bytes(20000), d_cnt, d_eod)
+        eng.synchronize()
+        assert eng.last_kernel().endswith("true>" if name == "sliced" else "false>"), (name, eng.last_kernel())
+        rows, eod = _demod_schedule(eng, d_x + 1600 * 4, N - 1600, N, [20000, 4096, 16, 1000, 48, 999, 8000])
+        digests[name] = (_digest(rows, eod), sum(len(r) for r in rows))
+        for p_ in (d_out, d_cnt, d_eod):
+            eng.device_free(p_)
+        eng.close()
+    assert digests["plain"] == digests["sliced"], digests
+    assert digests["plain"][1] >= 12 * S * 0.4
     gen.device_free(d_x)
     gen.close()
 
@@ -510,7 +559,7 @@ def test_config4_full_length_480000_samples():
     kernel, nbytes = _full_length_check(
         32768, lambda s: dict(baudRate=300, markFrequency=1000 + 10 * (s % 100), spaceFrequency=1200 + 10 * (s % 100)),
         480000, 16, 1600, 12, 48000)
-    assert "demod_blk_kernel<false, false>" in kernel      # the per-stream-constant instantiation
+    assert "demod_blk_kernel<false, false," in kernel      # the per-stream-constant instantiation
     assert nbytes >= 32768 * 16 * 6
 
 

@@ -98,7 +98,7 @@ for spec in sys.argv[3:]:
         env[k] = v
     lib = os.path.join(ROOT, "tools", "build", "libfskhip_%s.so" % tag) if tag else "-"
     try:
-        r = subprocess.run([sys.executable, "-c", CHILD, str(S), str(N), lib], env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, "-c", CHILD, str(S), str(N), lib], env=env, capture_output=True, text=True, timeout=int(os.environ.get("VAR_TIMEOUT", "300")))
     except subprocess.TimeoutExpired:
         print("%-28s TIMEOUT" % label, flush=True); continue
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]

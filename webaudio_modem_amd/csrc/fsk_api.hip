@@ -43,7 +43,9 @@ bool demod_blk_applicable(const DemodParams &P);
 hipError_t set_blk_lds_limit(const DemodParams &P);
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
-                             uint32_t *eod_counts, hipStream_t stream);
+                             uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, bool *sliced_out);
+uint32_t demod_blk_resident_wgs(const DemodParams &P, int device);
+size_t demod_blk_queue_words(uint32_t groups);
 hipError_t set_pipe_lds_limit(size_t pipe_bytes);
 hipError_t set_demod_lds_limit(size_t lds_bytes);
 size_t demod_lds_bytes(const DemodParams &P);
@@ -172,6 +174,9 @@ struct fskhip_engine {
   bool use_split3 = false;       // three waves per group (demod_pipe3_kernel): at most two groups per CU
   bool use_blk = true;          // four waves per group with the block-batched back wave (demod_blk_kernel, fsk_blk.hip): the default
                                  // wherever it applies (dsSPB a multiple of 4, >= 8); FSKHIP_SPLIT = 0 / 1 / 3 pins an older kernel
+  uint32_t blk_resident = 0;     // workgroups of demod_blk_kernel the device holds at once; larger batches run it persistent, in time slices
+  uint32_t blk_slice_tiles = 0;  // FSKHIP_SLICE_TILES: tiles per time slice (0 = the kernel file's default, "off" = never slice)
+  bool last_sliced = false;
   uint64_t pushes = 0;           // decimated samples since create (lock-step engines): the amplitude ring's write position
   bool gen_odd = false;          // fp32: the last generic-kernel launch left a decimator pair open (its partial sums are in
                                  // the reference's frame, the whole-tile kernels' in the free-running one)
@@ -300,7 +305,7 @@ int fskhip_destroy(fskhip_engine *e) {
   (void)hipDeviceSynchronize();
   void *bufs[] = {e->S.rs, e->S.is, e->S.poly, e->S.amp_ring, (void *)e->S.coef, (void *)e->S.nco_inc, e->d_samples,
                   e->d_samples2, e->d_out, e->d_counts, e->d_eod, e->d_lens, e->d_payloads, e->d_status, e->d_sigma,
-                  e->S.trace_amp, e->S.trace_post, e->S.trace_bit, e->S.trace_n, e->S.poly_u, e->S.cu_ctr};
+                  e->S.trace_amp, e->S.trace_post, e->S.trace_bit, e->S.trace_n, e->S.poly_u, e->S.cu_ctr, e->S.blk_q};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (auto ev : e->ev) (void)hipEventDestroy(ev);
@@ -593,7 +598,15 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   if (e->demod_ok && e->lds_bytes > 48 * 1024) CREATE_TRY(set_demod_lds_limit(e->lds_bytes));
   if (e->demod_ok && !P.wide && !P.frac && precision == FSKHIP_PRECISION_F32 && demod_pipe_lds_bytes(P) <= 160 * 1024)
     CREATE_TRY(set_pipe_lds_limit(demod_pipe_lds_bytes(P)));
-  if (e->demod_ok && precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(P)) CREATE_TRY(set_blk_lds_limit(P));
+  if (e->demod_ok && precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(P)) {
+    CREATE_TRY(set_blk_lds_limit(P));
+    e->blk_resident = demod_blk_resident_wgs(P, device);
+    if (const char *rw = getenv("FSKHIP_BLK_RESIDENT")) e->blk_resident = (uint32_t)strtoul(rw, nullptr, 10);   // tests: a "device" this small
+    if (const char *sl = getenv("FSKHIP_SLICE_TILES")) e->blk_slice_tiles = sl[0] == 'o' ? 0xFFFFFFFFu : (uint32_t)strtoul(sl, nullptr, 10);
+    if (e->blk_resident && e->n_blocks > e->blk_resident) {
+      CREATE_TRY(hipMalloc((void **)&e->S.blk_q, sizeof(uint32_t) * demod_blk_queue_words(e->n_blocks)));
+    }
+  }
   e->S.trace_stream = 0xFFFFFFFFu;
 #undef CREATE_TRY
   e->base_calls.assign(n_streams, 0);
@@ -687,9 +700,14 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
         // multiple of four (it is unless earlier calls had odd lengths: those calls then stay with the per-sample kernels)
         const bool quad_aligned = ((e->pushes + ((p0 + head) >> 1)) & 3u) == 0u;
         if (e->use_blk && demod_blk_applicable(e->P) && blk_lds <= 160 * 1024 && (quad_aligned || e->split_forced)) {
-          HIP_TRY(launch_demod_blk(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
-          e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_blk_kernel<true, true>" : "fsk::demod_blk_kernel<true, false>")
-                              : (e->P.uni_cfg ? "fsk::demod_blk_kernel<false, true>" : "fsk::demod_blk_kernel<false, false>");
+          HIP_TRY(launch_demod_blk(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
+                                   e->blk_resident, e->blk_slice_tiles, &e->last_sliced));
+          static const char *const names[8] = {
+              "fsk::demod_blk_kernel<false, false, false>", "fsk::demod_blk_kernel<false, false, true>",
+              "fsk::demod_blk_kernel<false, true, false>", "fsk::demod_blk_kernel<false, true, true>",
+              "fsk::demod_blk_kernel<true, false, false>", "fsk::demod_blk_kernel<true, false, true>",
+              "fsk::demod_blk_kernel<true, true, false>", "fsk::demod_blk_kernel<true, true, true>"};
+          e->last_kernel = names[(wb ? 4 : 0) + (e->P.uni_cfg ? 2 : 0) + (e->last_sliced ? 1 : 0)];   // <writeback, uniform, time-sliced>
         } else if (two_wave && e->use_split3 && pipe3_lds <= 160 * 1024 && (wgs_per_cu * pipe3_lds <= 160 * 1024 || e->split_forced)) {
           HIP_TRY(launch_demod_pipe3(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
           e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_pipe3_kernel<true, true>" : "fsk::demod_pipe3_kernel<true, false>")

@@ -168,11 +168,33 @@ __device__ inline void blk_prio(uint32_t hidx, uint32_t wgj) {
 #endif
 }
 
-template <bool WB, bool UNI>
+// Time slices.  One workgroup per group fills the chip only in whole rounds of (workgroups resident at once) = 4 per CU:
+// at 81 920 streams the second round runs a quarter full and the launch takes as long as 131 072 streams do.  Above one
+// round the launch is therefore PERSISTENT: as many workgroups as fit, each taking (group, time slice) items from one
+// queue in device memory -- slice 0 of every group first, in group order, then slices in the order their predecessors
+// finished (a group's slices are strictly sequential: its state travels through the state arrays exactly as it does
+// between two launches; its chain of slices is as long as the group's whole time, so every group must start early).  A
+// workgroup that completes slice s of a group pushes slice s + 1 behind the queue's tail; a popper whose entry has not
+// been pushed yet waits for it (the pusher is running and never waits, so this cannot lock up).
+// Coherence.  A group's next slice may run on another XCD, behind another L2.  Everything a slice hands on -- state
+// arrays, polyphase registers, amplitude ring, output counts -- is therefore written and read with device-scope cache
+// policy (sc1: kCoh, fsk_dev.h; stores write through, loads take no cached copy) and the push waits for the stores'
+// completion (vmcnt); no cache-wide write-back or invalidate is needed.  (An agent-scope release / acquire fence pair per
+// slice was measured first: buffer_wbl2 with the amplitude ring's dirty lines in L2 cost ~70 us per slice; queues
+// private to an XCD avoid it too but balance worse: profiles/r03_slices.txt.)
+struct BlkSched {
+  uint32_t *q;                   // [0] head, [1] tail, [16 + j] pushed entries: 1 << 31 | slice << 20 | group
+  uint32_t groups;               // 64-stream groups
+  uint32_t nslices;              // per group
+  uint32_t slice_tiles;          // tiles per slice (the last one may be shorter)
+  uint32_t total;                // groups * nslices
+};
+
+template <bool WB, bool UNI, bool SL>
 __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
-    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch, int append,
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n_call, size_t pitch, int append_call,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
-    uint32_t *__restrict__ eod_counts) {
+    uint32_t *__restrict__ eod_counts, BlkSched Z) {
   FSK_ABL_INIT
   FSK_STAMP_DECL
   extern __shared__ float4 lds[];
@@ -183,23 +205,14 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
   v4f *fin = ring + kBlkSlots * kBlkSlotV4;               // [0..1] wave 1's final I/Q low-pass state, [2] wave 2's final correction
   v4f *zt = fin + 3 * 64;
   uint32_t *poly = reinterpret_cast<uint32_t *>(zt + 4 * 8);   // [lane][PS], index 0 = the phase of the launch's first push
-  uint32_t *ctr = poly + 64u * PS;                        // produced by wave 0, 1, 2 | consumed by wave 3
+  uint32_t *ctr = poly + 64u * PS;                        // produced by wave 0, 1, 2 | consumed by wave 3 | [4] CU arrival | [5] item
   uint32_t *zmail = ctr + 8;                              // back -> wave 1: where to zero a lane's I/Q low-pass
   uint32_t *cmail = zmail + 64;                           // back -> wave 2: [0] from which decimated sample, [1..4] the correction there,
                                                           // [5] since which sample the back wave wants a lane's pair sums kept
-  uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
-
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t stream = blockIdx.x * 64u + lane;
-  const PipeCtx C = pipe_ctx(P, S, stream);
-  const size_t n_tiles = n / kFastTile;
-  const uint32_t nh = 2u * (uint32_t)n_tiles;               // half tiles = blocks
-  const uint64_t inc = UNI ? (((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo) : S.nco_inc[C.row4 >> 2];
-  const uint64_t free0 = pipe_free0<UNI>(C);
 
   if (threadIdx.x == 0) {
-    ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0;
     // Which wave plays which part.  A workgroup's four waves sit on the CU's four SIMDs (one each, in cyclic order from a
     // varying start); four workgroups share a CU at BASELINE config #3's size.  If the part followed the wave index, some
     // SIMDs would host three or four back waves and their groups would set the kernel's time (measured: 198 .. 295
@@ -210,6 +223,52 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     const uint32_t key = (xcc << 8) | ((hw >> 8) & 0xFFu);
     ctr[4] = __hip_atomic_fetch_add(&S.cu_ctr[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  __syncthreads();
+  const uint32_t simd = (__builtin_amdgcn_s_getreg(0xF804) >> 4) & 3u;
+  const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)((simd + ctr[4]) & 3u));
+  const uint32_t wgj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ctr[4] & 3u));
+
+  uint32_t push_e = 0;             // the entry to put behind the queue's tail: the slice after the one just completed
+#pragma unroll 1
+  for (;;) {
+  // ---- this workgroup's next item: group grp, tiles [t_begin, t_begin + n_tiles) of the call
+  uint32_t grp = blockIdx.x, t_begin = 0, slice = 0;
+  if (SL) {
+    // (push and pop in ONE divergent region inside the iteration: split across the loop's back edge, the compiler ran
+    // lane 0's part after the other lanes' barrier)
+    if (wave == 0 && lane == 0) {
+      if (push_e != 0u) {
+        const uint32_t j = __hip_atomic_fetch_add(&Z.q[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&Z.q[16u + j], push_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const uint32_t i = __hip_atomic_fetch_add(&Z.q[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t e = 0xFFFFFFFFu;
+      if (i < Z.groups) e = i;
+      else if (i < Z.total) {
+        const uint32_t *slot = &Z.q[16u + (i - Z.groups)];
+        while ((e = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(8);
+        e &= 0x7FFFFFFFu;
+      }
+      ctr[5] = e;
+    }
+    __syncthreads();
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctr[5]);
+    if (e == 0xFFFFFFFFu) return;
+    grp = e & 0xFFFFFu; slice = e >> 20;
+    t_begin = slice * Z.slice_tiles;
+  }
+  const size_t n_tiles = SL ? (size_t)((uint32_t)(n_call / kFastTile) - t_begin < Z.slice_tiles ? (uint32_t)(n_call / kFastTile) - t_begin : Z.slice_tiles)
+                            : n_call / kFastTile;
+  const size_t n = n_tiles * kFastTile;
+  const int append = (SL && slice != 0u) ? 1 : append_call;
+  uint32_t *gpoly = (uint32_t *)S.poly + (size_t)grp * P.d * 64u;
+  const uint32_t stream = grp * 64u + lane;
+  const PipeCtx C = pipe_ctx(P, S, stream);
+  const uint32_t nh = 2u * (uint32_t)n_tiles;               // half tiles = blocks
+  const uint64_t inc = UNI ? (((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo) : S.nco_inc[C.row4 >> 2];
+  const uint64_t free0 = pipe_free0<UNI>(C);
+
+  if (threadIdx.x == 0) { ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; }
   if (wave == 1) {
     const FastMem &M = C.M;
     const uint32_t fld = C.fld, row4 = C.row4;
@@ -239,9 +298,6 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     cmail[320u + lane] = 0u - dph;                          // (dph >= kHandPairs: the span is over)
   }
   __syncthreads();
-  const uint32_t simd = (__builtin_amdgcn_s_getreg(0xF804) >> 4) & 3u;
-  const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)((simd + ctr[4]) & 3u));
-  const uint32_t wgj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ctr[4] & 3u));
 
   if (role == 0) {
     // ------------------------------------------------------------------------------ loads, AGC, pre-filter
@@ -249,10 +305,10 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     FrontK K;
     front_load<UNI>(F, K, P, S, C);
     const uint32_t sub_row = lane >> 2, chunk = lane & 3;
-    const uint32_t rows_here = P.n_streams - blockIdx.x * 64u < 64u ? P.n_streams - blockIdx.x * 64u : 64u;
+    const uint32_t rows_here = P.n_streams - grp * 64u < 64u ? P.n_streams - grp * 64u : 64u;
     v4i in_rsrc;
     {
-      const uint64_t base = reinterpret_cast<uint64_t>(samples + (size_t)blockIdx.x * 64u * pitch);
+      const uint64_t base = reinterpret_cast<uint64_t>(samples + (size_t)grp * 64u * pitch);
       in_rsrc.x = (int)(uint32_t)base;
       in_rsrc.y = (int)(uint32_t)(base >> 32);
       in_rsrc.z = (int)(uint32_t)(rows_here * pitch * 4u);
@@ -266,7 +322,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(in_voff + (rows16) * in_row16), \
                "s"(in_rsrc), "s"(soff) : "memory")
     auto load_tile = [&](size_t t, v4f &a, v4f &b, v4f &c, v4f &d) {
-      const uint32_t tn = (uint32_t)((t < n_tiles ? t : n_tiles - 1) * kFastTile * 4u);
+      const uint32_t tn = (uint32_t)((t_begin + (t < n_tiles ? t : n_tiles - 1)) * kFastTile * 4u);
       BLK_BLOAD4(a, 0u, tn); BLK_BLOAD4(b, 1u, tn); BLK_BLOAD4(c, 2u, tn); BLK_BLOAD4(d, 3u, tn);
     };
     v4f a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
@@ -319,7 +375,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
           slot[cc * 64u + lane] = (v4f){y[0], y[1], y[2], y[3]};
           if (WB) {
             if (C.valid)
-              *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + (size_t)t * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
+              *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + (size_t)(t_begin + t) * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
           }
         }
         lds_post(&ctr[0], hidx + hf + 1u);
@@ -541,7 +597,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     {
       uint32_t ph = phase0;
       for (uint32_t i = 0; i < P.d; i++) {                    // rotate: LDS index 0 = the register of the first push
-        poly[lane * PS + i] = gpoly[ph * 64u + lane];
+        poly[lane * PS + i] = __hip_atomic_load(&gpoly[ph * 64u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ph = ph + 1u == P.d ? 0u : ph + 1u;
       }
     }
@@ -606,10 +662,10 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
           uint32_t q2 = X.amp_soff + amp_quad_bytes; q2 = q2 == amp_wrap ? 0u : q2;
           __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, am[0]), __builtin_bit_cast(uint32_t, am[1]),
                                                         __builtin_bit_cast(uint32_t, am[2]), __builtin_bit_cast(uint32_t, am[3])},
-                                                 amp_rsrc, M.avoff, X.amp_soff, 0);
+                                                 amp_rsrc, M.avoff, X.amp_soff, SL ? kCoh : 0);
           __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, am[4]), __builtin_bit_cast(uint32_t, am[5]),
                                                         __builtin_bit_cast(uint32_t, am[6]), __builtin_bit_cast(uint32_t, am[7])},
-                                                 amp_rsrc, M.avoff, q2, 0);
+                                                 amp_rsrc, M.avoff, q2, SL ? kCoh : 0);
           X.amp_soff = q2 + amp_quad_bytes; X.amp_soff = X.amp_soff == amp_wrap ? 0u : X.amp_soff;
         }
         X.k += (uint32_t)kBlk; X.kv += (uint32_t)kBlk;
@@ -673,12 +729,18 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     {
       uint32_t ph = phase0;
       for (uint32_t i = 0; i < P.d; i++) {
-        gpoly[ph * 64u + lane] = poly[lane * PS + i];
+        __hip_atomic_store(&gpoly[ph * 64u + lane], poly[lane * PS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ph = ph + 1u == P.d ? 0u : ph + 1u;
       }
     }
     const uint32_t phase_end = (phase0 + X.k) % P.d;
     pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, phase_end, amp_pos_of(X.amp_soff, amp_quad_bytes), inc, free0);
+  }
+  if (!SL) return;
+  // ---- the group's next slice goes behind the queue's tail once this one's state is in memory (pushed at the loop's top)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  push_e = slice + 1u < Z.nslices ? 0x80000000u | ((slice + 1u) << 20) | grp : 0u;
   }
 }
 
@@ -694,13 +756,23 @@ hipError_t set_blk_lds_limit(const DemodParams &P) {
   hipError_t e = hipSuccess;
   const size_t bytes = demod_blk_lds_bytes(P);
   if (bytes > 160 * 1024) return hipSuccess;
-#define FSK_ATTR(WBV, UNIV)                                                                                      \
+#define FSK_ATTR(WBV, UNIV, SLV)                                                                                 \
   if (e == hipSuccess)                                                                                           \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk_kernel<WBV, UNIV>),                       \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk_kernel<WBV, UNIV, SLV>),                  \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  FSK_ATTR(false, false) FSK_ATTR(false, true) FSK_ATTR(true, false) FSK_ATTR(true, true)
+  FSK_ATTR(false, false, false) FSK_ATTR(false, true, false) FSK_ATTR(true, false, false) FSK_ATTR(true, true, false)
+  FSK_ATTR(false, false, true) FSK_ATTR(false, true, true) FSK_ATTR(true, false, true) FSK_ATTR(true, true, true)
 #undef FSK_ATTR
   return e;
+}
+
+// workgroups of the block kernel the device holds at once (one round); 0 if it cannot tell
+uint32_t demod_blk_resident_wgs(const DemodParams &P, int device) {
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&demod_blk_kernel<false, true, true>), 256,
+                                                   demod_blk_lds_bytes(P)) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+  return per_cu > 0 && cus > 0 ? (uint32_t)per_cu * (uint32_t)cus : 0u;
 }
 
 #ifdef FSK_ABLATE
@@ -713,18 +785,46 @@ static void set_ablate_blk() {
 static inline void set_ablate_blk() {}
 #endif
 
+// Time slices (see BlkSched): only when the batch needs more than one round of resident workgroups and the call is long
+// enough for at least two slices.  slice_tiles = 0 picks kBlkSliceTiles (or what keeps a group within kBlkMaxSlices).
+static constexpr uint32_t kBlkSliceTiles = 768;    // 12 288 samples
+static constexpr uint32_t kBlkMaxSlices = 128;
+size_t demod_blk_queue_words(uint32_t groups) { return 16u + (size_t)groups * (kBlkMaxSlices - 1u); }
+
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
-                             uint32_t *eod_counts, hipStream_t stream) {
+                             uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, bool *sliced_out) {
   const uint32_t blocks = (P.n_streams + 63u) / 64u;
   const size_t lds = demod_blk_lds_bytes(P);
   set_ablate_blk();
-#define FSK_LAUNCH_BLK(WBV, UNIV)                                                                          \
-  hipLaunchKernelGGL((demod_blk_kernel<WBV, UNIV>), dim3(blocks), dim3(256), lds, stream, P, S, samples, n, pitch, \
-                     append ? 1 : 0, out, out_pitch, out_counts, eod_counts)
+  BlkSched Z = {nullptr, blocks, 1u, 0u, 0u};
+  const uint32_t n_tiles = (uint32_t)(n / kFastTile);
+  bool sliced = false;
+  if (S.blk_q && resident_wgs && blocks > resident_wgs && blocks < (1u << 20) && slice_tiles != 0xFFFFFFFFu) {
+    uint32_t st = slice_tiles ? slice_tiles : kBlkSliceTiles;
+    const uint32_t st_min = (n_tiles + kBlkMaxSlices - 1u) / kBlkMaxSlices;
+    st = st < st_min ? st_min : st;
+    const uint32_t ns = (n_tiles + st - 1u) / st;
+    if (ns >= 2u) {
+      sliced = true;
+      Z.q = S.blk_q; Z.nslices = ns; Z.slice_tiles = st; Z.total = blocks * ns;
+      const hipError_t e = hipMemsetAsync(S.blk_q, 0, sizeof(uint32_t) * (16u + (size_t)blocks * (ns - 1u)), stream);
+      if (e != hipSuccess) return e;
+    }
+  }
+  if (sliced_out) *sliced_out = sliced;
+  const uint32_t grid = sliced ? resident_wgs : blocks;
+#define FSK_LAUNCH_BLK(WBV, UNIV, SLV)                                                                          \
+  hipLaunchKernelGGL((demod_blk_kernel<WBV, UNIV, SLV>), dim3(grid), dim3(256), lds, stream, P, S, samples, n, pitch, \
+                     append ? 1 : 0, out, out_pitch, out_counts, eod_counts, Z)
   const bool uni = P.uni_cfg != 0;
-  if (writeback) { if (uni) FSK_LAUNCH_BLK(true, true); else FSK_LAUNCH_BLK(true, false); }
-  else { if (uni) FSK_LAUNCH_BLK(false, true); else FSK_LAUNCH_BLK(false, false); }
+  if (sliced) {
+    if (writeback) { if (uni) FSK_LAUNCH_BLK(true, true, true); else FSK_LAUNCH_BLK(true, false, true); }
+    else { if (uni) FSK_LAUNCH_BLK(false, true, true); else FSK_LAUNCH_BLK(false, false, true); }
+  } else {
+    if (writeback) { if (uni) FSK_LAUNCH_BLK(true, true, false); else FSK_LAUNCH_BLK(true, false, false); }
+    else { if (uni) FSK_LAUNCH_BLK(false, true, false); else FSK_LAUNCH_BLK(false, false, false); }
+  }
 #undef FSK_LAUNCH_BLK
   return hipGetLastError();
 }

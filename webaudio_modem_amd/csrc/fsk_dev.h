@@ -13,6 +13,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 static constexpr int kFastTile = 16;
+// Cache policy of every access to what one launch -- or one time slice of a persistent launch (fsk_blk.hip), possibly on
+// another XCD with another L2 -- hands to the next: sc1 = coherent at device scope (stores write through, loads do not
+// take a cached copy).  These are launch-start / launch-end / rare-path accesses; the per-sample traffic does not use it.
+static constexpr int kCoh = 16;
 static constexpr uint32_t kStarted = 0xFFFFFFFFu;  // thr_eff while a frame is started (matched_min is <= 0xFFFFFFFE)
 
 __device__ inline uint32_t popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
@@ -93,10 +97,10 @@ __device__ inline void amp_advance(uint32_t &soff, uint32_t quad_bytes, uint32_t
   if ((soff & 12u) == 0u) { soff += quad_bytes - 16u; if (soff == wrap) soff = 0u; }
 }
 __device__ inline uint32_t ist_load(const FastMem &M, uint32_t field) {
-  return __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, M.voff, field * M.fld, 0);
+  return __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, M.voff, field * M.fld, kCoh);
 }
 __device__ inline void ist_store(const FastMem &M, uint32_t field, uint32_t v) {
-  __builtin_amdgcn_raw_buffer_store_b32(v, M.is_rsrc, M.voff, field * M.fld, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(v, M.is_rsrc, M.voff, field * M.fld, kCoh);
 }
 
 

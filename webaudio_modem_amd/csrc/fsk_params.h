@@ -151,6 +151,7 @@ struct DemodState {
   uint32_t trace_cap;
   uint32_t trace_stream;  // 0xFFFFFFFF = off
   uint32_t *cu_ctr;       // u32 [2048]: workgroups started per compute unit (fsk_blk.hip spreads its waves' roles with it)
+  uint32_t *blk_q;        // u32 [16 + groups * 127] or null: fsk_blk.hip's (group, time slice) queue for batches beyond one round
 };
 
 struct ModParams {

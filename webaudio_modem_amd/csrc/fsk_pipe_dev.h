@@ -430,7 +430,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   *pslot = r;                                                  // (the polyphase register of this push slot)
   B.matched += (uint32_t)__builtin_popcount((r ^ qn) & mask);
   B.matched -= (uint32_t)__builtin_popcount((r_old ^ qn) & mask);
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, M.avoff, X.amp_soff, 0);  // syncAmplitudeBuffer.put
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, M.avoff, X.amp_soff, kCoh);  // syncAmplitudeBuffer.put
   {
     const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, amp - B.thr));   // amp < threshold (fsk.ts:285)
     B.ls = (B.ls & silent) | (X.kv & ~silent);                 // silence run = k - ls (fsk.ts:285-295)
@@ -454,7 +454,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
       }
       if (eod) {
         ist_store(M, IF_eod_total, ist_load(M, IF_eod_total) + 1u);
-        if (eod_counts && M.voff < 0xFFFFFFF0u) eod_counts[M.voff >> 2] += 1u;
+        if (eod_counts && M.voff < 0xFFFFFFF0u) __hip_atomic_fetch_add(&eod_counts[M.voff >> 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         back_reset<UNI>(B, P, M, X, inc, lane);
       }
       X.direct = kDirectPairs; X.zlive = 1u;                   // (wave-uniform: set where the wave-uniform branch is)
@@ -540,10 +540,10 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
 }
 
 // ---- state arrays <-> registers ------------------------------------------------------------------------------
-#define PIPE_RLOAD(f) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rsrc, row4, (uint32_t)RF_##f * fld, 0))
-#define PIPE_ILOAD(f) __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, row4, (uint32_t)IF_##f * fld, 0)
-#define PIPE_RSTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)(v)), rs_rsrc, M.voff, (uint32_t)RF_##f * fld, 0)
-#define PIPE_ISTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(v), M.is_rsrc, M.voff, (uint32_t)IF_##f * fld, 0)
+#define PIPE_RLOAD(f) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rsrc, row4, (uint32_t)RF_##f * fld, kCoh))
+#define PIPE_ILOAD(f) __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, row4, (uint32_t)IF_##f * fld, kCoh)
+#define PIPE_RSTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)(v)), rs_rsrc, M.voff, (uint32_t)RF_##f * fld, kCoh)
+#define PIPE_ISTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(v), M.is_rsrc, M.voff, (uint32_t)IF_##f * fld, kCoh)
 #define PIPE_CLOAD(f) (__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cf_rsrc, row4 * 2u, (uint32_t)(f) * fld * 2u, 0)))
 
 struct PipeCtx {   // descriptors and offsets both halves use
@@ -644,8 +644,8 @@ __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, co
   }
   if (B.thr_eff != kStartedP) { B.T = kBigWait; B.tlast = B.T - PIPE_ILOAD(bit_reload); }  // (re)park: decisions imply a started frame
   // append: a preceding launch of the same call (head samples up to a pair / 16-byte boundary) has produced output already
-  B.out_cnt = (append && C.valid) ? out_counts[stream] : 0u;
-  if (!append && C.valid && eod_counts) eod_counts[stream] = 0;  // incremented in memory by the (rare) EOD path
+  B.out_cnt = (append && C.valid) ? __hip_atomic_load(&out_counts[stream], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  if (!append && C.valid && eod_counts) __hip_atomic_store(&eod_counts[stream], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // incremented in memory by the (rare) EOD path
   if (!C.valid) {
     // Lanes beyond the batch run on zeros with a copy of the last stream's state.  Park them: no sync candidate (a
     // threshold `matched` cannot reach), no silence run (nothing is below a negative threshold), no bit clock -- so
@@ -708,7 +708,7 @@ __device__ inline void pipe_store(const FrontLane &F, bool store_front, const Ba
   PIPE_ISTORE(amp_len, al < P.amp_cap ? al : P.amp_cap);
   PIPE_ISTORE(poly_phase, phase);
   PIPE_ISTORE(amp_pos, amp_pos);
-  if (C.valid) out_counts[stream] = B.out_cnt;
+  if (C.valid) __hip_atomic_store(&out_counts[stream], B.out_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // wave-uniform LDS word, polled by the other wave of the workgroup
