@@ -166,3 +166,6 @@ def test_whole_tile_kernels_never_spill():
     assert check_isa.prefetch_register_hazards() == []
     assert check_isa.pipe_prefetch_hazards() == []
     assert check_isa.pipe_prefetch_hazards(r"_ZN3fsk18demod_pipe3_kernel") == []
+    # the four-wave block kernel (fsk_blk.hip): within 128 VGPRs, no scratch access inside the per-tile loops, the
+    # asynchronous hand-off counter read's registers untouched until a wait covers it
+    assert check_isa.blk_checks() == []

@@ -79,7 +79,8 @@ def test_full_size_chunking_invariance_and_oracle_sample(S, seconds, monkeypatch
         eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
         results[name] = _demod_schedule(eng, d_x, N, pitch, schedule)
         if name == "one_call":
-            assert eng.last_kernel().endswith("true>" if S > 65536 else "false>"), eng.last_kernel()
+            # (time slices only beyond one round of resident workgroups and for calls of at least two default slices)
+            assert eng.last_kernel().endswith("true>" if S > 65536 and N // 16 > 768 else "false>"), eng.last_kernel()
         eng.close()
     if S > 65536:
         # beyond one round of resident workgroups the one-call launch is persistent and time-sliced (fsk_blk.hip); the same

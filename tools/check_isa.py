@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static check of the compiled whole-tile demod kernels of fsk_pipe.hip (runs anywhere hipcc is installed, no GPU):
+"""Static check of the compiled whole-tile demod kernels of fsk_pipe.hip and fsk_blk.hip (runs anywhere hipcc is installed, no GPU):
 the one-wave kernel's tile prefetch uses inline-asm loads whose results are only valid after a hand-placed s_waitcnt, so
 the register allocator must never spill inside that kernel (a spill store of an in-flight load result
 would save garbage); the one-wave kernel must fit 168 VGPRs (3 waves per SIMD), the two-wave kernel 128."""
@@ -163,8 +163,84 @@ def pipe_prefetch_hazards(symbol=r"_ZN3fsk17demod_pipe_kernel"):
     return problems
 
 
+def blk_checks():
+    """fsk_blk.hip (four waves per group): eight kernel bodies (<write-back, uniform, time-sliced>), each within 128
+    VGPRs (four workgroups per CU).  The kernel is built with __launch_bounds__(256, 4) and spills in its set-up and in the
+    per-sample slow path; the loops that run per tile must not: every block of the innermost loop around each of the four
+    parts' asynchronous counter read (lds_peek4_begin: an asm ds_read_b128) has to be free of scratch instructions.  And
+    the registers that read lands in must not be touched before a wait that covers it (lgkmcnt(0))."""
+    src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_blk.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        asm = os.path.join(tmp, "d.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+                        "-S", "--cuda-device-only", "-o", asm, src], capture_output=True, text=True, check=True)
+        text = open(asm).read()
+
+    def regs_of(line):
+        out = set()
+        for m in re.finditer(r"v\[(\d+):(\d+)\]", line):
+            out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bv(\d+)\b", line):
+            out.add(int(m.group(1)))
+        return out
+
+    problems = []
+    found = list(re.finditer(r"^(_ZN3fsk16demod_blk_kernel\w+):[^\n]*\n", text, re.M))
+    if len(found) != 8:
+        problems.append(("demod_blk_kernel", "expected 8 kernel bodies in the ISA, found %d" % len(found)))
+    for name, n in re.findall(r"\.name:\s+(_ZN3fsk16demod_blk_kernel\w+)\s*\n(?:[^\n]*\n)*?\s+\.vgpr_count:\s+(\d+)", text):
+        if int(n) > 128:
+            problems.append((name, "%s VGPRs: more than four workgroups per CU allow" % n))
+    for m in found:
+        body = text[m.end():text.index(".Lfunc_end", m.end())].split("\n")
+        # basic blocks with the innermost loop each belongs to (the asm printer's comments on the label)
+        blocks, cur = [], None
+        for i, l in enumerate(body):
+            ml = re.match(r"\s*(\.LBB\d+_\d+):(.*)$", l)
+            if ml:
+                cur = {"name": ml.group(1), "start": i, "lines": [], "note": ml.group(2)}
+                blocks.append(cur)
+                continue
+            if cur is None:
+                continue
+            st = l.strip()
+            if st.startswith(";") and not cur["lines"]:
+                cur["note"] += " " + st
+            elif st and not st.startswith(";") and not st.startswith("."):
+                cur["lines"].append((i, st))
+        for b in blocks:
+            mh = re.search(r"This (?:Inner )?Loop Header: Depth=(\d+)", b["note"])
+            mi = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", b["note"])
+            b["loop"] = (b["name"][2:], int(mh.group(1))) if mh else ((mi.group(1), int(mi.group(2))) if mi else None)
+        peeks = 0
+        for b in blocks:
+            for k, (i, st) in enumerate(b["lines"]):
+                if not (st.startswith("ds_read_b128") and "ASMSTART" in body[i - 1]):
+                    continue
+                peeks += 1
+                if b["loop"] is None:
+                    problems.append((m.group(1), "counter read outside any loop: " + st))
+                    continue
+                for o in blocks:
+                    if o["loop"] == b["loop"] and any(x.startswith("scratch_") for _, x in o["lines"]):
+                        problems.append((m.group(1), "scratch access in a per-tile loop, block %s" % o["name"]))
+                dst = regs_of(st.split(",")[0])
+                for j in range(i + 1, min(len(body), i + 600)):
+                    line = body[j].strip()
+                    if not line or line.startswith(";") or line.startswith("."):
+                        continue
+                    if "s_waitcnt" in line and "lgkmcnt(0)" in line:
+                        break
+                    if regs_of(line) & dst:
+                        problems.append((m.group(1), "counter read's registers touched before a wait: " + line))
+                        break
+        if peeks < 4:   # (the compiler duplicates the back wave's block loop: six sites in the current build)
+            problems.append((m.group(1), "expected at least 4 asynchronous counter reads (one per part), found %d" % peeks))
+    return problems
+
+
 if __name__ == "__main__":
-    for name, what in prefetch_register_hazards() + pipe_prefetch_hazards() + pipe_prefetch_hazards(r"_ZN3fsk18demod_pipe3_kernel"):
+    for name, what in prefetch_register_hazards() + pipe_prefetch_hazards() + pipe_prefetch_hazards(r"_ZN3fsk18demod_pipe3_kernel") + blk_checks():
         print("HAZARD", name[:50], what)
         sys.exit(2)
     r = kernel_resources()

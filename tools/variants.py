@@ -78,7 +78,7 @@ if os.environ.get("VAR_STAMPS"):
               %% (np.median(late), np.percentile(late, 90), late.max(), int((late > 1000).sum()), g))
     if a[3, :g, 3].sum():
         c = a[3, :g, 3:7].astype(np.float64).sum(axis=0)
-        print("STAMP back wave blocks: %%.0f per group; slow because of a live correction %%.1f %%%%, ring wrap %%.1f %%%%, rare-event test %%.1f %%%%"
+        print("STAMP back wave blocks: %%.0f per group; per sample because a lane is inside this wave's own span after a reset %%.1f %%%%, (unused) %%.1f %%%%, per sample for a rare event %%.1f %%%%"
               %% (c[0] / g, 100 * c[1] / c[0], 100 * c[2] / c[0], 100 * c[3] / c[0]))
     for w in range(4):
         tot = a[w, :g, 1].astype(np.float64)

@@ -43,8 +43,9 @@ bool demod_blk_applicable(const DemodParams &P);
 hipError_t set_blk_lds_limit(const DemodParams &P);
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
-                             uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, bool *sliced_out);
-uint32_t demod_blk_resident_wgs(const DemodParams &P, int device);
+                             uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, uint32_t y_slots,
+                             bool *sliced_out);
+void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t *y_slots, uint32_t *resident_wgs);
 size_t demod_blk_queue_words(uint32_t groups);
 hipError_t set_pipe_lds_limit(size_t pipe_bytes);
 hipError_t set_demod_lds_limit(size_t lds_bytes);
@@ -175,6 +176,7 @@ struct fskhip_engine {
   bool use_blk = true;          // four waves per group with the block-batched back wave (demod_blk_kernel, fsk_blk.hip): the default
                                  // wherever it applies (dsSPB a multiple of 4, >= 8); FSKHIP_SPLIT = 0 / 1 / 3 pins an older kernel
   uint32_t blk_resident = 0;     // workgroups of demod_blk_kernel the device holds at once; larger batches run it persistent, in time slices
+  uint32_t blk_y_slots = 6;      // half tiles in the block kernel's y ring: as deep as the LDS allows at this batch size (FSKHIP_BLK_YSLOTS pins it)
   uint32_t blk_slice_tiles = 0;  // FSKHIP_SLICE_TILES: tiles per time slice (0 = the kernel file's default, "off" = never slice)
   bool last_sliced = false;
   uint64_t pushes = 0;           // decimated samples since create (lock-step engines): the amplitude ring's write position
@@ -600,7 +602,8 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     CREATE_TRY(set_pipe_lds_limit(demod_pipe_lds_bytes(P)));
   if (e->demod_ok && precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(P)) {
     CREATE_TRY(set_blk_lds_limit(P));
-    e->blk_resident = demod_blk_resident_wgs(P, device);
+    demod_blk_plan(P, e->n_blocks, device, &e->blk_y_slots, &e->blk_resident);
+    if (const char *ys = getenv("FSKHIP_BLK_YSLOTS")) e->blk_y_slots = (uint32_t)strtoul(ys, nullptr, 10);   // measurements
     if (const char *rw = getenv("FSKHIP_BLK_RESIDENT")) e->blk_resident = (uint32_t)strtoul(rw, nullptr, 10);   // tests: a "device" this small
     if (const char *sl = getenv("FSKHIP_SLICE_TILES")) e->blk_slice_tiles = sl[0] == 'o' ? 0xFFFFFFFFu : (uint32_t)strtoul(sl, nullptr, 10);
     if (e->blk_resident && e->n_blocks > e->blk_resident) {
@@ -701,7 +704,7 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
         const bool quad_aligned = ((e->pushes + ((p0 + head) >> 1)) & 3u) == 0u;
         if (e->use_blk && demod_blk_applicable(e->P) && blk_lds <= 160 * 1024 && (quad_aligned || e->split_forced)) {
           HIP_TRY(launch_demod_blk(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
-                                   e->blk_resident, e->blk_slice_tiles, &e->last_sliced));
+                                   e->blk_resident, e->blk_slice_tiles, e->blk_y_slots, &e->last_sliced));
           static const char *const names[8] = {
               "fsk::demod_blk_kernel<false, false, false>", "fsk::demod_blk_kernel<false, false, true>",
               "fsk::demod_blk_kernel<false, true, false>", "fsk::demod_blk_kernel<false, true, true>",

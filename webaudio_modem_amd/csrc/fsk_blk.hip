@@ -61,6 +61,13 @@ static_assert(4u * kBlkSlots <= kZeroLagPairs, "the wave that owns the I/Q low-p
 static_assert(4u * kBlkSlots <= kHandLag, "the discriminator wave (up to 4 * kBlkSlots - 1 samples beyond the start of the back wave's tile) must not have reached the hand-over sample when it is posted");
 static constexpr uint32_t kBlkSlotV4 = 2 * 64;     // v4f per x-ring slot: four pair sums (I, Q) -- in place -> four (phase, magnitude)
 static constexpr uint32_t kFlushBlocks = 16;       // byte queues are flushed every this many blocks
+// The y ring (wave 0 -> wave 1) may be deeper than the x ring.  With six slots everywhere the four waves hold exactly
+// three tiles between them and each tile goes round the closed chain "back wave frees a slot -> wave 0 -> 1 -> 2 -> back
+// wave": the group advances a tile per (t0 + t1 + t2 + t3) / 3, not per max(t) (measured busy cycles per sample at 8 192
+// streams 116 + 132 + 121 + 148 = 517 -> 172; the loop ran at 182).  Only wave 1 .. 3's distance is tied to the lag
+// constants (static_asserts above); wave 0 has no such tie, so its ring takes whatever LDS the launch has to spare.
+static constexpr uint32_t kBlkYMax = 28;
+__host__ __device__ inline uint32_t blk_zt_tiles(uint32_t y_slots) { return y_slots <= 12u ? 8u : 16u; }
 
 // lane stride of the polyphase registers in LDS: >= d, = 4 mod 8, so that the ds_read_b128 of 16 lanes at consecutive
 // strides touches 64 different banks (20 for 1200 baud, 84 for 300 baud)
@@ -188,6 +195,8 @@ struct BlkSched {
   uint32_t nslices;              // per group
   uint32_t slice_tiles;          // tiles per slice (the last one may be shorter)
   uint32_t total;                // groups * nslices
+  uint32_t y_slots;              // half tiles in the y ring (>= kBlkSlots): how far wave 0 may run ahead of the back wave
+  uint32_t zt_tiles;             // tiles of NCO phasors in flight (wave 0 -> wave 1), a power of two > y_slots / 2
 };
 
 template <bool WB, bool UNI, bool SL>
@@ -199,12 +208,15 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
   FSK_STAMP_DECL
   extern __shared__ float4 lds[];
   const uint32_t PS = blk_poly_stride(P.d);
+  const uint32_t NY = Z.y_slots;
   v4f *stage = reinterpret_cast<v4f *>(lds);
+  v4f *fin = stage;                                       // [0..1] wave 1's final I/Q low-pass state, [2] wave 2's final correction
+                                                          // (over the staging tile: wave 0 is done with it when they are written)
   v4f *yring = stage + 4 * kSlotStride;                   // wave 0 -> wave 1 (and the back wave after a reset): pre-filter outputs
-  v4f *ring = yring + kBlkSlots * 2 * 64;                 // wave 1: pair sums U -> wave 2: (phase, magnitude) IN PLACE -> wave 3
-  v4f *fin = ring + kBlkSlots * kBlkSlotV4;               // [0..1] wave 1's final I/Q low-pass state, [2] wave 2's final correction
-  v4f *zt = fin + 3 * 64;
-  uint32_t *poly = reinterpret_cast<uint32_t *>(zt + 4 * 8);   // [lane][PS], index 0 = the phase of the launch's first push
+  v4f *ring = yring + NY * 2 * 64;                        // wave 1: pair sums U -> wave 2: (phase, magnitude) IN PLACE -> wave 3
+  v4f *zt = ring + kBlkSlots * kBlkSlotV4;
+  const uint32_t ZTM = Z.zt_tiles - 1u;
+  uint32_t *poly = reinterpret_cast<uint32_t *>(zt + Z.zt_tiles * 8);   // [lane][PS], index 0 = the phase of the launch's first push
   uint32_t *ctr = poly + 64u * PS;                        // produced by wave 0, 1, 2 | consumed by wave 3 | [4] CU arrival | [5] item
   uint32_t *zmail = ctr + 8;                              // back -> wave 1: where to zero a lane's I/Q low-pass
   uint32_t *cmail = zmail + 64;                           // back -> wave 2: [0] from which decimated sample, [1..4] the correction there,
@@ -346,24 +358,24 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
       const uint32_t hidx = 2u * t;
       v4u32 cv;
       lds_peek4_begin(ctr, cv);                             // (read now, looked at after the tile: see lds_peek4_begin)
-      if (hidx + 1u - consumed >= kBlkSlots) {              // both of the tile's slots must be free
+      if (hidx + 1u - consumed >= NY) {                     // both of the tile's slots must be free
         FSK_STAMP_W0
-        while (hidx + 1u - consumed >= kBlkSlots) {         // ring full: the back wave (which may still need the slots'
+        while (hidx + 1u - consumed >= NY) {                // ring full: the back wave (which may still need the slots'
           consumed = lds_peek(&ctr[3]);                     // pre-filter outputs after a reset) has not released them
-          if (hidx + 1u - consumed >= kBlkSlots) __builtin_amdgcn_s_sleep(1);
+          if (hidx + 1u - consumed >= NY) __builtin_amdgcn_s_sleep(1);
         }
         FSK_STAMP_W1
       }
       if (UNI) {
         float pc, ps;
         nco_phasor(zacc, pc, ps);
-        reinterpret_cast<f2 *>(zt + (t & 3u) * 8u)[lane & 15u] = (f2){pc, ps};
+        reinterpret_cast<f2 *>(zt + (t & ZTM) * 8u)[lane & 15u] = (f2){pc, ps};
         zacc += inc16;
       }
 #pragma unroll
       for (uint32_t hf = 0; hf < 2; hf++) {
         v4f *slot = yring + slot_i * 2u * 64u;
-        slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
+        slot_i = slot_i + 1u == NY ? 0u : slot_i + 1u;
 #pragma unroll
         for (uint32_t cc = 0; cc < 2; cc++) {
           const uint32_t c = 2u * hf + cc;
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     }
     uint64_t tacc = free0;
     const uint64_t inc16 = inc * 16u;
-    uint32_t consumed = 0, produced = 0, slot_i = 0;
+    uint32_t consumed = 0, produced = 0, slot_i = 0, yslot_i = 0;
     float zr = 1.f, zi = 0.f;
     FSK_STAMP_BEGIN
     uint32_t hidx = 0;
@@ -444,14 +456,15 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
       do {
         v4u32 cv;
         lds_peek4_begin(ctr, cv);
-        const v4f *ztile = zt + ((hidx >> 1) & 3u) * 8u;
+        const v4f *ztile = zt + ((hidx >> 1) & ZTM) * 8u;
         if (!UNI && !(hidx & 1u)) {                           // per-stream tones: the tile's first phasor from the exact accumulator
           nco_phasor(tacc, zr, zi);
           tacc += inc16;
         }
-        const v4f *yslot = yring + slot_i * 2u * 64u;
+        const v4f *yslot = yring + yslot_i * 2u * 64u;
         v4f *slot = ring + slot_i * kBlkSlotV4;
         slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
+        yslot_i = yslot_i + 1u == NY ? 0u : yslot_i + 1u;
         const uint32_t zj = zmail[lane];
         const uint64_t zh = __builtin_amdgcn_ballot_w64(zj - 4u * hidx < 4u);
 #pragma unroll
@@ -615,7 +628,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     // block takes the per-sample path
     const bool amp_misaligned = (amp_pos0 & 3u) != 0u;
     const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
-    uint32_t produced = 0, slot_i = 0;
+    uint32_t produced = 0, slot_i = 0, yslot_i = 0;
     uint32_t pidx = 0;                                        // LDS index of the block's first polyphase register
     uint32_t bq = 0, nq = 0;                                  // completed bytes not yet stored (newest in the low byte)
     uint32_t *prow = poly + lane * PS;
@@ -637,8 +650,12 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
       uint32_t lim = lim0 < (produced & ~1u) ? lim0 : (produced & ~1u);
       // ---- the block loop: straight-line code with two branches, its back edge and the exit on anything rare (a branch
       // costs a wave ~35 cycles whether taken or not)
-      bool rare_exit = false;
-      do {
+      // (not while a lane is inside this wave's own span after a reset, nor with the amplitude ring off its quad grid: those
+      // tiles go sample by sample.  Running the own-span lanes' zir_step ahead of the block path was tried: with frames
+      // that end about together, 81 % of such tiles also hold another lane's 'eod' or false start and fail the block's
+      // rare test after paying for it -- 8 192 streams 118.7 -> 111.3 Gsamples/s, profiles/r03_own_span_blocks.txt.)
+      bool rare_exit = (X.zlive != 0u || amp_misaligned) && !FSK_ABL(3);
+      if (!rare_exit) do {
         v4u32 cv;
         lds_peek4_begin(ctr, cv);
         const uint32_t slot_j = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
@@ -651,10 +668,8 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         float am[kBlk];
         uint32_t bqn = bq, nqn = nq;
         const uint32_t rare = blk_fast(Bn, K, Q, X.kv, pa, rp, am, bqn, nqn);
-        // (a live correction of this wave's, or the amplitude ring's wrap, make the block path void: ~3 % of the blocks)
-        const uint64_t pre = (uint64_t)(X.zlive | (amp_misaligned ? 1u : 0u));
         FSK_STAMP_COUNT(0)                                    // blocks
-        if (__builtin_expect(((__builtin_amdgcn_ballot_w64((int32_t)rare < 0) | pre) != 0ull) & !FSK_ABL(3), 0)) { rare_exit = true; break; }
+        if (__builtin_expect((__builtin_amdgcn_ballot_w64((int32_t)rare < 0) != 0ull) & !FSK_ABL(3), 0)) { rare_exit = true; break; }
         B = Bn; bq = bqn; nq = nqn;
         *reinterpret_cast<uint4 *>(prow + pidx) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
         *reinterpret_cast<uint4 *>(prow + pidx2) = make_uint4(rp[4], rp[5], rp[6], rp[7]);
@@ -670,6 +685,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         }
         X.k += (uint32_t)kBlk; X.kv += (uint32_t)kBlk;
         slot_i = slot_j + 1u == kBlkSlots ? 0u : slot_j + 1u;
+        yslot_i = yslot_i + 2u >= NY ? yslot_i + 2u - NY : yslot_i + 2u;
         pidx = pidx2 + 4u >= P.d ? 0u : pidx2 + 4u;
         t += 2u;
         lds_post(&ctr[3], t);                                 // slots free (this wave's reads of them are complete)
@@ -683,7 +699,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
 #pragma unroll 1
         for (uint32_t hh = 0; hh < 2; hh++) {
           const v4f *slot = ring + slot_i * kBlkSlotV4;
-          const v4f *yslot = yring + slot_i * 2u * 64u;
+          const v4f *yslot = yring + yslot_i * 2u * 64u;
 #pragma unroll 1
           for (uint32_t c = 0; c < 2; c++) {
             const v4f u4 = slot[c * 64u + lane];             // pair sums where this wave's own span covers the lane, else (phase, magnitude)
@@ -701,6 +717,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
             }
           }
           slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
+          yslot_i = yslot_i + 1u == NY ? 0u : yslot_i + 1u;
           pidx = pidx + 4u >= P.d ? 0u : pidx + 4u;
           t++;
           lds_post(&ctr[3], t);
@@ -745,17 +762,19 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-size_t demod_blk_lds_bytes(const DemodParams &P) {
-  return sizeof(float4) * (4 * kSlotStride + kBlkSlots * 2 * 64 + kBlkSlots * kBlkSlotV4 + 3 * 64 + 4 * 8) +
+size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots) {
+  return sizeof(float4) * (4 * kSlotStride + y_slots * 2 * 64 + kBlkSlots * kBlkSlotV4 + blk_zt_tiles(y_slots) * 8) +
          sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 8u + 64u + 6u * 64u);
 }
+size_t demod_blk_lds_bytes(const DemodParams &P) { return demod_blk_lds_bytes(P, kBlkSlots); }
 // the block path needs whole blocks of polyphase registers (dsSPB a multiple of 4) and at most one bit decision per block
 bool demod_blk_applicable(const DemodParams &P) { return P.d >= 8u && (P.d & 3u) == 0u && !P.wide && !P.frac; }
 
 hipError_t set_blk_lds_limit(const DemodParams &P) {
   hipError_t e = hipSuccess;
-  const size_t bytes = demod_blk_lds_bytes(P);
-  if (bytes > 160 * 1024) return hipSuccess;
+  if (demod_blk_lds_bytes(P) > 160 * 1024) return hipSuccess;
+  size_t bytes = demod_blk_lds_bytes(P, kBlkYMax);
+  bytes = bytes > 160 * 1024 ? 160 * 1024 : bytes;
 #define FSK_ATTR(WBV, UNIV, SLV)                                                                                 \
   if (e == hipSuccess)                                                                                           \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk_kernel<WBV, UNIV, SLV>),                  \
@@ -766,13 +785,33 @@ hipError_t set_blk_lds_limit(const DemodParams &P) {
   return e;
 }
 
-// workgroups of the block kernel the device holds at once (one round); 0 if it cannot tell
-uint32_t demod_blk_resident_wgs(const DemodParams &P, int device) {
-  int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&demod_blk_kernel<false, true, true>), 256,
-                                                   demod_blk_lds_bytes(P)) != hipSuccess) return 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
-  return per_cu > 0 && cus > 0 ? (uint32_t)per_cu * (uint32_t)cus : 0u;
+// How to launch a batch of `groups` on `device`: the y ring as deep as the LDS allows while every CU still holds its
+// share of the groups (at most four workgroups: the register file's limit), and how many workgroups the device then
+// holds at once (one round; larger batches are run persistently, in time slices).  Zeros if it cannot tell.
+void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t *y_slots, uint32_t *resident_wgs) {
+  *y_slots = kBlkSlots; *resident_wgs = 0;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return;
+  auto held = [&](uint32_t y) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&demod_blk_kernel<false, true, true>), 256,
+                                                     demod_blk_lds_bytes(P, y)) != hipSuccess) return 0u;
+    return per_cu > 0 ? (uint32_t)per_cu : 0u;
+  };
+  const uint32_t most = held(kBlkSlots);                       // (four)
+  if (!most) return;
+  uint32_t want = (groups + (uint32_t)cus - 1u) / (uint32_t)cus;
+  want = want < 1u ? 1u : want > most ? most : want;
+  uint32_t y = kBlkSlots;
+  // (the occupancy query, and 512-byte granules, let a third workgroup "fit" beside 2 x 54 112 bytes; the hardware did not
+  // place it and 49 152 streams ran in two rounds.  1 280 = 160 KB / 128 and 2 048 both explain what was measured.)
+  auto fits = [&](uint32_t yy) {
+    const size_t b = demod_blk_lds_bytes(P, yy);
+    return (size_t)want * ((b + 1279u) / 1280u * 1280u) <= 160u * 1024u && (size_t)want * ((b + 2047u) & ~(size_t)2047u) <= 160u * 1024u;
+  };
+  while (y + 2u <= kBlkYMax && fits(y + 2u) && held(y + 2u) >= want) y += 2u;
+  *y_slots = y;
+  *resident_wgs = held(y) * (uint32_t)cus;
 }
 
 #ifdef FSK_ABLATE
@@ -793,11 +832,13 @@ size_t demod_blk_queue_words(uint32_t groups) { return 16u + (size_t)groups * (k
 
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
-                             uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, bool *sliced_out) {
+                             uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, uint32_t y_slots,
+                             bool *sliced_out) {
   const uint32_t blocks = (P.n_streams + 63u) / 64u;
-  const size_t lds = demod_blk_lds_bytes(P);
+  y_slots = y_slots < kBlkSlots ? kBlkSlots : y_slots > kBlkYMax ? kBlkYMax : y_slots;
+  const size_t lds = demod_blk_lds_bytes(P, y_slots);
   set_ablate_blk();
-  BlkSched Z = {nullptr, blocks, 1u, 0u, 0u};
+  BlkSched Z = {nullptr, blocks, 1u, 0u, 0u, y_slots, blk_zt_tiles(y_slots)};
   const uint32_t n_tiles = (uint32_t)(n / kFastTile);
   bool sliced = false;
   if (S.blk_q && resident_wgs && blocks > resident_wgs && blocks < (1u << 20) && slice_tiles != 0xFFFFFFFFu) {

@@ -293,6 +293,107 @@ __device__ inline float disc_post(BackLane &B, const BackK &K, float ph, float &
   return B.py;
 }
 
+// The ZIR correction's share of one decimated sample, for a wave some lane of which carries one (X.zlive): w = U - q, q
+// advances; lanes inside the span after a reset run the zero-started ("direct") instance instead and derive q's start
+// values from it; phase / magnitude are re-evaluated where that changes them (HAND: for the lanes whose correction is this
+// wave's own).  One function for the per-sample path (back_pair) and the block path's own-span blocks (fsk_blk.hip).
+template <bool UNI, bool HAND>
+__device__ inline void zir_step(BackLane &B, const BackK &K, BackU &X, float Ui, float Uq, const float *ypair, uint64_t inc,
+                                uint32_t lane, float &ph, float &amp) {
+  const uint32_t dph0 = B.dph;
+  float wi = Ui - B.qai, wq = Uq - B.qaq;
+  {
+    const float ni = __builtin_fmaf(K.c1, B.qbi, -(K.c2 * B.qai));
+    const float nq = __builtin_fmaf(K.c1, B.qbq, -(K.c2 * B.qaq));
+    B.qai = B.qbi; B.qaq = B.qbq; B.qbi = ni; B.qbq = nq;
+  }
+  // ---- rare: the decimated samples after a reset come from the zero-started instance; its last two (the first two
+  // after the front has zeroed its filters) also yield q's start values
+  if (__builtin_expect(X.direct != 0u, 0)) {
+    X.direct--;
+    if (B.dph < kDirectPairs) {
+      const float y0 = ypair[0], y1 = ypair[1];
+      const uint32_t n0 = 2u * (X.k - 1u);
+      // the front's phasors of these two samples, evaluated the same way (nco_phasor)
+      float c0, s0, c1, s1;
+      nco_phasor(X.free0 + inc * (uint64_t)n0, c0, s0);
+      nco_phasor(X.free0 + inc * (uint64_t)(n0 + 1u), c1, s1);
+      float di, dq;
+      {
+        const float mi = y0 * c0, mq = y0 * s0;
+        const float ti = __builtin_fmaf(2.0f, B.dix1, mi) + B.dix2, tq = __builtin_fmaf(2.0f, B.dqx1, mq) + B.dqx2;
+        B.dvi = __builtin_fmaf(K.lp_a2, B.dvi, __builtin_fmaf(K.lp_nd, B.diy, ti));
+        B.dqv = __builtin_fmaf(K.lp_a2, B.dqv, __builtin_fmaf(K.lp_nd, B.dqy, tq));
+        B.diy += B.dvi; B.dqy += B.dqv;
+        B.dix2 = B.dix1; B.dix1 = mi; B.dqx2 = B.dqx1; B.dqx1 = mq;
+        di = B.diy; dq = B.dqy;
+      }
+      {
+        const float mi = y1 * c1, mq = y1 * s1;
+        const float ti = __builtin_fmaf(2.0f, B.dix1, mi) + B.dix2, tq = __builtin_fmaf(2.0f, B.dqx1, mq) + B.dqx2;
+        B.dvi = __builtin_fmaf(K.lp_a2, B.dvi, __builtin_fmaf(K.lp_nd, B.diy, ti));
+        B.dqv = __builtin_fmaf(K.lp_a2, B.dqv, __builtin_fmaf(K.lp_nd, B.dqy, tq));
+        B.diy += B.dvi; B.dqy += B.dqv;
+        B.dix2 = B.dix1; B.dix1 = mi; B.dqx2 = B.dqx1; B.dqx1 = mq;
+        di += B.diy; dq += B.dqy;
+      }
+      wi = di; wq = dq;
+      if (B.dph == kZeroLagPairs) {
+        B.q0i = Ui - di; B.q0q = Uq - dq;
+      } else if (B.dph == kZeroLagPairs + 1u) {
+        const float q1i = Ui - di, q1q = Uq - dq;
+        B.qai = __builtin_fmaf(K.c1, q1i, -(K.c2 * B.q0i));
+        B.qaq = __builtin_fmaf(K.c1, q1q, -(K.c2 * B.q0q));
+        B.qbi = __builtin_fmaf(K.c1, B.qai, -(K.c2 * q1i));
+        B.qbq = __builtin_fmaf(K.c1, B.qaq, -(K.c2 * q1q));
+        if (HAND) {
+          // the correction stays here for the next kHandLag decimated samples (numbers X.k .. X.k + kHandLag - 1 of this
+          // launch) and then moves to the discriminator wave: post what the recurrence makes of it by then
+          float ai = B.qai, aq = B.qaq, bi = B.qbi, bq = B.qbq;
+          for (uint32_t g = 0; g < kHandLag; g++) {
+            const float ni = __builtin_fmaf(K.c1, bi, -(K.c2 * ai)), nq = __builtin_fmaf(K.c1, bq, -(K.c2 * aq));
+            ai = bi; aq = bq; bi = ni; bq = nq;
+          }
+          X.cmail[64u + lane] = __builtin_bit_cast(uint32_t, ai); X.cmail[128u + lane] = __builtin_bit_cast(uint32_t, aq);
+          X.cmail[192u + lane] = __builtin_bit_cast(uint32_t, bi); X.cmail[256u + lane] = __builtin_bit_cast(uint32_t, bq);
+          X.cmail[lane] = X.k + kHandLag;
+        }
+      }
+      B.dph += 1u;
+    }
+  }
+  if (dph0 >= kDirectPairs && dph0 < kHandPairs) {          // the un-retired span after the direct instance
+    B.dph = dph0 + 1u;
+    if (HAND && B.dph == kHandPairs) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }   // handed over
+  }
+  if (HAND) {
+    // lanes whose correction (or direct instance) is this wave's own evaluate the discriminator here; the others keep
+    // the discriminator wave's result, which already carries their correction
+    const bool own = dph0 < kHandPairs;
+    if (__builtin_amdgcn_ballot_w64(own)) {
+      float a2;
+      const float p2 = atan2_amp_fma(wq, wi, a2, K.tiny, K.sgn);
+      ph = own ? p2 : ph; amp = own ? a2 : amp;
+    }
+    X.zlive = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(B.dph < kHandPairs) != 0));
+  } else {
+    const uint32_t changed = (__builtin_bit_cast(uint32_t, wi) ^ __builtin_bit_cast(uint32_t, Ui)) |
+                             (__builtin_bit_cast(uint32_t, wq) ^ __builtin_bit_cast(uint32_t, Uq));
+    if (__builtin_amdgcn_ballot_w64(changed != 0u)) ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
+  }
+  if (!HAND) {
+    // a correction that has decayed below 2^-28 of the magnitude it corrects is retired to exactly zero (both decay at
+    // the low-pass's own rate at least, so it stays negligible; a rule of the stream's own values only, so every kernel
+    // and every chunking retires it at the same decimated sample)
+    const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(B.qai), __builtin_fabsf(B.qaq)),
+                                      __builtin_fmaxf(__builtin_fabsf(B.qbi), __builtin_fabsf(B.qbq)));
+    const bool steady = dph0 >= kHandPairs;                       // (from the sample on that the discriminator wave would own it)
+    const bool small = !(big > amp * 3.7252902984619141e-09f);   // (<=: a zero correction under the bare (0, 0) guard retires too)
+    if (steady & small) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }
+    X.zlive = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(!steady | !small) != 0));
+  }
+}
+
 // One decimated sample: ZIR correction, discriminator (fsk.ts:245-264), processDownsampledBit (fsk.ts:278-344),
 // processByte (346-375).  ypair: LDS address of this pair's two pre-filter outputs (read by the direct instance only);
 // pslot: where the polyphase sync-bit register of this push lives (r_old is its value).
@@ -316,100 +417,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   float amp, ph;
   if (PA) { ph = ph_u; amp = amp_u; }
   else ph = atan2_amp_fma(Uq, Ui, amp, K.tiny, K.sgn);
-  if (__builtin_expect(X.zlive != 0u, 0)) {
-    const uint32_t dph0 = B.dph;
-    float wi = Ui - B.qai, wq = Uq - B.qaq;
-    {
-      const float ni = __builtin_fmaf(K.c1, B.qbi, -(K.c2 * B.qai));
-      const float nq = __builtin_fmaf(K.c1, B.qbq, -(K.c2 * B.qaq));
-      B.qai = B.qbi; B.qaq = B.qbq; B.qbi = ni; B.qbq = nq;
-    }
-    // ---- rare: the decimated samples after a reset come from the zero-started instance; its last two (the first two
-    // after the front has zeroed its filters) also yield q's start values
-    if (__builtin_expect(X.direct != 0u, 0)) {
-      X.direct--;
-      if (B.dph < kDirectPairs) {
-        const float y0 = ypair[0], y1 = ypair[1];
-        const uint32_t n0 = 2u * (X.k - 1u);
-        // the front's phasors of these two samples, evaluated the same way (nco_phasor)
-        float c0, s0, c1, s1;
-        nco_phasor(X.free0 + inc * (uint64_t)n0, c0, s0);
-        nco_phasor(X.free0 + inc * (uint64_t)(n0 + 1u), c1, s1);
-        float di, dq;
-        {
-          const float mi = y0 * c0, mq = y0 * s0;
-          const float ti = __builtin_fmaf(2.0f, B.dix1, mi) + B.dix2, tq = __builtin_fmaf(2.0f, B.dqx1, mq) + B.dqx2;
-          B.dvi = __builtin_fmaf(K.lp_a2, B.dvi, __builtin_fmaf(K.lp_nd, B.diy, ti));
-          B.dqv = __builtin_fmaf(K.lp_a2, B.dqv, __builtin_fmaf(K.lp_nd, B.dqy, tq));
-          B.diy += B.dvi; B.dqy += B.dqv;
-          B.dix2 = B.dix1; B.dix1 = mi; B.dqx2 = B.dqx1; B.dqx1 = mq;
-          di = B.diy; dq = B.dqy;
-        }
-        {
-          const float mi = y1 * c1, mq = y1 * s1;
-          const float ti = __builtin_fmaf(2.0f, B.dix1, mi) + B.dix2, tq = __builtin_fmaf(2.0f, B.dqx1, mq) + B.dqx2;
-          B.dvi = __builtin_fmaf(K.lp_a2, B.dvi, __builtin_fmaf(K.lp_nd, B.diy, ti));
-          B.dqv = __builtin_fmaf(K.lp_a2, B.dqv, __builtin_fmaf(K.lp_nd, B.dqy, tq));
-          B.diy += B.dvi; B.dqy += B.dqv;
-          B.dix2 = B.dix1; B.dix1 = mi; B.dqx2 = B.dqx1; B.dqx1 = mq;
-          di += B.diy; dq += B.dqy;
-        }
-        wi = di; wq = dq;
-        if (B.dph == kZeroLagPairs) {
-          B.q0i = Ui - di; B.q0q = Uq - dq;
-        } else if (B.dph == kZeroLagPairs + 1u) {
-          const float q1i = Ui - di, q1q = Uq - dq;
-          B.qai = __builtin_fmaf(K.c1, q1i, -(K.c2 * B.q0i));
-          B.qaq = __builtin_fmaf(K.c1, q1q, -(K.c2 * B.q0q));
-          B.qbi = __builtin_fmaf(K.c1, B.qai, -(K.c2 * q1i));
-          B.qbq = __builtin_fmaf(K.c1, B.qaq, -(K.c2 * q1q));
-          if (HAND) {
-            // the correction stays here for the next kHandLag decimated samples (numbers X.k .. X.k + kHandLag - 1 of this
-            // launch) and then moves to the discriminator wave: post what the recurrence makes of it by then
-            float ai = B.qai, aq = B.qaq, bi = B.qbi, bq = B.qbq;
-            for (uint32_t g = 0; g < kHandLag; g++) {
-              const float ni = __builtin_fmaf(K.c1, bi, -(K.c2 * ai)), nq = __builtin_fmaf(K.c1, bq, -(K.c2 * aq));
-              ai = bi; aq = bq; bi = ni; bq = nq;
-            }
-            X.cmail[64u + lane] = __builtin_bit_cast(uint32_t, ai); X.cmail[128u + lane] = __builtin_bit_cast(uint32_t, aq);
-            X.cmail[192u + lane] = __builtin_bit_cast(uint32_t, bi); X.cmail[256u + lane] = __builtin_bit_cast(uint32_t, bq);
-            X.cmail[lane] = X.k + kHandLag;
-          }
-        }
-        B.dph += 1u;
-      }
-    }
-    if (dph0 >= kDirectPairs && dph0 < kHandPairs) {          // the un-retired span after the direct instance
-      B.dph = dph0 + 1u;
-      if (HAND && B.dph == kHandPairs) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }   // handed over
-    }
-    if (HAND) {
-      // lanes whose correction (or direct instance) is this wave's own evaluate the discriminator here; the others keep
-      // the discriminator wave's result, which already carries their correction
-      const bool own = dph0 < kHandPairs;
-      if (__builtin_amdgcn_ballot_w64(own)) {
-        float a2;
-        const float p2 = atan2_amp_fma(wq, wi, a2, K.tiny, K.sgn);
-        ph = own ? p2 : ph; amp = own ? a2 : amp;
-      }
-      X.zlive = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(B.dph < kHandPairs) != 0));
-    } else {
-      const uint32_t changed = (__builtin_bit_cast(uint32_t, wi) ^ __builtin_bit_cast(uint32_t, Ui)) |
-                               (__builtin_bit_cast(uint32_t, wq) ^ __builtin_bit_cast(uint32_t, Uq));
-      if (__builtin_amdgcn_ballot_w64(changed != 0u)) ph = atan2_amp_fma(wq, wi, amp, K.tiny, K.sgn);
-    }
-    if (!HAND) {
-      // a correction that has decayed below 2^-28 of the magnitude it corrects is retired to exactly zero (both decay at
-      // the low-pass's own rate at least, so it stays negligible; a rule of the stream's own values only, so every kernel
-      // and every chunking retires it at the same decimated sample)
-      const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(B.qai), __builtin_fabsf(B.qaq)),
-                                        __builtin_fmaxf(__builtin_fabsf(B.qbi), __builtin_fabsf(B.qbq)));
-      const bool steady = dph0 >= kHandPairs;                       // (from the sample on that the discriminator wave would own it)
-      const bool small = !(big > amp * 3.7252902984619141e-09f);   // (<=: a zero correction under the bare (0, 0) guard retires too)
-      if (steady & small) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }
-      X.zlive = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(!steady | !small) != 0));
-    }
-  }
+  if (__builtin_expect(X.zlive != 0u, 0)) zir_step<UNI, HAND>(B, K, X, Ui, Uq, ypair, inc, lane, ph, amp);
   // ---- discriminator (fsk.ts:251-264)
   const float f = disc_post(B, K, ph, amp);
   // slicer (fsk.ts:264): f > 0  <=>  sign bit of 0 - f  (f = +-0 gives +0, i.e. bit 0)
