@@ -390,8 +390,8 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
               *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + (size_t)(t_begin + t) * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
           }
         }
-        lds_post(&ctr[0], hidx + hf + 1u);
       }
+      lds_post(&ctr[0], hidx + 2u);                         // (per tile: the other waves work in whole tiles too)
       consumed = lds_peek4_get(cv, 3);
     };
     const uint32_t nt = (uint32_t)n_tiles;
@@ -432,18 +432,18 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     uint32_t consumed = 0, produced = 0, slot_i = 0, yslot_i = 0;
     float zr = 1.f, zi = 0.f;
     FSK_STAMP_BEGIN
-    uint32_t hidx = 0;
+    uint32_t hidx = 0;                                        // half tiles done; this wave works a tile (two of them) at a time
     while (hidx < nh) {
       if ((hidx & 63u) == 0u) blk_prio(hidx, wgj);
-      if (produced <= hidx || hidx - consumed >= kBlkSlots) {
+      if (produced < hidx + 2u || hidx + 2u - consumed > kBlkSlots) {
         FSK_STAMP_W0
-        while (produced <= hidx) {                            // wave 0's half tile
+        while (produced < hidx + 2u) {                        // wave 0's tile
           produced = lds_peek(&ctr[0]);
-          if (produced <= hidx) __builtin_amdgcn_s_sleep(1);
+          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(1);
         }
-        while (hidx - consumed >= kBlkSlots) {               // ring full: wait for the back wave
+        while (hidx + 2u - consumed > kBlkSlots) {           // ring full: wait for the back wave
           consumed = lds_peek(&ctr[3]);
-          if (hidx - consumed >= kBlkSlots) __builtin_amdgcn_s_sleep(1);
+          if (hidx + 2u - consumed > kBlkSlots) __builtin_amdgcn_s_sleep(1);
         }
         FSK_STAMP_W1
       }
@@ -457,26 +457,35 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         v4u32 cv;
         lds_peek4_begin(ctr, cv);
         const v4f *ztile = zt + ((hidx >> 1) & ZTM) * 8u;
-        if (!UNI && !(hidx & 1u)) {                           // per-stream tones: the tile's first phasor from the exact accumulator
+        if (!UNI) {                                           // per-stream tones: the tile's first phasor from the exact accumulator
           nco_phasor(tacc, zr, zi);
           tacc += inc16;
         }
-        const v4f *yslot = yring + yslot_i * 2u * 64u;
+        const uint32_t zj = zmail[lane];
+        // the tile's inputs first (twelve LDS reads in flight together), then straight-line arithmetic: ONE branch per tile
+        // (a lane's filters to be zeroed inside it: rare), none per quad
+        v4f y4[4], zz[8];
+        {
+          const v4f *ys0 = yring + yslot_i * 2u * 64u;
+          yslot_i = yslot_i + 1u == NY ? 0u : yslot_i + 1u;
+          const v4f *ys1 = yring + yslot_i * 2u * 64u;
+          yslot_i = yslot_i + 1u == NY ? 0u : yslot_i + 1u;
+          y4[0] = ys0[lane]; y4[1] = ys0[64u + lane]; y4[2] = ys1[lane]; y4[3] = ys1[64u + lane];
+          if (UNI) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) zz[i] = ztile[i];
+          }
+        }
         v4f *slot = ring + slot_i * kBlkSlotV4;
         slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
-        yslot_i = yslot_i + 1u == NY ? 0u : yslot_i + 1u;
-        const uint32_t zj = zmail[lane];
-        const uint64_t zh = __builtin_amdgcn_ballot_w64(zj - 4u * hidx < 4u);
-#pragma unroll
-        for (uint32_t cc = 0; cc < 2; cc++) {
-          const uint32_t c = 2u * (hidx & 1u) + cc;
-          const v4f y4 = yslot[cc * 64u + lane];
-          const uint32_t pb = 4u * hidx + 2u * cc;
+        v4f *slot2 = ring + slot_i * kBlkSlotV4;
+        slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
+        v4f u4[4];
+        auto quad = [&](const uint32_t c, const bool zeroing) {
           float zc[4], zs[4];
           if (UNI) {
-            const v4f z01 = ztile[c * 2u], z23 = ztile[c * 2u + 1u];
-            zc[0] = z01.x; zs[0] = z01.y; zc[1] = z01.z; zs[1] = z01.w;
-            zc[2] = z23.x; zs[2] = z23.y; zc[3] = z23.z; zs[3] = z23.w;
+            zc[0] = zz[2 * c].x; zs[0] = zz[2 * c].y; zc[1] = zz[2 * c].z; zs[1] = zz[2 * c].w;
+            zc[2] = zz[2 * c + 1].x; zs[2] = zz[2 * c + 1].y; zc[3] = zz[2 * c + 1].z; zs[3] = zz[2 * c + 1].w;
           } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -485,30 +494,30 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
               zr = nr; zi = ni;
             }
           }
-          const float y[4] = {y4.x, y4.y, y4.z, y4.w};
+          const float y[4] = {y4[c].x, y4[c].y, y4[c].z, y4[c].w};
+          const uint32_t pb = 4u * hidx + 2u * c;
           float oi[4], oq[4];
-          if (FSK_ABL(1)) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) oi[j] = oq[j] = y[j] + zc[j];
-          } else if (__builtin_expect(zh != 0ull, 0)) {
-            asm volatile("s_nop 0");
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              if (!(j & 1)) front_zero(F, zj == pb + (uint32_t)(j >> 1));
-              front_mix_lp(F, K, y[j], zc[j], zs[j], oi[j], oq[j]);
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) front_mix_lp(F, K, y[j], zc[j], zs[j], oi[j], oq[j]);
+          for (int j = 0; j < 4; j++) {
+            if (FSK_ABL(1)) { oi[j] = oq[j] = y[j] + zc[j]; continue; }
+            if (zeroing && !(j & 1)) front_zero(F, zj == pb + (uint32_t)(j >> 1));
+            front_mix_lp(F, K, y[j], zc[j], zs[j], oi[j], oq[j]);
           }
-          slot[cc * 64u + lane] = (v4f){oi[0] + oi[1], oq[0] + oq[1], oi[2] + oi[3], oq[2] + oq[3]};   // U (I, Q) x 2
+          u4[c] = (v4f){oi[0] + oi[1], oq[0] + oq[1], oi[2] + oi[3], oq[2] + oq[3]};   // U (I, Q) x 2
+        };
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(zj - 4u * hidx < 8u) != 0ull, 0)) {
+          asm volatile("s_nop 0");
+          quad(0, true); quad(1, true); quad(2, true); quad(3, true);
+        } else {
+          quad(0, false); quad(1, false); quad(2, false); quad(3, false);
         }
-        hidx++;
+        slot[lane] = u4[0]; slot[64u + lane] = u4[1]; slot2[lane] = u4[2]; slot2[64u + lane] = u4[3];
+        hidx += 2u;
         lds_post(&ctr[1], hidx);                              // for the discriminator wave
         produced = lds_peek4_get(cv, 0); consumed = lds_peek4_get(cv, 3);
         lim = lim0 < produced ? lim0 : produced;
         lim = lim < consumed + kBlkSlots ? lim : consumed + kBlkSlots;
-      } while (hidx < lim);
+      } while (hidx + 2u <= lim);
     }
     FSK_STAMP_END(1)
     fin[lane] = (v4f){F.ix1, F.ix2, F.iy, F.iv};
@@ -529,14 +538,14 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     uint64_t qlive = __builtin_amdgcn_ballot_w64((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f));   // (raw masks: no bool round trips)
     uint32_t produced = 0, slot_i = 0;
     FSK_STAMP_BEGIN
-    uint32_t hidx = 0;
+    uint32_t hidx = 0;                                        // half tiles done; a tile (two of them, eight decimated samples) at a time
     while (hidx < nh) {
       if ((hidx & 63u) == 0u) blk_prio(hidx, wgj);
-      if (produced <= hidx) {
+      if (produced < hidx + 2u) {
         FSK_STAMP_W0
-        while (produced <= hidx) {
+        while (produced < hidx + 2u) {
           produced = lds_peek(&ctr[1]);
-          if (produced <= hidx) __builtin_amdgcn_s_sleep(1);
+          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(1);
         }
         FSK_STAMP_W1
       }
@@ -548,16 +557,18 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         lds_peek4_begin(ctr, cv);
         v4f *slot = ring + slot_i * kBlkSlotV4;
         slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
-        const v4f ua = slot[lane], ub = slot[64u + lane];
+        v4f *slot2 = ring + slot_i * kBlkSlotV4;
+        slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
+        const v4f ua = slot[lane], ub = slot[64u + lane], uc = slot2[lane], ud = slot2[64u + lane];
         const uint32_t kq = cmail[lane];
         const uint32_t ow = 4u * hidx - cmail[320u + lane];     // decimated samples since the back wave's own span began
-        const float ui[4] = {ua.x, ua.z, ub.x, ub.z}, uq[4] = {ua.y, ua.w, ub.y, ub.w};
-        float ph[4], am[4];
-        // one test for everything that is not the plain discriminator: a hand-over due in this half tile, a lane inside
-        // the back wave's own span, a live correction
-        if (__builtin_expect((__builtin_amdgcn_ballot_w64((kq - 4u * hidx < 4u) | (ow < kHandPairs)) | qlive) != 0ull, 0)) {
+        const float ui[8] = {ua.x, ua.z, ub.x, ub.z, uc.x, uc.z, ud.x, ud.z}, uq[8] = {ua.y, ua.w, ub.y, ub.w, uc.y, uc.w, ud.y, ud.w};
+        float ph[8], am[8];
+        // one test for everything that is not the plain discriminator: a hand-over due in this tile, a lane inside the
+        // back wave's own span, a live correction
+        if (__builtin_expect((__builtin_amdgcn_ballot_w64((kq - 4u * hidx < 8u) | (ow < kHandPairs)) | qlive) != 0ull, 0)) {
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
+          for (int j = 0; j < 8; j++) {
             if (kq == 4u * hidx + (uint32_t)j) {              // the back wave's correction becomes this wave's here
               Qz.ai = __builtin_bit_cast(float, cmail[64u + lane]); Qz.aq = __builtin_bit_cast(float, cmail[128u + lane]);
               Qz.bi = __builtin_bit_cast(float, cmail[192u + lane]); Qz.bq = __builtin_bit_cast(float, cmail[256u + lane]);
@@ -579,18 +590,20 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
           qlive = __builtin_amdgcn_ballot_w64((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f));
         } else if (FSK_ABL(2)) {
 #pragma unroll
-          for (int j = 0; j < 4; j++) { ph[j] = ui[j]; am[j] = uq[j]; }
+          for (int j = 0; j < 8; j++) { ph[j] = ui[j]; am[j] = uq[j]; }
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; j++) ph[j] = atan2_amp_fma(uq[j], ui[j], am[j], tiny, sgn);
+          for (int j = 0; j < 8; j++) ph[j] = atan2_amp_fma(uq[j], ui[j], am[j], tiny, sgn);
         }
-        slot[lane] = (v4f){ph[0], am[0], ph[1], am[1]};       // in place: wave 1 will not touch the slot before the back wave frees it
+        slot[lane] = (v4f){ph[0], am[0], ph[1], am[1]};       // in place: wave 1 will not touch the slots before the back wave frees them
         slot[64u + lane] = (v4f){ph[2], am[2], ph[3], am[3]};
-        hidx++;
+        slot2[lane] = (v4f){ph[4], am[4], ph[5], am[5]};
+        slot2[64u + lane] = (v4f){ph[6], am[6], ph[7], am[7]};
+        hidx += 2u;
         lds_post(&ctr[2], hidx);
         produced = lds_peek4_get(cv, 1);
         lim = lim0 < produced ? lim0 : produced;
-      } while (hidx < lim);
+      } while (hidx + 2u <= lim);
     }
     FSK_STAMP_END(2)
     fin[128u + lane] = (v4f){Qz.ai, Qz.aq, Qz.bi, Qz.bq};
