@@ -162,6 +162,19 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #ifndef FSK_BLK_PRIO
 #define FSK_BLK_PRIO 1
 #endif
+// s_sleep argument (x 64 cycles) of each wave's hand-off poll
+#ifndef FSK_BLK_SLEEP_A
+#define FSK_BLK_SLEEP_A 1
+#endif
+#ifndef FSK_BLK_SLEEP_B
+#define FSK_BLK_SLEEP_B 1
+#endif
+#ifndef FSK_BLK_SLEEP_C
+#define FSK_BLK_SLEEP_C 1
+#endif
+#ifndef FSK_BLK_SLEEP_D
+#define FSK_BLK_SLEEP_D 1
+#endif
 __device__ inline void blk_prio(uint32_t hidx, uint32_t wgj) {
 #if FSK_BLK_PRIO
   if ((hidx & 63u) == 0u) {
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         FSK_STAMP_W0
         while (hidx + 1u - consumed >= NY) {                // ring full: the back wave (which may still need the slots'
           consumed = lds_peek(&ctr[3]);                     // pre-filter outputs after a reset) has not released them
-          if (hidx + 1u - consumed >= NY) __builtin_amdgcn_s_sleep(1);
+          if (hidx + 1u - consumed >= NY) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_A);
         }
         FSK_STAMP_W1
       }
@@ -439,11 +452,11 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         FSK_STAMP_W0
         while (produced < hidx + 2u) {                        // wave 0's tile
           produced = lds_peek(&ctr[0]);
-          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(1);
+          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_B);
         }
         while (hidx + 2u - consumed > kBlkSlots) {           // ring full: wait for the back wave
           consumed = lds_peek(&ctr[3]);
-          if (hidx + 2u - consumed > kBlkSlots) __builtin_amdgcn_s_sleep(1);
+          if (hidx + 2u - consumed > kBlkSlots) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_B);
         }
         FSK_STAMP_W1
       }
@@ -545,7 +558,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         FSK_STAMP_W0
         while (produced < hidx + 2u) {
           produced = lds_peek(&ctr[1]);
-          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(1);
+          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_C);
         }
         FSK_STAMP_W1
       }
@@ -653,7 +666,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         FSK_STAMP_W0
         while (produced < t + 2u) {
           produced = lds_peek(&ctr[2]);
-          if (produced < t + 2u) __builtin_amdgcn_s_sleep(1);
+          if (produced < t + 2u) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_D);
         }
         FSK_STAMP_W1
       }
@@ -838,7 +851,8 @@ static inline void set_ablate_blk() {}
 #endif
 
 // Time slices (see BlkSched): only when the batch needs more than one round of resident workgroups and the call is long
-// enough for at least two slices.  slice_tiles = 0 picks kBlkSliceTiles (or what keeps a group within kBlkMaxSlices).
+// enough for at least two slices.  slice_tiles = 0 starts from kBlkSliceTiles (or what keeps a group within
+// kBlkMaxSlices) and then picks the slice count that packs best (below).
 static constexpr uint32_t kBlkSliceTiles = 768;    // 12 288 samples
 static constexpr uint32_t kBlkMaxSlices = 128;
 size_t demod_blk_queue_words(uint32_t groups) { return 16u + (size_t)groups * (kBlkMaxSlices - 1u); }
@@ -858,7 +872,22 @@ hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, c
     uint32_t st = slice_tiles ? slice_tiles : kBlkSliceTiles;
     const uint32_t st_min = (n_tiles + kBlkMaxSlices - 1u) / kBlkMaxSlices;
     st = st < st_min ? st_min : st;
-    const uint32_t ns = (n_tiles + st - 1u) / st;
+    uint32_t ns = (n_tiles + st - 1u) / st;
+    if (!slice_tiles && ns >= 2u) {
+      // How many slices: items are handed out whole, so groups * ns items on `resident` workgroups take about
+      // ceil(groups * ns / resident) slice times -- 1 088 groups in 8 slices need 9 of them (1.125 rounds) where 16
+      // slices need 17 (1.0625) -- and every slice change costs ~17 us (1.1 % of a 768-tile slice at config #3's rate).
+      double best = 1e30;
+      uint32_t best_ns = ns;
+      for (uint32_t c = ns; c <= 4u * ns && c <= kBlkMaxSlices && (n_tiles + c - 1u) / c >= 96u; c++) {
+        const double rounds = (double)(((uint64_t)blocks * c + resident_wgs - 1u) / resident_wgs) / (double)c;
+        const double cost = rounds * (1.0 + 0.011 * (double)c / (double)ns);
+        if (cost < best - 1e-9) { best = cost; best_ns = c; }
+      }
+      ns = best_ns;
+      st = (n_tiles + ns - 1u) / ns;
+      ns = (n_tiles + st - 1u) / st;
+    }
     if (ns >= 2u) {
       sliced = true;
       Z.q = S.blk_q; Z.nslices = ns; Z.slice_tiles = st; Z.total = blocks * ns;

@@ -12,9 +12,11 @@
 
 namespace fsk {
 
-// Stage ablation (tools/stage_times.py, -DFSK_ABLATE builds only): bit w of g_ablate set = wave w of a group skips its
-// arithmetic and only moves data (loads, LDS hand-off, counters), so that the remaining waves set the pace.  Results are
-// wrong by construction; only the kernel time is read.  Compiled out of the shipped library.
+// Stage ablation (-DFSK_ABLATE builds only: tools/build_variant.sh abl -DFSK_ABLATE, then tools/variants.py
+// "label@abl:FSK_ABLATE=mask"): bit w of g_ablate set = wave w of a group skips its arithmetic and only moves data
+// (loads, LDS hand-off, counters), so that the remaining waves set the pace; bit 3 in fsk_blk.hip = the back wave never
+// takes its per-sample path.  Results are wrong by construction; only the kernel time is read.  Compiled out of the
+// shipped library.
 #ifdef FSK_ABLATE
 static __device__ int g_ablate;
 #define FSK_ABL_INIT const int abl_mask = __builtin_amdgcn_readfirstlane(g_ablate);
