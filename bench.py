@@ -592,9 +592,10 @@ def worker(args):
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                 "binding_bound": "valu_issue",
                 "valu_issue": issue,
-                "binding_note": "the kernel is bound by vector instruction issue, not by HBM (DESIGN.md section 5): `frac` is "
-                                "the HBM fraction BASELINE.json's metric asks for, `valu_issue.frac` is the same run against the "
-                                "ceiling that binds",
+                "binding_note": "the kernel is bound by SIMD time -- vector instruction issue (half-rate and transcendental "
+                                "classes included) plus the cycles every branch / LDS / memory instruction costs its wave -- "
+                                "not by HBM (DESIGN.md section 5): `frac` is the HBM fraction BASELINE.json's metric asks "
+                                "for, `valu_issue.frac` is the same run's vector instructions against the SIMDs' issue peak",
             },
             "cpu_baseline": cpu_obj,
         }

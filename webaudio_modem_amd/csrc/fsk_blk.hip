@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
               X.kv += 1u;
               uint32_t *ps = prow + pidx + 2u * c + (uint32_t)h;
               const uint32_t r_old = *ps;
-              back_pair<UNI, true, false, true>(B, K, P, S, M, ps, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
+              back_pair<UNI, true, false, true, SL ? kCoh : 0>(B, K, P, S, M, ps, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
                                                 h ? u4.z : u4.x, h ? u4.w : u4.y, yp + 2 * h, r_old, inc, h ? pa.z : pa.x, h ? pa.w : pa.y);
               amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
             }

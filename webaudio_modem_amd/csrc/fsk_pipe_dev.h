@@ -404,9 +404,11 @@ __device__ inline void zir_step(BackLane &B, const BackK &K, BackU &X, float Ui,
 // same function, same inputs where nothing changed, so the result does not depend on which wave computed it.
 // TRC: honour fskhip_trace_enable and fskhip_enable_signal_quality (the sample-granular kernel only; an engine with
 // either switched on runs entirely on it).
+// AMP_AUX: cache policy of the amplitude ring's store (kCoh in fsk_blk.hip's time-sliced launches, whose next slice may read
+// the ring behind another L2).
 // HAND (fsk_blk.hip's back wave): the correction belongs to this wave only while zr_dph < kHandPairs; after that the
 // discriminator wave applies it and ph_u / amp_u already are the corrected pair sum's.
-template <bool UNI, bool PA = false, bool TRC = false, bool HAND = false>
+template <bool UNI, bool PA = false, bool TRC = false, bool HAND = false, int AMP_AUX = 0>
 __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams &P, const DemodState &S, const FastMem &M,
                                  uint32_t *pslot, uint32_t lane, __amdgpu_buffer_rsrc_t amp_rsrc, uint8_t *out,
                                  uint32_t out_pitch, uint32_t *eod_counts, BackU &X, float Ui, float Uq,
@@ -440,7 +442,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   *pslot = r;                                                  // (the polyphase register of this push slot)
   B.matched += (uint32_t)__builtin_popcount((r ^ qn) & mask);
   B.matched -= (uint32_t)__builtin_popcount((r_old ^ qn) & mask);
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, M.avoff, X.amp_soff, kCoh);  // syncAmplitudeBuffer.put
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, M.avoff, X.amp_soff, AMP_AUX);  // syncAmplitudeBuffer.put
   {
     const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, amp - B.thr));   // amp < threshold (fsk.ts:285)
     B.ls = (B.ls & silent) | (X.kv & ~silent);                 // silence run = k - ls (fsk.ts:285-295)
