@@ -210,6 +210,32 @@ def test_whole_tile_kernels_agree_on_ragged_batches(S, monkeypatch):
     gen.close()
 
 
+@pytest.mark.parametrize("S", [200, 4096])
+def test_y_ring_depth_does_not_change_results(S, monkeypatch):
+    """demod_blk_kernel's y ring (wave 0 -> wave 1) takes whatever LDS the batch leaves (fsk_blk.hip, demod_blk_plan): 6 half
+    tiles at least, an odd number and the maximum included here; bytes and eod counts must not depend on it."""
+    import webaudio_modem_amd as wm
+    N = 48000
+    gen = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    d_x = gen.device_malloc(S * N * 4)
+    gen.synth_device(d_x, N, N, 12, SEED + 11, 300, 0.1, 1.0)
+    gen.synchronize()
+    digests = {}
+    for y in ("auto", "6", "7", "12", "28"):
+        if y != "auto":
+            monkeypatch.setenv("FSKHIP_BLK_YSLOTS", y)
+        eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+        monkeypatch.delenv("FSKHIP_BLK_YSLOTS", raising=False)
+        rows, eod = _demod_schedule(eng, d_x, N, N, [20000, 4096, 16, 1000, 48, 999, 8000])
+        assert "demod_blk_kernel" in eng.last_kernel()
+        digests[y] = (_digest(rows, eod), sum(len(r) for r in rows))
+        eng.close()
+    assert len(set(digests.values())) == 1, digests
+    assert digests["auto"][1] >= 12 * S * 0.4
+    gen.device_free(d_x)
+    gen.close()
+
+
 @pytest.mark.parametrize("S,resident,slice_tiles", [(1000, 5, 1), (1000, 3, 7), (4096, 16, 64), (4096, 63, 3)])
 def test_time_sliced_persistent_launch_matches_one_workgroup_per_group(S, resident, slice_tiles, monkeypatch):
     """Batches beyond one round of resident workgroups run demod_blk_kernel persistently over (group, time slice) items
@@ -245,6 +271,48 @@ def test_time_sliced_persistent_launch_matches_one_workgroup_per_group(S, reside
     assert digests["plain"] == digests["sliced"], digests
     assert digests["plain"][1] >= 12 * S * 0.4
     gen.device_free(d_x)
+    gen.close()
+
+
+def test_time_sliced_launch_with_agc_write_back(monkeypatch):
+    """FSKHIP_DEMOD_WRITEBACK_AGC through the time-sliced launch: wave 0 writes the AGC'd samples over its input slice by
+    slice; the buffer afterwards and the decoded bytes must equal the plain launch's."""
+    import webaudio_modem_amd as wm
+    from webaudio_modem_amd._lib import DEMOD_WRITEBACK_AGC
+    S, N = 1000, 32000
+    gen = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    d_src = gen.device_malloc(S * N * 4)
+    gen.synth_device(d_src, N, N, 12, SEED + 13, 300, 0.1, 1.0)
+    gen.synchronize()
+    src = np.empty((S, N), np.float32)
+    gen.d2h(src, d_src)
+    results = {}
+    for name, env in (("plain", {"FSKHIP_SLICE_TILES": "off"}), ("sliced", {"FSKHIP_BLK_RESIDENT": "4", "FSKHIP_SLICE_TILES": "9"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+        for k in env:
+            monkeypatch.delenv(k)
+        d_x = eng.device_malloc(S * N * 4)
+        eng.h2d(d_x, src)
+        op = eng.max_bytes(N)
+        d_out, d_cnt, d_eod = eng.device_malloc(S * op), eng.device_malloc(S * 4), eng.device_malloc(S * 4)
+        eng.demodulate_device(d_x, N, N, d_out, op, d_cnt, d_eod, DEMOD_WRITEBACK_AGC)
+        eng.synchronize()
+        assert eng.last_kernel().startswith("fsk::demod_blk_kernel<true,") and eng.last_kernel().endswith("true>" if name == "sliced" else "false>"), eng.last_kernel()
+        x = np.empty((S, N), np.float32)
+        out = np.empty((S, op), np.uint8)
+        cnt = np.empty(S, np.uint32)
+        eng.d2h(x, d_x); eng.d2h(out, d_out); eng.d2h(cnt, d_cnt)
+        results[name] = (x, [out[s, :cnt[s]].tobytes() for s in range(S)])
+        for p_ in (d_x, d_out, d_cnt, d_eod):
+            eng.device_free(p_)
+        eng.close()
+    assert results["plain"][1] == results["sliced"][1]
+    assert np.array_equal(results["plain"][0].view(np.uint32), results["sliced"][0].view(np.uint32))
+    assert not np.array_equal(results["plain"][0], src)      # (the AGC did write)
+    assert sum(len(r) for r in results["plain"][1]) >= 12 * S * 0.4
+    gen.device_free(d_src)
     gen.close()
 
 

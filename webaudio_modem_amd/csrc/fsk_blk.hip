@@ -175,14 +175,35 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #ifndef FSK_BLK_SLEEP_D
 #define FSK_BLK_SLEEP_D 1
 #endif
-__device__ inline void blk_prio(uint32_t hidx, uint32_t wgj) {
-#if FSK_BLK_PRIO
-  if ((hidx & 63u) == 0u) {
-    switch (((hidx >> 6) + wgj) & 3u) {
+#ifndef FSK_BLK_PRIO_PERIOD
+#define FSK_BLK_PRIO_PERIOD 64
+#endif
+__device__ inline void blk_prio(uint32_t hidx, uint32_t wgj, uint32_t role = 0) {
+#if FSK_BLK_PRIO == 1
+  if ((hidx & (FSK_BLK_PRIO_PERIOD - 1u)) == 0u) {
+    switch (((hidx / FSK_BLK_PRIO_PERIOD) + wgj) & 3u) {
       case 0: __builtin_amdgcn_s_setprio(0); break;
       case 1: __builtin_amdgcn_s_setprio(1); break;
       case 2: __builtin_amdgcn_s_setprio(2); break;
       default: __builtin_amdgcn_s_setprio(3); break;
+    }
+  }
+#elif FSK_BLK_PRIO == 2      // (measurement builds) by part: the back wave first
+  if (hidx == 0u) {
+    switch (role) {
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
+  }
+#elif FSK_BLK_PRIO == 3      // (measurement builds) the back wave always highest, the others rotate over three levels
+  if (role == 3u) { if (hidx == 0u) __builtin_amdgcn_s_setprio(3); }
+  else if ((hidx & (FSK_BLK_PRIO_PERIOD - 1u)) == 0u) {
+    switch (((hidx / FSK_BLK_PRIO_PERIOD) + wgj) % 3u) {
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      default: __builtin_amdgcn_s_setprio(2); break;
     }
   }
 #endif
@@ -410,7 +431,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     const uint32_t nt = (uint32_t)n_tiles;
     FSK_STAMP_BEGIN
     for (uint32_t t0 = 0; t0 < nt; t0 += 96u) {             // (a multiple of three tiles and of 64 half tiles)
-      blk_prio(2u * t0, wgj);
+      blk_prio(2u * t0, wgj, 0u);
       const uint32_t te = t0 + 96u < nt ? t0 + 96u : nt;
       for (uint32_t t = t0; t < te; t += 3) {
         do_tile(t, a0, a1, a2, a3);
@@ -447,7 +468,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     FSK_STAMP_BEGIN
     uint32_t hidx = 0;                                        // half tiles done; this wave works a tile (two of them) at a time
     while (hidx < nh) {
-      if ((hidx & 63u) == 0u) blk_prio(hidx, wgj);
+      if ((hidx & 63u) == 0u) blk_prio(hidx, wgj, 1u);
       if (produced < hidx + 2u || hidx + 2u - consumed > kBlkSlots) {
         FSK_STAMP_W0
         while (produced < hidx + 2u) {                        // wave 0's tile
@@ -553,7 +574,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     FSK_STAMP_BEGIN
     uint32_t hidx = 0;                                        // half tiles done; a tile (two of them, eight decimated samples) at a time
     while (hidx < nh) {
-      if ((hidx & 63u) == 0u) blk_prio(hidx, wgj);
+      if ((hidx & 63u) == 0u) blk_prio(hidx, wgj, 2u);
       if (produced < hidx + 2u) {
         FSK_STAMP_W0
         while (produced < hidx + 2u) {
@@ -661,7 +682,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     FSK_STAMP_BEGIN
     uint32_t t = 0;                                           // half tiles consumed (a block = a tile = two of them)
     while (t < nh) {
-      blk_prio(t & ~15u, wgj);                               // (t advances in steps of two; the outer loop sees every multiple of 16)
+      blk_prio(t & ~15u, wgj, 3u);                            // (t advances in steps of two; the outer loop sees every multiple of 16)
       if (produced < t + 2u) {
         FSK_STAMP_W0
         while (produced < t + 2u) {
