@@ -80,6 +80,15 @@ def main(budget=None, seed=None, max_rounds=None):
         if target and os.environ.get("SOAK_FORCE_SPLIT"):
             os.environ["FSKHIP_SPLIT"] = os.environ["SOAK_FORCE_SPLIT"]
         os.environ["FSKHIP_SPLIT_LAST"] = os.environ["FSKHIP_SPLIT"]
+        # the four-wave block kernel's launch shapes (its own generator: the main random stream stays replayable): a
+        # "device" of 1-3 resident workgroups so that batches of 2-5 groups run persistent and time-sliced, slices down to
+        # one tile, y rings of every depth class
+        knobs = {}
+        krng = np.random.default_rng((seed * 1000003 + rounds) & 0x7FFFFFFF)
+        if os.environ["FSKHIP_SPLIT"] == "4" and krng.random() < 0.6:
+            knobs = {"FSKHIP_BLK_RESIDENT": str(int(krng.integers(1, 4))), "FSKHIP_SLICE_TILES": str(int(krng.choice([1, 2, 5, 16, 64]))),
+                     "FSKHIP_BLK_YSLOTS": str(int(krng.choice([6, 7, 8, 12, 28])))}
+            os.environ.update(knobs)
         # a quarter of the rounds: per-stream tone pairs (BASELINE config #4) -> the per-stream-constant kernel variants
         per_stream = rng.random() < 0.25 and "markFrequency" not in cfg and cfg.get("sampleRate", 48000) == 48000
         if per_stream:
@@ -90,8 +99,10 @@ def main(budget=None, seed=None, max_rounds=None):
         writeback = rng.random() < 0.3
         eng = wm.FSKEngine(S, cfgs if per_stream else cfg, precision=prec)
         os.environ.pop("FSKHIP_SPLIT")
+        for k_ in knobs:
+            os.environ.pop(k_)
         if os.environ.get("SOAK_VERBOSE"):
-            print("round", rounds, cfg, "prec", prec, "S", S, "split", eng and os.environ.get("FSKHIP_SPLIT_LAST"), flush=True)
+            print("round", rounds, cfg, "prec", prec, "S", S, "split", eng and os.environ.get("FSKHIP_SPLIT_LAST"), knobs, flush=True)
         if not eng.demod_supported():
             eng.close()
             continue
