@@ -1,6 +1,6 @@
 #!/bin/bash
 # which waves get the SIMD first
-out=gpurun_out/exp34; mkdir -p $out
+out=gpurun_out/experiment; mkdir -p $out
 N=96000
 {
 for S in 32768 65536 131072; do

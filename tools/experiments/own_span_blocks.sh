@@ -1,6 +1,6 @@
 #!/bin/bash
 # own-span tiles on the block path: parity first, then timing
-out=gpurun_out/exp26; mkdir -p $out
+out=gpurun_out/experiment; mkdir -p $out
 FSKHIP_SPLIT=4 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "golden and four" > $out/parity.txt 2>&1
 tail -2 $out/parity.txt
 grep -q " passed" $out/parity.txt || exit 1

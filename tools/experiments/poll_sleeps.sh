@@ -1,6 +1,6 @@
 #!/bin/bash
 # hand-off poll sleeps
-out=gpurun_out/exp31; mkdir -p $out
+out=gpurun_out/experiment; mkdir -p $out
 N=96000
 {
 for S in 8192 65536 131072; do

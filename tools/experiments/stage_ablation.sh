@@ -1,6 +1,6 @@
 #!/bin/bash
 # where the four waves' time goes now (y ring 16 deep), and what the per-sample slow path costs (ablation: skip it)
-out=gpurun_out/exp25; mkdir -p $out
+out=gpurun_out/experiment; mkdir -p $out
 N=96000
 {
 for S in 8192 65536; do

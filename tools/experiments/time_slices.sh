@@ -1,6 +1,6 @@
 #!/bin/bash
 # time-sliced persistent launch: parity first, then the sweep across the cliff
-out=gpurun_out/exp21; mkdir -p $out
+out=gpurun_out/experiment; mkdir -p $out
 timeout 300 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "time_sliced" > $out/tests_small.txt 2>&1
 tail -3 $out/tests_small.txt
 grep -q passed $out/tests_small.txt || exit 1

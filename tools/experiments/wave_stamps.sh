@@ -1,5 +1,5 @@
 #!/bin/bash
-out=gpurun_out/exp27; mkdir -p $out
+out=gpurun_out/experiment; mkdir -p $out
 N=96000
 {
 for S in 8192 65536; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # y-ring depth sweep
-out=gpurun_out/exp23; mkdir -p $out
+out=gpurun_out/experiment; mkdir -p $out
 N=96000
 {
 for S in 4096 8192 16384 32768 49152; do
