@@ -341,6 +341,64 @@ def test_ragged_stream_count_and_odd_lengths(pname, prec, tol):
     eng.close()
 
 
+@pytest.mark.parametrize("baud", [600, 400, 240], ids=["dsSPB_40", "dsSPB_60", "dsSPB_100"])
+def test_other_bit_cells_through_the_block_kernel(baud, monkeypatch):
+    """The block kernel takes dsSPB = multiples of 4 whose sync-ring capacity -- (bits + 32) * dsSPB * 1.1 evaluated in
+    doubles, fsk.ts:145,149 -- is an integer: 20 (the goldens' 1200 baud), 40, 80 (300 baud) with the default 24 pattern
+    bits; 60 and 100 give 3696.0000000000005 and 6160.000000000001, fractional rings, the generic kernel.  Here 40 (other
+    polyphase stride in LDS, register wraps at other blocks) and the two fractional ones for the routing: 130 streams
+    with different payloads, lead-ins and levels, a ragged call schedule, against the oracle; FSKHIP_SPLIT=1 on the same
+    buffers as a cross-check."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    cfg = dict(baudRate=baud, markFrequency=2 * baud, spaceFrequency=3 * baud)
+    S = 130
+    rng = np.random.RandomState(baud)
+    sigs = []
+    for s in range(S):
+        o = po.OracleCore(cfg)
+        parts = [np.zeros(rng.randint(0, 300), np.float32)]
+        for _ in range(3):
+            parts += [o.modulate(bytes(rng.randint(0, 256, rng.randint(1, 9)).astype(np.uint8))) * np.float32(rng.uniform(0.1, 1.0)),
+                      np.zeros(rng.randint(50, 2500), np.float32)]
+        sigs.append(np.concatenate(parts))
+    N = max(len(x) for x in sigs)
+    x = np.zeros((S, N), np.float32)
+    for s in range(S):
+        x[s, :len(sigs[s])] = sigs[s]
+    x[S // 2:] += (rng.standard_normal((S - S // 2, N)) * 0.02).astype(np.float32)      # half of them over a noise floor
+    want, want_eod = [], []
+    for s in range(S):
+        b, e = po.OracleCore(cfg).demodulate(x[s])
+        want.append(b)
+        want_eod.append(e)
+    assert sum(len(w) for w in want) > 2 * S      # (the reference itself drops frames that follow a gap too closely)
+    for split in ("4", "1"):
+        monkeypatch.setenv("FSKHIP_SPLIT", split)
+        eng = wm.FSKEngine(S, cfg, precision=wm.PRECISION_F32)
+        monkeypatch.delenv("FSKHIP_SPLIT")
+        got = [b""] * S
+        eods = np.zeros(S, np.int64)
+        off = 0
+        for n in [4096, 16, 1000, 48, 3, 8000, 129, 10 ** 9]:
+            n = min(n, N - off)
+            if n <= 0:
+                break
+            out, eod = eng.demodulate_data(x[:, off:off + n])
+            for s in range(S):
+                got[s] += out[s]
+            eods += eod
+            off += n
+        if split == "4":
+            d = 48000 // 2 // baud
+            whole_tiles = ((24 + 32) * d * 1.1).is_integer()      # fsk.ts:145,149 in doubles: 2464.0 but 3696.0000000000005
+            assert eng.last_kernel().startswith(("fsk::demod_blk_kernel", "fsk::demod_tail_kernel") if whole_tiles else "fsk::demod_kernel<float"), eng.last_kernel()
+        eng.close()
+        for s in range(S):
+            assert got[s] == want[s], (split, s)
+            assert int(eods[s]) == want_eod[s], (split, s)
+
+
 def test_single_stream_reset_desynchronises_decimator():
     """reset(stream) at an odd sample count leaves that stream's /2 decimator out of phase with its
     neighbours (per-lane decimation path of the kernel)."""

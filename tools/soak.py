@@ -18,6 +18,9 @@ CONFIGS = [
     dict(baudRate=300, markFrequency=1070, spaceFrequency=1270), dict(parity="even"), dict(stopBits=2),
     dict(preamblePattern=[0x55, 0x55, 0x55], sfdPattern=[0x7E]), dict(sampleRate=44100), dict(agcEnabled=False),
     dict(baudRate=2400, markFrequency=2400, spaceFrequency=4800), dict(syncThreshold=0.75),
+    # dsSPB = 8, 12, 16: the block kernel's smallest bit cells (one decision per eight-sample block at most)
+    dict(baudRate=3000, markFrequency=3000, spaceFrequency=6000), dict(baudRate=2000, markFrequency=2000, spaceFrequency=4000),
+    dict(baudRate=1500, markFrequency=1500, spaceFrequency=3000),
 ]
 KEYS = ["frameStarted", "globalSampleCounter", "receivedBitsLength", "syncDetections"]
 # Known, documented divergence of the fp32 path ("fp32 in exact-zero tails"): with a lowered syncThreshold the

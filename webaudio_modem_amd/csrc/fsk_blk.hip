@@ -815,6 +815,8 @@ size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots) {
 }
 size_t demod_blk_lds_bytes(const DemodParams &P) { return demod_blk_lds_bytes(P, kBlkSlots); }
 // the block path needs whole blocks of polyphase registers (dsSPB a multiple of 4) and at most one bit decision per block
+// (in practice dsSPB = 20, 40, 80: the whole-tile kernels only see configurations whose sync-ring capacity, (bits + 32) *
+// dsSPB * 1.1 in doubles, is an integer -- fsk_api.hip)
 bool demod_blk_applicable(const DemodParams &P) { return P.d >= 8u && (P.d & 3u) == 0u && !P.wide && !P.frac; }
 
 hipError_t set_blk_lds_limit(const DemodParams &P) {
