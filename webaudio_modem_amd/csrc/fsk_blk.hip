@@ -91,25 +91,33 @@ __device__ inline uint32_t blk_fast(BackLane &Bn, const BackK &K, const BlkK &Q,
   am[0] = pa[0].y; am[1] = pa[0].w; am[2] = pa[1].y; am[3] = pa[1].w;
   am[4] = pa[2].y; am[5] = pa[2].w; am[6] = pa[3].y; am[7] = pa[3].w;
   uint32_t w = 0, rare = 0;
-  const uint32_t ls0 = Bn.ls;
-  uint32_t kvj = kv0;
+  // inside the block the correlator's count is carried as its distance to the threshold and the last loud sample as its
+  // index relative to the block (1 .. kBlk, or <= 0 for "before it"): the per-sample test is then one operation and the
+  // sample index an inline constant
+  uint32_t dm = Bn.matched - Bn.thr_eff;
+  const uint32_t lsr0 = Bn.ls - kv0;
+  uint32_t lsr = lsr0;
 #pragma unroll
   for (int j = 0; j < kBlk; j++) {
-    kvj += 1u;
     const float f = disc_post(Bn, K, phs[j], am[j]);                        // fsk.ts:251-261
-    const uint32_t bit = sign_bit(__builtin_bit_cast(uint32_t, 0.0f - f));   // fsk.ts:264
+    // slicer (fsk.ts:264): the bit is the sign of 0 - f (f = +-0 gives +0, bit 0); it is shifted into the registers
+    // straight from there (v_alignbit: {hi, lo} >> 31 = hi << 1 | sign of lo) without being extracted first
+    const uint32_t nf = __builtin_bit_cast(uint32_t, 0.0f - f);
     const uint32_t rold = rp[j];
-    const uint32_t r = rold + rold + bit;                                    // syncSamplesBuffer.put(bit)
+    const uint32_t r = __builtin_amdgcn_alignbit(rold, nf, 31);              // syncSamplesBuffer.put(bit)
     rp[j] = r;
-    Bn.matched += (uint32_t)__builtin_popcount((r ^ K.qn) & K.mask);
-    Bn.matched -= (uint32_t)__builtin_popcount((rold ^ K.qn) & K.mask);
-    rare |= ~(Bn.matched - Bn.thr_eff);                                      // sign set <=> matched >= thr_eff (sync candidate)
+    dm += (uint32_t)__builtin_popcount((r ^ K.qn) & K.mask);
+    dm -= (uint32_t)__builtin_popcount((rold ^ K.qn) & K.mask);
+    rare |= ~dm;                                                             // sign set <=> matched >= thr_eff (sync candidate)
     const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, am[j] - Bn.thr));   // fsk.ts:285
-    Bn.ls = (Bn.ls & silent) | (kvj & ~silent);
-    w = w + w + bit;                                                         // sample 1 ends up in bit kBlk - 1
+    lsr = (lsr & silent) | ((uint32_t)(j + 1) & ~silent);
+    w = __builtin_amdgcn_alignbit(w, nf, 31);                                // sample 1 ends up in bit kBlk - 1
   }
+  Bn.matched = dm + Bn.thr_eff;
+  Bn.ls = lsr + kv0;
   // 'eod' (fsk.ts:288): no silence run inside the block is longer than the one a wholly silent block would end with
-  rare |= K.eod_m1 - (kvj - ls0);
+  // (eod_m1 - ((kv0 + kBlk) - ls at entry))
+  rare |= K.eod_m1 - (uint32_t)kBlk + lsr0;
   // ---- bit clock, once per block (fsk.ts:335-341): decision at sample jd of the block
   uint32_t jd = Bn.T - kv0;                        // 1..kBlk in this block; 0 right after a sync (nextBitSampleIndex = k)
   jd -= neg_mask(jd - 1u);                         // 0 -> 1
