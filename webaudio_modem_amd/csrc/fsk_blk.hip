@@ -57,6 +57,7 @@ namespace fsk {
 #define FSK_BLK_SLOTS 6
 #endif
 static constexpr uint32_t kBlkSlots = FSK_BLK_SLOTS;   // half tiles in the rings
+static_assert((kBlkSlots & 1u) == 0u, "blocks are two half tiles on an even slot");
 static_assert(4u * kBlkSlots <= kZeroLagPairs, "the wave that owns the I/Q low-pass must learn of a reset before it has passed the zeroing point");
 static_assert(4u * kBlkSlots <= kHandLag, "the discriminator wave (up to 4 * kBlkSlots - 1 samples beyond the start of the back wave's tile) must not have reached the hand-over sample when it is posted");
 static constexpr uint32_t kBlkSlotV4 = 2 * 64;     // v4f per x-ring slot: four pair sums (I, Q) -- in place -> four (phase, magnitude)
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     // block takes the per-sample path
     const bool amp_misaligned = (amp_pos0 & 3u) != 0u;
     const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
-    uint32_t produced = 0, slot_i = 0, yslot_i = 0;
+    uint32_t produced = 0, slot_i = 0;                        // (x-ring slot of half tile t; even wherever a block starts)
     uint32_t pidx = 0;                                        // LDS index of the block's first polyphase register
     uint32_t bq = 0, nq = 0;                                  // completed bytes not yet stored (newest in the low byte)
     uint32_t *prow = poly + lane * PS;
@@ -710,10 +711,10 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
       // that end about together, 81 % of such tiles also hold another lane's 'eod' or false start and fail the block's
       // rare test after paying for it -- 8 192 streams 118.7 -> 111.3 Gsamples/s, profiles/r03_own_span_blocks.txt.)
       bool rare_exit = (X.zlive != 0u || amp_misaligned) && !FSK_ABL(3);
-      if (!rare_exit) do {
+      if (!rare_exit) for (;;) {
         v4u32 cv;
         lds_peek4_begin(ctr, cv);
-        const uint32_t slot_j = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
+        const uint32_t slot_j = slot_i + 1u;                  // (kBlkSlots is even and blocks start on even slots)
         const uint32_t pidx2 = pidx + 4u >= P.d ? 0u : pidx + 4u;
         const v4f *slot = ring + slot_i * kBlkSlotV4, *slot2 = ring + slot_j * kBlkSlotV4;
         const v4f pa[4] = {slot[lane], slot[64u + lane], slot2[lane], slot2[64u + lane]};
@@ -739,14 +740,14 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
           X.amp_soff = q2 + amp_quad_bytes; X.amp_soff = X.amp_soff == amp_wrap ? 0u : X.amp_soff;
         }
         X.k += (uint32_t)kBlk; X.kv += (uint32_t)kBlk;
-        slot_i = slot_j + 1u == kBlkSlots ? 0u : slot_j + 1u;
-        yslot_i = yslot_i + 2u >= NY ? yslot_i + 2u - NY : yslot_i + 2u;
+        slot_i = slot_i + 2u == kBlkSlots ? 0u : slot_i + 2u;
         pidx = pidx2 + 4u >= P.d ? 0u : pidx2 + 4u;
         t += 2u;
         lds_post(&ctr[3], t);                                 // slots free (this wave's reads of them are complete)
         produced = lds_peek4_get(cv, 2);
         lim = lim0 < (produced & ~1u) ? lim0 : (produced & ~1u);
-      } while (t < lim);
+        if (!(t < lim)) break;
+      }
       if (rare_exit) {
         // something rare in the tile at t: sample by sample from its entry state (the round-2 path, unchanged)
         if (X.zlive != 0u) { FSK_STAMP_COUNT(1) } else { FSK_STAMP_COUNT(3) }
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
 #pragma unroll 1
         for (uint32_t hh = 0; hh < 2; hh++) {
           const v4f *slot = ring + slot_i * kBlkSlotV4;
-          const v4f *yslot = yring + yslot_i * 2u * 64u;
+          const v4f *yslot = yring + (t % NY) * 2u * 64u;    // (wave 0 wrote half tile t of this launch there)
 #pragma unroll 1
           for (uint32_t c = 0; c < 2; c++) {
             const v4f u4 = slot[c * 64u + lane];             // pair sums where this wave's own span covers the lane, else (phase, magnitude)
@@ -772,7 +773,6 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
             }
           }
           slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
-          yslot_i = yslot_i + 1u == NY ? 0u : yslot_i + 1u;
           pidx = pidx + 4u >= P.d ? 0u : pidx + 4u;
           t++;
           lds_post(&ctr[3], t);
