@@ -79,8 +79,15 @@ def test_full_size_chunking_invariance_and_oracle_sample(S, seconds, monkeypatch
         eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
         results[name] = _demod_schedule(eng, d_x, N, pitch, schedule)
         if name == "one_call":
-            # (time slices only beyond one round of resident workgroups and for calls of at least two default slices)
-            assert eng.last_kernel().endswith("true>" if S > 65536 and N // 16 > 768 else "false>"), eng.last_kernel()
+            # beyond one round of resident workgroups: the block kernel in time slices if the call is long enough for
+            # two of them, round 2's kernels otherwise; within one round: one workgroup per group
+            k = eng.last_kernel()
+            if S <= 65536:
+                assert k.startswith("fsk::demod_blk_kernel") and k.endswith("false>"), k
+            elif N // 16 > 768:
+                assert k.startswith("fsk::demod_blk_kernel") and k.endswith("true>"), k
+            else:
+                assert "demod_blk_kernel" not in k, k
         eng.close()
     if S > 65536:
         # beyond one round of resident workgroups the one-call launch is persistent and time-sliced (fsk_blk.hip); the same
@@ -88,7 +95,7 @@ def test_full_size_chunking_invariance_and_oracle_sample(S, seconds, monkeypatch
         monkeypatch.setenv("FSKHIP_SLICE_TILES", "off")
         eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
         results["one_call_unsliced"] = _demod_schedule(eng, d_x, N, pitch, [N])
-        assert eng.last_kernel().endswith("false>"), eng.last_kernel()
+        assert "demod_blk_kernel" not in eng.last_kernel(), eng.last_kernel()      # (round 2's kernel for this size)
         eng.close()
         monkeypatch.delenv("FSKHIP_SLICE_TILES")
     base_rows, base_eod = results["one_call"]

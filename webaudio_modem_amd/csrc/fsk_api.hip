@@ -46,6 +46,8 @@ hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, c
                              uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, uint32_t y_slots,
                              bool *sliced_out);
 void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t *y_slots, uint32_t *resident_wgs);
+uint32_t demod_blk_slices(const DemodParams &P, const DemodState &S, size_t n, uint32_t resident_wgs, uint32_t slice_tiles,
+                          uint32_t *slice_tiles_out);
 size_t demod_blk_queue_words(uint32_t groups);
 hipError_t set_pipe_lds_limit(size_t pipe_bytes);
 hipError_t set_demod_lds_limit(size_t lds_bytes);
@@ -176,6 +178,8 @@ struct fskhip_engine {
   bool use_blk = true;          // four waves per group with the block-batched back wave (demod_blk_kernel, fsk_blk.hip): the default
                                  // wherever it applies (dsSPB a multiple of 4, >= 8); FSKHIP_SPLIT = 0 / 1 / 3 pins an older kernel
   uint32_t blk_resident = 0;     // workgroups of demod_blk_kernel the device holds at once; larger batches run it persistent, in time slices
+  uint32_t blk_min_tiles = 0;    // calls with fewer whole tiles than this stay with round 2's kernels (the four-wave pipeline's fill and
+                                 // drain cost more than it saves on them); FSKHIP_BLK_MIN_TILES
   uint32_t blk_y_slots = 6;      // half tiles in the block kernel's y ring: as deep as the LDS allows at this batch size (FSKHIP_BLK_YSLOTS pins it)
   uint32_t blk_slice_tiles = 0;  // FSKHIP_SLICE_TILES: tiles per time slice (0 = the kernel file's default, "off" = never slice)
   bool last_sliced = false;
@@ -365,7 +369,10 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     if (const char *sp = getenv("FSKHIP_SPLIT")) {    // tests / measurements: 0 = one wave, 1 = two, 3 = three per group, 4 = three with the block back
       e->use_split = sp[0] == '1' || sp[0] == '3' || sp[0] == '4'; e->use_split3 = sp[0] == '3'; e->use_blk = sp[0] == '4';
       e->split_forced = true;
-      if (sp[0] == 'a') { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < (uint32_t)cus * 8u; }   // 'auto' spelled out
+      if (sp[0] == 'a' || sp[0] == 'b') {   // 'auto' spelled out; 'b' = auto without the block kernel (round 2's choice)
+        e->use_blk = sp[0] == 'a'; e->split_forced = false; e->use_split = n_blocks < (uint32_t)cus * 8u;
+        e->use_split3 = e->use_split && n_blocks > (uint32_t)cus && n_blocks <= (uint32_t)cus * 2u;
+      }
     }
   }
 
@@ -604,6 +611,7 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     CREATE_TRY(set_blk_lds_limit(P));
     demod_blk_plan(P, e->n_blocks, device, &e->blk_y_slots, &e->blk_resident);
     if (const char *ys = getenv("FSKHIP_BLK_YSLOTS")) e->blk_y_slots = (uint32_t)strtoul(ys, nullptr, 10);   // measurements
+    if (const char *mt = getenv("FSKHIP_BLK_MIN_TILES")) e->blk_min_tiles = (uint32_t)strtoul(mt, nullptr, 10);
     if (const char *rw = getenv("FSKHIP_BLK_RESIDENT")) e->blk_resident = (uint32_t)strtoul(rw, nullptr, 10);   // tests: a "device" this small
     if (const char *sl = getenv("FSKHIP_SLICE_TILES")) e->blk_slice_tiles = sl[0] == 'o' ? 0xFFFFFFFFu : (uint32_t)strtoul(sl, nullptr, 10);
     if (e->blk_resident && e->n_blocks > e->blk_resident) {
@@ -702,7 +710,15 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
         // the block kernel stores amplitudes a quad at a time: the ring's write position at its first sample must be a
         // multiple of four (it is unless earlier calls had odd lengths: those calls then stay with the per-sample kernels)
         const bool quad_aligned = ((e->pushes + ((p0 + head) >> 1)) & 3u) == 0u;
-        if (e->use_blk && demod_blk_applicable(e->P) && blk_lds <= 160 * 1024 && (quad_aligned || e->split_forced)) {
+        // Batches beyond one round of resident workgroups run the block kernel persistently, in time slices; a call too
+        // short for two slices would run it in several rounds of one workgroup per group, each paying the four-wave
+        // pipeline's fill and drain, and round 2's kernels are faster there (262 144 streams x 128-sample quanta, the
+        // FSKProcessor loop: 0.195 against 0.247 ms; x 4 096 samples 384 against 370 Gsamples/s:
+        // profiles/r03_short_calls.txt)
+        const bool blk_fits = !(e->blk_resident && e->n_blocks > e->blk_resident) ||
+                              demod_blk_slices(e->P, e->S, n_fast, e->blk_resident, e->blk_slice_tiles, nullptr) >= 2u;
+        if (e->use_blk && demod_blk_applicable(e->P) && blk_lds <= 160 * 1024 && (quad_aligned || e->split_forced) &&
+            ((blk_fits && n_fast / 16 >= e->blk_min_tiles) || e->split_forced)) {
           HIP_TRY(launch_demod_blk(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
                                    e->blk_resident, e->blk_slice_tiles, e->blk_y_slots, &e->last_sliced));
           static const char *const names[8] = {

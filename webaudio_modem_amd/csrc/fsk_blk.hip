@@ -228,7 +228,7 @@ __device__ inline void blk_prio(uint32_t hidx, uint32_t wgj, uint32_t role = 0) 
 // been pushed yet waits for it (the pusher is running and never waits, so this cannot lock up).
 // Coherence.  A group's next slice may run on another XCD, behind another L2.  Everything a slice hands on -- state
 // arrays, polyphase registers, amplitude ring, output counts -- is therefore written and read with device-scope cache
-// policy (sc1: kCoh, fsk_dev.h; stores write through, loads take no cached copy) and the push waits for the stores'
+// policy (sc1: kCohSc1, fsk_dev.h; stores write through, loads take no cached copy) and the push waits for the stores'
 // completion (vmcnt); no cache-wide write-back or invalidate is needed.  (An agent-scope release / acquire fence pair per
 // slice was measured first: buffer_wbl2 with the amplitude ring's dirty lines in L2 cost ~70 us per slice; queues
 // private to an XCD avoid it too but balance worse: profiles/r03_slices.txt.)
@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     uint32_t *__restrict__ eod_counts, BlkSched Z) {
   FSK_ABL_INIT
   FSK_STAMP_DECL
+  constexpr int COH = SL ? kCohSc1 : 0;           // cache policy of what a time slice hands to the next (fsk_dev.h)
   extern __shared__ float4 lds[];
   const uint32_t PS = blk_poly_stride(P.d);
   const uint32_t NY = Z.y_slots;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
   const PipeCtx C = pipe_ctx(P, S, stream);
   const uint32_t nh = 2u * (uint32_t)n_tiles;               // half tiles = blocks
   const uint64_t inc = UNI ? (((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo) : S.nco_inc[C.row4 >> 2];
-  const uint64_t free0 = pipe_free0<UNI>(C);
+  const uint64_t free0 = pipe_free0<UNI, COH>(C);
 
   if (threadIdx.x == 0) { ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; }
   if (wave == 1) {
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     // ------------------------------------------------------------------------------ loads, AGC, pre-filter
     FrontLane F;
     FrontK K;
-    front_load<UNI>(F, K, P, S, C);
+    front_load<UNI, COH>(F, K, P, S, C);
     const uint32_t sub_row = lane >> 2, chunk = lane & 3;
     const uint32_t rows_here = P.n_streams - grp * 64u < 64u ? P.n_streams - grp * 64u : 64u;
     v4i in_rsrc;
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     // ------------------------------------------------------------------------------ mixer, I/Q low-pass, pair sums
     FrontLane F;
     FrontK K;
-    front_load<UNI>(F, K, P, S, C);
+    front_load<UNI, COH>(F, K, P, S, C);
     float wre = 1.f, wim = 0.f;
     if (!UNI) {
       const __amdgpu_buffer_rsrc_t cf_rsrc = C.cf_rsrc;
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     // ---------------------------------------------------------------------------------------------- block back
     BackLane B;
     BackK K;
-    back_load<UNI>(B, K, P, S, C, stream, out_counts, eod_counts, append);
+    back_load<UNI, COH>(B, K, P, S, C, stream, out_counts, eod_counts, append);
     if (B.dph >= kHandPairs) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }   // the discriminator wave's
     BlkK Q;
     Q.stop_m1 = (1u << P.stop_pos) - 1u; Q.sh9 = P.stop_pos - 9u; Q.ff = 0xFFu;
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     {
       uint32_t ph = phase0;
       for (uint32_t i = 0; i < P.d; i++) {                    // rotate: LDS index 0 = the register of the first push
-        poly[lane * PS + i] = __hip_atomic_load(&gpoly[ph * 64u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        poly[lane * PS + i] = COH ? __hip_atomic_load(&gpoly[ph * 64u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gpoly[ph * 64u + lane];
         ph = ph + 1u == P.d ? 0u : ph + 1u;
       }
     }
@@ -733,10 +734,10 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
           uint32_t q2 = X.amp_soff + amp_quad_bytes; q2 = q2 == amp_wrap ? 0u : q2;
           __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, am[0]), __builtin_bit_cast(uint32_t, am[1]),
                                                         __builtin_bit_cast(uint32_t, am[2]), __builtin_bit_cast(uint32_t, am[3])},
-                                                 amp_rsrc, M.avoff, X.amp_soff, SL ? kCoh : 0);
+                                                 amp_rsrc, M.avoff, X.amp_soff, COH);
           __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, am[4]), __builtin_bit_cast(uint32_t, am[5]),
                                                         __builtin_bit_cast(uint32_t, am[6]), __builtin_bit_cast(uint32_t, am[7])},
-                                                 amp_rsrc, M.avoff, q2, SL ? kCoh : 0);
+                                                 amp_rsrc, M.avoff, q2, COH);
           X.amp_soff = q2 + amp_quad_bytes; X.amp_soff = X.amp_soff == amp_wrap ? 0u : X.amp_soff;
         }
         X.k += (uint32_t)kBlk; X.kv += (uint32_t)kBlk;
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
               X.kv += 1u;
               uint32_t *ps = prow + pidx + 2u * c + (uint32_t)h;
               const uint32_t r_old = *ps;
-              back_pair<UNI, true, false, true, SL ? kCoh : 0>(B, K, P, S, M, ps, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
+              back_pair<UNI, true, false, true, COH>(B, K, P, S, M, ps, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
                                                 h ? u4.z : u4.x, h ? u4.w : u4.y, yp + 2 * h, r_old, inc, h ? pa.z : pa.x, h ? pa.w : pa.y);
               amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
             }
@@ -801,12 +802,13 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     {
       uint32_t ph = phase0;
       for (uint32_t i = 0; i < P.d; i++) {
-        __hip_atomic_store(&gpoly[ph * 64u + lane], poly[lane * PS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (COH) __hip_atomic_store(&gpoly[ph * 64u + lane], poly[lane * PS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else gpoly[ph * 64u + lane] = poly[lane * PS + i];
         ph = ph + 1u == P.d ? 0u : ph + 1u;
       }
     }
     const uint32_t phase_end = (phase0 + X.k) % P.d;
-    pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, phase_end, amp_pos_of(X.amp_soff, amp_quad_bytes), inc, free0);
+    pipe_store<UNI, COH>(F, false, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, phase_end, amp_pos_of(X.amp_soff, amp_quad_bytes), inc, free0);
   }
   if (!SL) return;
   // ---- the group's next slice goes behind the queue's tail once this one's state is in memory (pushed at the loop's top)
@@ -888,6 +890,37 @@ static constexpr uint32_t kBlkSliceTiles = 768;    // 12 288 samples
 static constexpr uint32_t kBlkMaxSlices = 128;
 size_t demod_blk_queue_words(uint32_t groups) { return 16u + (size_t)groups * (kBlkMaxSlices - 1u); }
 
+// Slices per group for a call of n samples (1 = one workgroup per group, not persistent) and their length in tiles.
+uint32_t demod_blk_slices(const DemodParams &P, const DemodState &S, size_t n, uint32_t resident_wgs, uint32_t slice_tiles,
+                          uint32_t *slice_tiles_out) {
+  const uint32_t blocks = (P.n_streams + 63u) / 64u;
+  const uint32_t n_tiles = (uint32_t)(n / kFastTile);
+  if (slice_tiles_out) *slice_tiles_out = 0;
+  if (!(S.blk_q && resident_wgs && blocks > resident_wgs && blocks < (1u << 20) && slice_tiles != 0xFFFFFFFFu)) return 1u;
+  uint32_t st = slice_tiles ? slice_tiles : kBlkSliceTiles;
+  const uint32_t st_min = (n_tiles + kBlkMaxSlices - 1u) / kBlkMaxSlices;
+  st = st < st_min ? st_min : st;
+  uint32_t ns = (n_tiles + st - 1u) / st;
+  if (ns < 2u) return 1u;
+  if (!slice_tiles) {
+    // How many slices: items are handed out whole, so groups * ns items on `resident` workgroups take about
+    // ceil(groups * ns / resident) slice times -- 1 088 groups in 8 slices need 9 of them (1.125 rounds) where 16
+    // slices need 17 (1.0625) -- and every slice change costs ~17 us (1.1 % of a 768-tile slice at config #3's rate).
+    double best = 1e30;
+    uint32_t best_ns = ns;
+    for (uint32_t c = ns; c <= 4u * ns && c <= kBlkMaxSlices && (n_tiles + c - 1u) / c >= 96u; c++) {
+      const double rounds = (double)(((uint64_t)blocks * c + resident_wgs - 1u) / resident_wgs) / (double)c;
+      const double cost = rounds * (1.0 + 0.011 * (double)c / (double)ns);
+      if (cost < best - 1e-9) { best = cost; best_ns = c; }
+    }
+    ns = best_ns;
+    st = (n_tiles + ns - 1u) / ns;
+    ns = (n_tiles + st - 1u) / st;
+  }
+  if (slice_tiles_out) *slice_tiles_out = st;
+  return ns;
+}
+
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, uint32_t y_slots,
@@ -897,34 +930,13 @@ hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, c
   const size_t lds = demod_blk_lds_bytes(P, y_slots);
   set_ablate_blk();
   BlkSched Z = {nullptr, blocks, 1u, 0u, 0u, y_slots, blk_zt_tiles(y_slots)};
-  const uint32_t n_tiles = (uint32_t)(n / kFastTile);
-  bool sliced = false;
-  if (S.blk_q && resident_wgs && blocks > resident_wgs && blocks < (1u << 20) && slice_tiles != 0xFFFFFFFFu) {
-    uint32_t st = slice_tiles ? slice_tiles : kBlkSliceTiles;
-    const uint32_t st_min = (n_tiles + kBlkMaxSlices - 1u) / kBlkMaxSlices;
-    st = st < st_min ? st_min : st;
-    uint32_t ns = (n_tiles + st - 1u) / st;
-    if (!slice_tiles && ns >= 2u) {
-      // How many slices: items are handed out whole, so groups * ns items on `resident` workgroups take about
-      // ceil(groups * ns / resident) slice times -- 1 088 groups in 8 slices need 9 of them (1.125 rounds) where 16
-      // slices need 17 (1.0625) -- and every slice change costs ~17 us (1.1 % of a 768-tile slice at config #3's rate).
-      double best = 1e30;
-      uint32_t best_ns = ns;
-      for (uint32_t c = ns; c <= 4u * ns && c <= kBlkMaxSlices && (n_tiles + c - 1u) / c >= 96u; c++) {
-        const double rounds = (double)(((uint64_t)blocks * c + resident_wgs - 1u) / resident_wgs) / (double)c;
-        const double cost = rounds * (1.0 + 0.011 * (double)c / (double)ns);
-        if (cost < best - 1e-9) { best = cost; best_ns = c; }
-      }
-      ns = best_ns;
-      st = (n_tiles + ns - 1u) / ns;
-      ns = (n_tiles + st - 1u) / st;
-    }
-    if (ns >= 2u) {
-      sliced = true;
-      Z.q = S.blk_q; Z.nslices = ns; Z.slice_tiles = st; Z.total = blocks * ns;
-      const hipError_t e = hipMemsetAsync(S.blk_q, 0, sizeof(uint32_t) * (16u + (size_t)blocks * (ns - 1u)), stream);
-      if (e != hipSuccess) return e;
-    }
+  uint32_t st = 0;
+  const uint32_t ns = demod_blk_slices(P, S, n, resident_wgs, slice_tiles, &st);
+  const bool sliced = ns >= 2u;
+  if (sliced) {
+    Z.q = S.blk_q; Z.nslices = ns; Z.slice_tiles = st; Z.total = blocks * ns;
+    const hipError_t e = hipMemsetAsync(S.blk_q, 0, sizeof(uint32_t) * (16u + (size_t)blocks * (ns - 1u)), stream);
+    if (e != hipSuccess) return e;
   }
   if (sliced_out) *sliced_out = sliced;
   const uint32_t grid = sliced ? resident_wgs : blocks;

@@ -13,10 +13,12 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 static constexpr int kFastTile = 16;
-// Cache policy of every access to what one launch -- or one time slice of a persistent launch (fsk_blk.hip), possibly on
-// another XCD with another L2 -- hands to the next: sc1 = coherent at device scope (stores write through, loads do not
-// take a cached copy).  These are launch-start / launch-end / rare-path accesses; the per-sample traffic does not use it.
-static constexpr int kCoh = 16;
+// Cache policy of the accesses to what one time slice of a persistent launch (fsk_blk.hip) hands to the next -- possibly
+// on another XCD, behind another L2: sc1 = coherent at device scope (stores write through, loads take no cached copy).
+// Only those launches use it (template parameter COH of the state helpers, 0 everywhere else): between launches the
+// kernel boundary does the job, and the write-through costs -- a 128-sample FSKProcessor quantum moves about as many
+// bytes of state as of samples and ran 0.20 instead of 0.14 ms when every kernel carried it.
+static constexpr int kCohSc1 = 16;
 static constexpr uint32_t kStarted = 0xFFFFFFFFu;  // thr_eff while a frame is started (matched_min is <= 0xFFFFFFFE)
 
 __device__ inline uint32_t popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
@@ -96,11 +98,13 @@ __device__ inline void amp_advance(uint32_t &soff, uint32_t quad_bytes, uint32_t
   soff += 4u;
   if ((soff & 12u) == 0u) { soff += quad_bytes - 16u; if (soff == wrap) soff = 0u; }
 }
+template <int COH = 0>
 __device__ inline uint32_t ist_load(const FastMem &M, uint32_t field) {
-  return __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, M.voff, field * M.fld, kCoh);
+  return __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, M.voff, field * M.fld, COH);
 }
+template <int COH = 0>
 __device__ inline void ist_store(const FastMem &M, uint32_t field, uint32_t v) {
-  __builtin_amdgcn_raw_buffer_store_b32(v, M.is_rsrc, M.voff, field * M.fld, kCoh);
+  __builtin_amdgcn_raw_buffer_store_b32(v, M.is_rsrc, M.voff, field * M.fld, COH);
 }
 
 

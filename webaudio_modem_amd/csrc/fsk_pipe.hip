@@ -57,6 +57,11 @@
 #include "fsk_pipe_dev.h"
 
 namespace fsk {
+// these kernels hand their state on across kernel boundaries only: plain cache policy for the PIPE_* accesses (fsk_dev.h)
+static constexpr int COH = 0;
+}
+
+namespace fsk {
 
 // ================================================================================================================
 // Two waves per 64-stream group.

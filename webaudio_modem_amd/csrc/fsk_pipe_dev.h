@@ -223,15 +223,15 @@ struct BackU {                   // wave-uniform context of one decimated sample
 };
 
 // resetState() fsk.ts:175-188 at the end of push k: the next input sample is n0 = 2k of this launch.
-template <bool UNI>
+template <bool UNI, int COH = 0>
 __device__ inline void back_reset(BackLane &B, const DemodParams &P, const FastMem &M, const BackU &X, uint64_t inc,
                                   uint32_t lane) {
   // the reference's NCO restarts at 0: from here on its phase is the free-running frame's minus that frame's phase at
   // n0, and its lastPhase = 0 is that phase in the free frame
   const uint64_t fr0 = X.free0 + inc * (uint64_t)(2u * X.k);
   const uint64_t off = 0ull - fr0;
-  ist_store(M, IF_fr_lo, (uint32_t)off);
-  ist_store(M, IF_fr_hi, (uint32_t)(off >> 32));
+  ist_store<COH>(M, IF_fr_lo, (uint32_t)off);
+  ist_store<COH>(M, IF_fr_hi, (uint32_t)(off >> 32));
   {
     double r = (double)fr0 * 5.42101086242752217e-20 * 6.283185307179586476925;   // 2^-64 turns -> radians
     r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
@@ -247,7 +247,7 @@ __device__ inline void back_reset(BackLane &B, const DemodParams &P, const FastM
   B.dix1 = B.dix2 = B.diy = B.dvi = 0.f;
   B.dqx1 = B.dqx2 = B.dqy = B.dqv = 0.f;
   B.px1 = B.px2 = B.py = B.pv = 0.f;
-  ist_store(M, IF_gsc, 0u - X.k);
+  ist_store<COH>(M, IF_gsc, 0u - X.k);
   B.rho = X.k % P.cadence;
   B.ls = X.k;
   B.acc = 0; B.T = X.k + kBigWait; B.tlast = B.T;
@@ -404,11 +404,11 @@ __device__ inline void zir_step(BackLane &B, const BackK &K, BackU &X, float Ui,
 // same function, same inputs where nothing changed, so the result does not depend on which wave computed it.
 // TRC: honour fskhip_trace_enable and fskhip_enable_signal_quality (the sample-granular kernel only; an engine with
 // either switched on runs entirely on it).
-// AMP_AUX: cache policy of the amplitude ring's store (kCoh in fsk_blk.hip's time-sliced launches, whose next slice may read
-// the ring behind another L2).
+// COH: cache policy of this function's state accesses and of the amplitude ring's store (kCohSc1 in fsk_blk.hip's
+// time-sliced launches, whose next slice may run behind another L2; 0 otherwise).
 // HAND (fsk_blk.hip's back wave): the correction belongs to this wave only while zr_dph < kHandPairs; after that the
 // discriminator wave applies it and ph_u / amp_u already are the corrected pair sum's.
-template <bool UNI, bool PA = false, bool TRC = false, bool HAND = false, int AMP_AUX = 0>
+template <bool UNI, bool PA = false, bool TRC = false, bool HAND = false, int COH = 0>
 __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams &P, const DemodState &S, const FastMem &M,
                                  uint32_t *pslot, uint32_t lane, __amdgpu_buffer_rsrc_t amp_rsrc, uint8_t *out,
                                  uint32_t out_pitch, uint32_t *eod_counts, BackU &X, float Ui, float Uq,
@@ -442,7 +442,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   *pslot = r;                                                  // (the polyphase register of this push slot)
   B.matched += (uint32_t)__builtin_popcount((r ^ qn) & mask);
   B.matched -= (uint32_t)__builtin_popcount((r_old ^ qn) & mask);
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, M.avoff, X.amp_soff, AMP_AUX);  // syncAmplitudeBuffer.put
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, amp), amp_rsrc, M.avoff, X.amp_soff, COH);  // syncAmplitudeBuffer.put
   {
     const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, amp - B.thr));   // amp < threshold (fsk.ts:285)
     B.ls = (B.ls & silent) | (X.kv & ~silent);                 // silence run = k - ls (fsk.ts:285-295)
@@ -460,14 +460,14 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
     const bool cand = ((int32_t)m1 >= 0) & (B.rho == X.k % P.cadence);   // globalSampleCounter % round(dsSPB/4) == 0
     if (__builtin_amdgcn_ballot_w64(eod)) {                    // fsk.ts:288-291
       if (TRC && P.quality) {   // opt-in estimates (sample-granular kernel only): the noise floor of the silence behind the first 'eod' after a sync
-        const uint32_t pushes = ist_load(M, IF_amp_len) + X.k;
+        const uint32_t pushes = ist_load<COH>(M, IF_amp_len) + X.k;
         quality_on_eod<float>(P, S, lane, M.voff >> 2, eod & (M.voff < 0xFFFFFFF0u), amp_pos_of(X.amp_soff, P.n_streams * 16u),
                               pushes < P.amp_cap ? pushes : P.amp_cap);
       }
       if (eod) {
-        ist_store(M, IF_eod_total, ist_load(M, IF_eod_total) + 1u);
+        ist_store<COH>(M, IF_eod_total, ist_load<COH>(M, IF_eod_total) + 1u);
         if (eod_counts && M.voff < 0xFFFFFFF0u) __hip_atomic_fetch_add(&eod_counts[M.voff >> 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        back_reset<UNI>(B, P, M, X, inc, lane);
+        back_reset<UNI, COH>(B, P, M, X, inc, lane);
       }
       X.direct = kDirectPairs; X.zlive = 1u;                   // (wave-uniform: set where the wave-uniform branch is)
     }
@@ -475,9 +475,9 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
     bool sync_now = false;
     uint32_t slen = 0;
     if (cand & !eod) {
-      const uint32_t ring_base = ist_load(M, IF_ring_len);
+      const uint32_t ring_base = ist_load<COH>(M, IF_ring_len);
       sync_now = (ring_base + X.k >= P.sample_count) & (M.voff < 0xFFFFFFF0u);
-      const uint32_t pushes = ist_load(M, IF_amp_len) + X.k;
+      const uint32_t pushes = ist_load<COH>(M, IF_amp_len) + X.k;
       slen = pushes < P.amp_cap ? pushes : P.amp_cap;
     }
     uint64_t m = __builtin_amdgcn_ballot_w64(sync_now);
@@ -486,7 +486,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
         B.thr_eff = kStartedP;
         B.sreg = 1u;
         B.acc = 0; B.T = X.k; B.tlast = X.k;
-        ist_store(M, IF_sync_det, ist_load(M, IF_sync_det) + 1u);
+        ist_store<COH>(M, IF_sync_det, ist_load<COH>(M, IF_sync_det) + 1u);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's ring stores have reached L2
       while (m) {
@@ -544,7 +544,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
         B.sreg = s0;
       }
       if (__builtin_amdgcn_ballot_w64(bad_start)) {
-        if (bad_start) back_reset<UNI>(B, P, M, X, inc, lane);
+        if (bad_start) back_reset<UNI, COH>(B, P, M, X, inc, lane);
         X.direct = kDirectPairs; X.zlive = 1u;
       }
     }
@@ -552,10 +552,10 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
 }
 
 // ---- state arrays <-> registers ------------------------------------------------------------------------------
-#define PIPE_RLOAD(f) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rsrc, row4, (uint32_t)RF_##f * fld, kCoh))
-#define PIPE_ILOAD(f) __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, row4, (uint32_t)IF_##f * fld, kCoh)
-#define PIPE_RSTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)(v)), rs_rsrc, M.voff, (uint32_t)RF_##f * fld, kCoh)
-#define PIPE_ISTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(v), M.is_rsrc, M.voff, (uint32_t)IF_##f * fld, kCoh)
+#define PIPE_RLOAD(f) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rsrc, row4, (uint32_t)RF_##f * fld, COH))
+#define PIPE_ILOAD(f) __builtin_amdgcn_raw_buffer_load_b32(M.is_rsrc, row4, (uint32_t)IF_##f * fld, COH)
+#define PIPE_RSTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)(v)), rs_rsrc, M.voff, (uint32_t)RF_##f * fld, COH)
+#define PIPE_ISTORE(f, v) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(v), M.is_rsrc, M.voff, (uint32_t)IF_##f * fld, COH)
 #define PIPE_CLOAD(f) (__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cf_rsrc, row4 * 2u, (uint32_t)(f) * fld * 2u, 0)))
 
 struct PipeCtx {   // descriptors and offsets both halves use
@@ -581,7 +581,7 @@ __device__ inline PipeCtx pipe_ctx(const DemodParams &P, const DemodState &S, ui
 
 // NCO phase of the free-running frame at the first sample of the launch = the stream's NCO phase minus its frame offset.
 // Uniform configuration: every stream of the batch shares the frame, so this is a wave-uniform value (SGPRs).
-template <bool UNI>
+template <bool UNI, int COH = 0>
 __device__ inline uint64_t pipe_free0(const PipeCtx &C) {
   const FastMem &M = C.M;
   const uint32_t fld = C.fld, row4 = C.row4;
@@ -595,7 +595,7 @@ __device__ inline uint64_t pipe_free0(const PipeCtx &C) {
 }
 
 // front state (AGC, pre-filter, free-running I/Q low-pass)
-template <bool UNI>
+template <bool UNI, int COH = 0>
 __device__ inline void front_load(FrontLane &F, FrontK &K, const DemodParams &P, const DemodState &S, const PipeCtx &C) {
   const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc, cf_rsrc = C.cf_rsrc;
   const uint32_t fld = C.fld, row4 = C.row4;
@@ -619,7 +619,7 @@ __device__ inline void front_load(FrontLane &F, FrontK &K, const DemodParams &P,
   asm volatile("" : "+v"(K.bp_b0), "+v"(K.bp_na1), "+v"(K.bp_na2), "+v"(K.lp_a2), "+v"(K.lp_nd));
 }
 
-template <bool UNI>
+template <bool UNI, int COH = 0>
 __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, const DemodState &S, const PipeCtx &C,
                                  uint32_t stream, uint32_t *out_counts, uint32_t *eod_counts, int append) {
   const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
@@ -656,8 +656,8 @@ __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, co
   }
   if (B.thr_eff != kStartedP) { B.T = kBigWait; B.tlast = B.T - PIPE_ILOAD(bit_reload); }  // (re)park: decisions imply a started frame
   // append: a preceding launch of the same call (head samples up to a pair / 16-byte boundary) has produced output already
-  B.out_cnt = (append && C.valid) ? __hip_atomic_load(&out_counts[stream], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  if (!append && C.valid && eod_counts) __hip_atomic_store(&eod_counts[stream], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // incremented in memory by the (rare) EOD path
+  B.out_cnt = (append && C.valid) ? (COH ? __hip_atomic_load(&out_counts[stream], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : out_counts[stream]) : 0u;
+  if (!append && C.valid && eod_counts) { if (COH) __hip_atomic_store(&eod_counts[stream], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else eod_counts[stream] = 0; }  // incremented in memory by the (rare) EOD path
   if (!C.valid) {
     // Lanes beyond the batch run on zeros with a copy of the last stream's state.  Park them: no sync candidate (a
     // threshold `matched` cannot reach), no silence run (nothing is below a negative threshold), no bit clock -- so
@@ -675,7 +675,7 @@ __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, co
 
 // everything back to the state arrays.  F: the front's final state, n: samples of the launch, k: decimated samples,
 // kappa = k % cadence, free0: the free-running frame's NCO phase at the first sample of the launch.
-template <bool UNI>
+template <bool UNI, int COH = 0>
 __device__ inline void pipe_store(const FrontLane &F, bool store_front, const BackLane &B, const DemodParams &P,
                                   const PipeCtx &C, uint32_t stream, uint32_t *out_counts, size_t n, uint32_t k,
                                   uint32_t kappa, uint32_t phase, uint32_t amp_pos, uint64_t inc, uint64_t free0) {
@@ -720,7 +720,7 @@ __device__ inline void pipe_store(const FrontLane &F, bool store_front, const Ba
   PIPE_ISTORE(amp_len, al < P.amp_cap ? al : P.amp_cap);
   PIPE_ISTORE(poly_phase, phase);
   PIPE_ISTORE(amp_pos, amp_pos);
-  if (C.valid) __hip_atomic_store(&out_counts[stream], B.out_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (C.valid) { if (COH) __hip_atomic_store(&out_counts[stream], B.out_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else out_counts[stream] = B.out_cnt; }
 }
 
 // wave-uniform LDS word, polled by the other wave of the workgroup
