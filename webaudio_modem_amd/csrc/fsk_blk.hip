@@ -11,25 +11,27 @@
 // slowest wave.  (Removing the back wave's arithmetic piece by piece confirmed it: profiles/r03_back_cuts.txt.)
 //
 // What.  The chain is cut where nothing but a reset feeds back, into four waves of about equal length:
-//   0  tile loads, AGC, pre-filter                                   -> y ring   (what resetState() never touches)
+//   0  tile loads, AGC, pre-filter, the tile's NCO phasors           -> y ring   (what resetState() never touches)
 //   1  mixer + free-running I/Q low-pass + pair sums U               -> x ring   (zeroes a lane's filters kZeroLagPairs after a reset)
 //   2  ZIR correction (once it is this wave's) + discriminator       -> x ring, IN PLACE (phase, magnitude) over U
-//   3  post filter, slicer, sync correlator, frame state machine, a whole tile (eight decimated samples) at a time
-// and the back wave (3) restates fsk.ts:278-375 per block:
+//   3  post filter, slicer, sync correlator, frame state machine
+// every one of them a whole tile (sixteen input = eight decimated samples) per step, its LDS inputs read up front, one
+// branch per tile besides the loop's; the back wave (3) restates fsk.ts:278-375 per block:
 //   * per decimated sample only what is a recurrence: discriminator tail + post filter + slicer (disc_post, shared with
 //     the per-sample path), the sync correlator's running count, the silence run's last loud sample;
 //   * once per block: the bit clock.  A lane decides at most one bit per block (decisions are dsSPB >= 8 decimated
 //     samples apart), at sample jd = nextBitSampleIndex - k0 of the block, so the vote, the byte shift register and the
 //     start / stop-bit classification are evaluated once from the block's eight slicer bits (popcounts of an 8-bit word);
 //   * ONE exit test per block for everything rare: 'eod' (bounded from above by the silence run at the block's end), a
-//     sync candidate (matched >= threshold at any of the eight samples), a bad start or stop bit, a correction or direct
-//     instance of this wave's own, the amplitude ring about to wrap.  A block that trips it is redone sample by sample by
-//     back_pair (the round-2 code, unchanged arithmetic) from the block's entry state; the block path commits nothing
-//     before the test.  ~3 % of the blocks of BASELINE config #3's signal.
+//     sync candidate (matched >= threshold at any of the eight samples), a bad start or stop bit.  A block that trips it
+//     -- and every block while a lane is inside this wave's own span after a reset, or while the amplitude ring is off
+//     its quad grid -- is redone sample by sample by back_pair (the round-2 code, unchanged arithmetic) from the block's
+//     entry state; the block path commits nothing before the test.  3.5 % of the blocks of BASELINE config #3's signal.
 //   * the polyphase sync registers live lane-major in LDS (four consecutive phases = one ds_read_b128 / ds_write_b128),
 //     rotated so that every block starts at a multiple of four;
-//   * the amplitudes of a block are stored back to back at its end; completed bytes go to a four-byte queue per lane
-//     that is flushed every eight tiles (at most two bytes per lane can complete in between).
+//   * the amplitudes of a block are stored as two 16-byte quads at its end (fsk_dev.h: the ring's layout); completed
+//     bytes go to a four-byte queue per lane that is flushed every sixteen blocks (at most two bytes per lane can
+//     complete in between: a byte takes 10 x dsSPB >= 80 decimated samples).
 // Who owns the ZIR correction.  After a reset the back wave runs the direct instance (kDirectPairs samples) and then keeps
 // the correction for kHandLag more samples, un-retired (fsk_params.h); its values at the hand-over sample follow from the
 // recurrence alone, so it posts them (cmail) to wave 2 -- which may be up to 24 decimated samples ahead -- when the direct
@@ -41,8 +43,10 @@
 //
 // Which wave plays which part follows the SIMD it landed on, rotated by the workgroups the CU has started, so that every
 // SIMD hosts one wave of each part (see the kernel).
-// LDS: stage [4][65] v4f | yring [6][2][64] v4f | xring [6][2][64] v4f | fin [3][64] v4f | zt [4][8] v4f |
-//      poly [64][PS] u32 | counters [8] | zmail [64] u32 | cmail [6][64] u32
+// Batches beyond one round of resident workgroups run persistently over (group, time slice) items: BlkSched below.
+// LDS: stage [4][65] v4f (the final-state hand-over fin [3][64] over it) | yring [y_slots][2][64] v4f, y_slots = 6 .. 28 by
+//      what the batch leaves (demod_blk_plan) | xring [6][2][64] v4f | zt [8 or 16][8] v4f | poly [64][PS] u32 |
+//      counters [8] | zmail [64] u32 | cmail [6][64] u32
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
