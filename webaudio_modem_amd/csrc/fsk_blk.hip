@@ -54,6 +54,7 @@
 #include "fsk_params.h"
 #include "fsk_dev.h"
 #include "fsk_pipe_dev.h"
+#include "fsk_blk_sched.h"
 
 namespace fsk {
 
@@ -887,42 +888,15 @@ static void set_ablate_blk() {
 static inline void set_ablate_blk() {}
 #endif
 
-// Time slices (see BlkSched): only when the batch needs more than one round of resident workgroups and the call is long
-// enough for at least two slices.  slice_tiles = 0 starts from kBlkSliceTiles (or what keeps a group within
-// kBlkMaxSlices) and then picks the slice count that packs best (below).
-static constexpr uint32_t kBlkSliceTiles = 768;    // 12 288 samples
-static constexpr uint32_t kBlkMaxSlices = 128;
+// Time slices (see BlkSched; how a call is cut: fsk_blk_sched.h)
 size_t demod_blk_queue_words(uint32_t groups) { return 16u + (size_t)groups * (kBlkMaxSlices - 1u); }
 
-// Slices per group for a call of n samples (1 = one workgroup per group, not persistent) and their length in tiles.
+// Slices per group for a call of n samples (1 = one workgroup per group, not persistent) and their length in tiles: the
+// arithmetic is fsk_blk_sched.h's.
 uint32_t demod_blk_slices(const DemodParams &P, const DemodState &S, size_t n, uint32_t resident_wgs, uint32_t slice_tiles,
                           uint32_t *slice_tiles_out) {
-  const uint32_t blocks = (P.n_streams + 63u) / 64u;
-  const uint32_t n_tiles = (uint32_t)(n / kFastTile);
-  if (slice_tiles_out) *slice_tiles_out = 0;
-  if (!(S.blk_q && resident_wgs && blocks > resident_wgs && blocks < (1u << 20) && slice_tiles != 0xFFFFFFFFu)) return 1u;
-  uint32_t st = slice_tiles ? slice_tiles : kBlkSliceTiles;
-  const uint32_t st_min = (n_tiles + kBlkMaxSlices - 1u) / kBlkMaxSlices;
-  st = st < st_min ? st_min : st;
-  uint32_t ns = (n_tiles + st - 1u) / st;
-  if (ns < 2u) return 1u;
-  if (!slice_tiles) {
-    // How many slices: items are handed out whole, so groups * ns items on `resident` workgroups take about
-    // ceil(groups * ns / resident) slice times -- 1 088 groups in 8 slices need 9 of them (1.125 rounds) where 16
-    // slices need 17 (1.0625) -- and every slice change costs ~17 us (1.1 % of a 768-tile slice at config #3's rate).
-    double best = 1e30;
-    uint32_t best_ns = ns;
-    for (uint32_t c = ns; c <= 4u * ns && c <= kBlkMaxSlices && (n_tiles + c - 1u) / c >= 96u; c++) {
-      const double rounds = (double)(((uint64_t)blocks * c + resident_wgs - 1u) / resident_wgs) / (double)c;
-      const double cost = rounds * (1.0 + 0.011 * (double)c / (double)ns);
-      if (cost < best - 1e-9) { best = cost; best_ns = c; }
-    }
-    ns = best_ns;
-    st = (n_tiles + ns - 1u) / ns;
-    ns = (n_tiles + st - 1u) / st;
-  }
-  if (slice_tiles_out) *slice_tiles_out = st;
-  return ns;
+  return blk_slice_count((P.n_streams + 63u) / 64u, (uint32_t)(n / kFastTile), resident_wgs, slice_tiles, S.blk_q != nullptr,
+                         slice_tiles_out);
 }
 
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
