@@ -46,6 +46,7 @@
 
 #include "fsk_params.h"
 #include "fsk_dev.h"
+#include "fsk_f64math.h"
 
 #ifndef FSK_FAST_WAVES
 #define FSK_FAST_WAVES 4
@@ -91,6 +92,8 @@ template <>
 struct Consts<double> {
   double lp_b0, lp_b1, lp_b2, lp_a1, lp_a2, agc_att, agc_rel;
   double bp_b0, bp_a1, bp_a2, omega;
+  double cw, sw;        // e^{j omega}: one NCO step as a rotation (mix_lp)
+  bool omega_small;     // omega < 2 pi: the reference's `% (2 pi)` is one conditional subtraction
   __device__ void init(const DemodParams &P, const DemodState &S, uint32_t row) {
     lp_b0 = P.lp_b0; lp_b1 = P.lp_b1; lp_b2 = P.lp_b2; lp_a1 = P.lp_a1; lp_a2 = P.lp_a2;
     agc_att = P.agc_attack; agc_rel = P.agc_release;
@@ -99,6 +102,8 @@ struct Consts<double> {
     bp_a1 = S.coef[(size_t)CF_bp_a1 * n + row];
     bp_a2 = S.coef[(size_t)CF_bp_a2 * n + row];
     omega = S.coef[(size_t)CF_omega * n + row];
+    cw = S.coef[(size_t)CF_w1_re * n + row]; sw = S.coef[(size_t)CF_w1_im * n + row];
+    omega_small = omega >= 0.0 && omega < 6.283185307179586476925;
   }
 };
 
@@ -111,6 +116,7 @@ struct Lane {
   FSK_INT_FIELDS(X)
 #undef X
   uint32_t thr_eff;  // matched_min while searching, 0xFFFFFFFF while a frame is started (not stored)
+  Real nco_c, nco_s; // fp64: cos / sin of nco_phase, carried by rotation between refreshes (not stored; see mix_lp)
 };
 
 template <typename Real>
@@ -257,14 +263,13 @@ __device__ inline float pre_stage(Lane<double> &L, const Consts<double> &C, bool
   float xs = xin;
   if (agc_on) {
     xs = (float)((double)xin * L.agc_gain);  // samples[i] *= gain : Float32Array store
+    // (one division and two selects instead of the reference's two branches: the same operations on the same values in
+    // every case -- level == 0 divides to +inf and is discarded -- and a divergent branch costs a lone wave ~35 cycles)
     double level = fabs((double)xs);
-    if (level > 0.5) {
-      double target = 0.5 / level;
-      L.agc_gain += (target - L.agc_gain) * C.agc_att;
-    } else if (level > 0.0) {
-      double target = 0.5 / level;
-      L.agc_gain += (target - L.agc_gain) * C.agc_rel;
-    }
+    const double target = 0.5 / level;
+    const double rate = level > 0.5 ? C.agc_att : C.agc_rel;
+    const double gn = L.agc_gain + (target - L.agc_gain) * rate;
+    L.agc_gain = level > 0.0 ? gn : L.agc_gain;
     double g = L.agc_gain < 10.0 ? L.agc_gain : 10.0;
     L.agc_gain = g > 0.1 ? g : 0.1;
   }
@@ -274,11 +279,38 @@ __device__ inline float pre_stage(Lane<double> &L, const Consts<double> &C, bool
 }
 
 // NCO mix + I/Q low-pass for one pre-filtered sample (fsk.ts:228-238): the part resetState() zeroes.
+//
+// The NCO.  The reference evaluates Math.cos / Math.sin of localOscPhase and advances it by `(phase + omega) % (2 pi)`
+// every sample.  The phase itself is kept exactly as the reference has it (for 0 <= omega < 2 pi the `%` is one
+// conditional subtraction, exact by Sterbenz' lemma, so nco_phase is bit for bit the reference's at every sample); its
+// cosine and sine are carried as a phasor that is ROTATED by e^{j omega} each sample (four FMAs) and re-evaluated from the
+// exact phase by nco_refresh() at every tile boundary (32 samples) and set to exactly (1, 0) by a reset.  Between two
+// refreshes the phasor drifts from the true cos / sin of nco_phase by at most 32 x (the `+`'s rounding 4.4e-16 + the
+// rotation's 2e-16) = 2e-14, against the 1e-12 the fp64 intermediates are held to; evaluating both functions afresh per
+// sample (the device library's: ~150 instructions and a dozen branches) was 60 % of this kernel's time.
+__device__ inline void nco_refresh(Lane<double> &L, const Consts<double> &C) {
+  if (C.omega_small) sincos_0_2pi(L.nco_phase, L.nco_c, L.nco_s);
+}
+__device__ inline void nco_refresh(Lane<float> &, const Consts<float> &) {}
+__device__ inline bool nco_rot_ok(const Consts<double> &C) { return __builtin_amdgcn_ballot_w64(!C.omega_small) == 0ull; }
+__device__ inline bool nco_rot_ok(const Consts<float> &) { return true; }
+template <bool ROT = false>
 __device__ inline void mix_lp(Lane<double> &L, const Consts<double> &C, float pre, double &fi, double &fq) {
   double s = (double)pre;
-  double ci = s * cos(L.nco_phase);
-  double cq = s * sin(L.nco_phase);
-  L.nco_phase = fmod(L.nco_phase + C.omega, 2.0 * 3.14159265358979323846);
+  double ci, cq;
+  if (ROT || C.omega_small) {   // (ROT: the caller has checked omega_small for the whole wave)
+    ci = s * L.nco_c;
+    cq = s * L.nco_s;
+    const double t = L.nco_phase + C.omega;                       // in [0, 4 pi)
+    L.nco_phase = t >= 2.0 * 3.14159265358979323846 ? t - 2.0 * 3.14159265358979323846 : t;   // == fmod(t, 2 pi)
+    const double nc = __builtin_fma(L.nco_c, C.cw, -(L.nco_s * C.sw));
+    const double ns = __builtin_fma(L.nco_s, C.cw, L.nco_c * C.sw);
+    L.nco_c = nc; L.nco_s = ns;
+  } else {                                                        // (a centre frequency above the sample rate)
+    ci = s * cos(L.nco_phase);
+    cq = s * sin(L.nco_phase);
+    L.nco_phase = fmod(L.nco_phase + C.omega, 2.0 * 3.14159265358979323846);
+  }
   fi = biquad64(C.lp_b0, C.lp_b1, C.lp_b2, C.lp_a1, C.lp_a2, L.li_x1, L.li_x2, L.li_y1, L.li_y2, ci);
   fq = biquad64(C.lp_b0, C.lp_b1, C.lp_b2, C.lp_a1, C.lp_a2, L.lq_x1, L.lq_x2, L.lq_y1, L.lq_y2, cq);
 }
@@ -289,7 +321,7 @@ __device__ inline bool discriminate(Lane<double> &L, const Consts<double> &C, do
   const double PI = 3.14159265358979323846;
   double avg_i = sum_i / 2.0;
   double avg_q = sum_q / 2.0;
-  double phase = atan2(avg_q, avg_i);
+  double phase = atan2_lean(avg_q, avg_i);     // (fsk_f64math.h: within 1.5 ulp of Math.atan2)
   amp = sqrt(avg_i * avg_i + avg_q * avg_q);
   double dphi = phase - L.last_phase;
   if (dphi > PI) dphi -= 2.0 * PI;
@@ -300,7 +332,7 @@ __device__ inline bool discriminate(Lane<double> &L, const Consts<double> &C, do
   return f > 0.0;
 }
 
-__device__ inline void nco_reset(Lane<double> &L) { L.nco_phase = 0.0; }
+__device__ inline void nco_reset(Lane<double> &L) { L.nco_phase = 0.0; L.nco_c = 1.0; L.nco_s = 0.0; }
 
 // ---- fp32: throughput path ---------------------------------------------------------------------
 // Same chain, leaner forms: b1 = 0 / b2 = -b0 (band-pass) and b1 = 2*b0, b2 = b0 (low-pass) are
@@ -333,6 +365,7 @@ __device__ inline float pre_stage(Lane<float> &L, const Consts<float> &C, bool a
   return y;
 }
 
+template <bool ROT = false>
 __device__ inline void mix_lp(Lane<float> &L, const Consts<float> &C, float y, float &fi, float &fq) {
   // NCO: phase in turns = top 32 bits of the accumulator
   float turns = (float)L.nco_hi * 2.3283064365386963e-10f;  // 2^-32
@@ -451,78 +484,85 @@ __device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
     cand = (L.matched >= L.thr_eff) & (L.cad_ctr == 0) & (R.k >= need);
   }
 
-  // ---- rare path 1: end of data (fsk.ts:288-291) ------------------------------------------------
-  if (__ballot(eod)) {
-    if (P.quality) {   // opt-in estimates: the noise floor of the silence that caused the first 'eod' after a sync
-      const uint32_t pushes = amp_base + R.k;
-      quality_on_eod<Real>(P, S, lane, row, eod & valid, R.amp_pos ? R.amp_pos - 1u : P.amp_cap - 1u,
-                           pushes < P.amp_cap ? pushes : P.amp_cap);
-    }
-    if (eod) {
-      O.eod_cnt++;
-      L.eod_total++;
-      reset_state(L, P.matched_min);
-      did_reset = true;
-    }
-  }
-  // ---- rare path 2: frame sync found (fsk.ts:315-327) -------------------------------------------
+  // Control flow: TWO wave-uniform tests per decimated sample -- "something rare" (an 'eod', a sync candidate) and "a
+  // decision with consequences" (a byte completes, a bad start bit, a parked clock) -- around straight-line code: with one
+  // wave per SIMD (fp64 at BASELINE config #3's size) every branch instruction, taken or not, stalls the wave ~35 cycles
+  // (profiles/r03_valu_probe_ctl.txt), and the five separate tests this function used to make were a third of the
+  // fp64 kernel's time.
   const bool sync_now = cand & !eod;
-  uint64_t m = __ballot(sync_now);
-  if (m) {
-    if (sync_now) {
-      L.started = 1; L.thr_eff = 0xFFFFFFFFu;
-      L.byte_cur = 0; L.bit_pos = 0;
-      L.bit_acc = 0; L.bit_wait = 0; L.bit_reload = 0;
-      L.sync_det++;
-    }
-    // silence.threshold = mean(syncAmplitudeBuffer) * 0.1: the 64 lanes read the syncing stream's
-    // ring column together and tree-reduce in f64
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's ring stores have reached L2
-    const uint32_t pushes = amp_base + R.k;
-    const uint32_t my_len = pushes < P.amp_cap ? pushes : P.amp_cap;
-    while (m) {
-      const int src = __ffsll((unsigned long long)m) - 1;
-      m &= m - 1;
-      const uint32_t srow = __shfl(row, src, 64);
-      const uint32_t slen = __shfl(my_len, src, 64);
-      double part = 0.0;
-      for (uint32_t i = lane; i < slen; i += 64) {
-        const float *p = S.amp_ring + amp_index(i, srow, P.n_streams);
-        part += (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L1 bypass
+  if (__ballot(eod | sync_now)) {
+    // ---- rare path 1: end of data (fsk.ts:288-291) ----------------------------------------------
+    if (__ballot(eod)) {
+      if (P.quality) {   // opt-in estimates: the noise floor of the silence that caused the first 'eod' after a sync
+        const uint32_t pushes = amp_base + R.k;
+        quality_on_eod<Real>(P, S, lane, row, eod & valid, R.amp_pos ? R.amp_pos - 1u : P.amp_cap - 1u,
+                             pushes < P.amp_cap ? pushes : P.amp_cap);
       }
-      const double sum = wave_sum(part);
-      if ((int)lane == src) {
-        L.sil_thr = (Real)((sum / (double)slen) * 0.1);
-        if (P.quality) quality_on_sync<Real>(P, S, row, sum / (double)slen);
+      if (eod) {
+        O.eod_cnt++;
+        L.eod_total++;
+        reset_state(L, P.matched_min);
+        did_reset = true;
+      }
+    }
+    // ---- rare path 2: frame sync found (fsk.ts:315-327) -----------------------------------------
+    uint64_t m = __ballot(sync_now);
+    if (m) {
+      if (sync_now) {
+        L.started = 1; L.thr_eff = 0xFFFFFFFFu;
+        L.byte_cur = 0; L.bit_pos = 0;
+        L.bit_acc = 0; L.bit_wait = 0; L.bit_reload = 0;
+        L.sync_det++;
+      }
+      // silence.threshold = mean(syncAmplitudeBuffer) * 0.1: the 64 lanes read the syncing stream's
+      // ring column together and tree-reduce in f64
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's ring stores have reached L2
+      const uint32_t pushes = amp_base + R.k;
+      const uint32_t my_len = pushes < P.amp_cap ? pushes : P.amp_cap;
+      while (m) {
+        const int src = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        const uint32_t srow = __shfl(row, src, 64);
+        const uint32_t slen = __shfl(my_len, src, 64);
+        double part = 0.0;
+        for (uint32_t i = lane; i < slen; i += 64) {
+          const float *p = S.amp_ring + amp_index(i, srow, P.n_streams);
+          part += (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L1 bypass
+        }
+        const double sum = wave_sum(part);
+        if ((int)lane == src) {
+          L.sil_thr = (Real)((sum / (double)slen) * 0.1);
+          if (P.quality) quality_on_sync<Real>(P, S, row, sum / (double)slen);
+        }
       }
     }
   }
-  // ---- rare path 3 (some lane nearly every step): bit decision + processByte (fsk.ts:335-375) ---
+  // ---- bit decision + processByte (fsk.ts:335-375): some lane decides at nearly every step, so the decision itself is
+  // masked arithmetic for all lanes; only its consequences branch
   const bool dec_now = decide & !eod & (L.started != 0);
-  if (__ballot(dec_now)) {
-    bool emit = false, bad_start = false, good_start = false;
-    uint32_t q_cnt = 0, q_ones = 0;
-    if (dec_now) {
-      const uint32_t cnt = L.bit_reload - L.bit_wait;           // bitAccumCount
-      const uint32_t b = (2u * L.bit_acc > cnt) ? 1u : 0u;      // fsk.ts:336
-      q_cnt = cnt; q_ones = L.bit_acc;
-      L.bit_acc = 0;
-      L.bit_wait += P.d;                                        // nextBitSampleIndex += dsSPB
-      L.bit_reload = L.bit_wait;
-      const uint32_t pos = L.bit_pos;
-      // data bits MSB first: positions 1..8 land in bits 7..0; position 0 (start bit, must be 0 to
-      // get here) and positions >= 9 land above bit 7 and are masked off when the byte is emitted
-      L.byte_cur |= b << ((8u - pos) & 31u);
-      const bool is_stop = pos == P.stop_pos;
-      bad_start = (pos == 0) & (b != 0);
-      good_start = (pos == 0) & (b == 0);
-      emit = is_stop & (b != 0);
-      L.bit_pos = is_stop ? 0u : pos + 1;
-      if (is_stop & (b == 0)) {                                 // bad stop bit: fsk.ts:363-366
-        L.started = 0; L.thr_eff = P.matched_min; L.bit_wait = kBigWait;
-        L.bit_pos = pos;
-      }
-    }
+  const uint32_t cnt = L.bit_reload - L.bit_wait;               // bitAccumCount
+  const uint32_t b = (2u * L.bit_acc > cnt) ? 1u : 0u;          // fsk.ts:336
+  const uint32_t q_cnt = cnt, q_ones = L.bit_acc;
+  const uint32_t pos = L.bit_pos;
+  const bool is_stop = pos == P.stop_pos;
+  const bool bad_start = dec_now & (pos == 0) & (b != 0);
+  const bool good_start = dec_now & (pos == 0) & (b == 0);
+  const bool emit = dec_now & is_stop & (b != 0);
+  const bool bad_stop = dec_now & is_stop & (b == 0);           // fsk.ts:363-366
+  {
+    const uint32_t wait_n = L.bit_wait + P.d;                   // nextBitSampleIndex += dsSPB
+    L.bit_acc = dec_now ? 0u : L.bit_acc;
+    L.bit_reload = dec_now ? wait_n : L.bit_reload;
+    L.bit_wait = dec_now ? (bad_stop ? kBigWait : wait_n) : L.bit_wait;
+    // data bits MSB first: positions 1..8 land in bits 7..0; position 0 (start bit, must be 0 to
+    // get here) and positions >= 9 land above bit 7 and are masked off when the byte is emitted
+    L.byte_cur |= dec_now ? (b << ((8u - pos) & 31u)) : 0u;
+    L.bit_pos = dec_now ? ((is_stop & !bad_stop) ? 0u : (bad_stop ? pos : pos + 1u)) : pos;
+    L.started = bad_stop ? 0u : L.started;
+    L.thr_eff = bad_stop ? P.matched_min : L.thr_eff;
+  }
+  const bool park = decide & (L.started == 0) & !bad_start;     // bit_wait ran down without a frame (12 h of decimated samples)
+  if (__ballot(bad_start | emit | park | (good_start & (P.quality != 0)))) {
     if (__ballot(bad_start)) {
       if (bad_start) { reset_state(L, P.matched_min); did_reset = true; }  // fsk.ts:352-355
     }
@@ -530,16 +570,12 @@ __device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
       if (good_start & valid) quality_on_start<Real>(P, S, row, post);
       if (emit & valid) quality_on_byte<Real>(P, S, row, (uint32_t)(uint8_t)L.byte_cur, q_ones, q_cnt, post);
     }
-    if (__ballot(emit)) {
-      if (emit) {
-        if (valid && O.out_cnt < O.out_pitch) O.out_row[O.out_cnt] = (uint8_t)L.byte_cur;
-        O.out_cnt++;
-        L.byte_cur = 0;
-      }
+    if (emit) {
+      if (valid && O.out_cnt < O.out_pitch) O.out_row[O.out_cnt] = (uint8_t)L.byte_cur;
+      O.out_cnt++;
+      L.byte_cur = 0;
     }
-  }
-  // bit_wait ran down without a frame (12 h of decimated samples): park it again
-  if (__ballot(decide & (L.started == 0))) {
+    // park the clock again
     if (decide & (L.started == 0)) L.bit_wait = kBigWait;
   }
   return did_reset;
@@ -707,7 +743,7 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       pre_y[k] = pre_stage(L, C, agc_on, x[k], wbv[k]);
-      mix_lp(L, C, pre_y[k], fi[k], fq[k]);
+      mix_lp<true>(L, C, pre_y[k], fi[k], fq[k]);
     }
     Real amp0, post0, amp1, post1;
     const bool bit0 = discriminate(L, C, fi[0] + fi[1], fq[0] + fq[1], amp0, post0);
@@ -724,18 +760,20 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
       if (p == 0 && __ballot(rst)) {
         if (rst) {  // resetState() ran after pair 0: redo the reset-sensitive half of samples 2,3
           Real gi2, gq2, gi3, gq3;
-          mix_lp(L, C, pre_y[2], gi2, gq2);
-          mix_lp(L, C, pre_y[3], gi3, gq3);
+          mix_lp<true>(L, C, pre_y[2], gi2, gq2);
+          mix_lp<true>(L, C, pre_y[3], gi3, gq3);
           bit1 = discriminate(L, C, gi2 + gi3, gq2 + gq3, amp1, post1);
         }
       }
     }
   };
 
-  const bool fast = UNI && (__builtin_amdgcn_readfirstlane((int)L.ds_cnt) == 0);
+  // (fp64: the four-sample block runs the NCO as a rotation, which needs omega < 2 pi in every lane -- any real configuration)
+  const bool fast = UNI && (__builtin_amdgcn_readfirstlane((int)L.ds_cnt) == 0) && nco_rot_ok(C);
   bool cur_fast = n > 0 && tile_is_fast(0);
   if (cur_fast) load_tile_fast(0);
   for (size_t t0 = 0; t0 < n; t0 += kTile) {
+    nco_refresh(L, C);   // fp64: the NCO phasor afresh from the exact phase (mix_lp)
     __syncthreads();  // single-wave workgroup: orders last tile's LDS reads before the overwrite
     if (cur_fast) {
 #pragma unroll
