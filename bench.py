@@ -68,6 +68,15 @@ WORKLOADS = {
     "c4": dict(cfg=dict(baudRate=300, markFrequency=1000, spaceFrequency=1200), payload=16, snr=None, num="4",
                desc="300 baud, per-stream mark/space tone pairs @48 kHz", per_stream=True),
     "default": dict(cfg=dict(), payload=100, snr=None, num="-", desc="default 1650/1850 Hz 1200 baud @48 kHz"),
+    # VERDICT r03 #3 -- what a receiver bank does most of its life.  idle: ONE frame per stream, then a Gaussian floor 30 dB
+    # under it for the rest of the 10 s: after the frame every stream fires 'eod' each samplesForEOD decimated samples and
+    # resets (fsk.ts:285-295), with independent timing per stream.
+    "idle": dict(cfg=dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200), payload=100, snr=None, num="3 (idle variant)",
+                 desc="Bell-202 1200 baud @48 kHz, ONE frame per stream then a noise floor 30 dB under it", idle_db=30.0),
+    # c1x: BASELINE config #1's tone pair as written (mark 1270 / space 1070: the polarity the reference does not decode) at
+    # config #3's stream count: a bank that searches for a preamble all the time and never finds one (fsk.ts:297-328)
+    "c1x": dict(cfg=dict(baudRate=300, markFrequency=1270, spaceFrequency=1070), payload=32, snr=None, num="1 (x 65 536)",
+                desc="V.21 300 baud with config #1's polarity (mark 1270 / space 1070 Hz: never syncs) @48 kHz"),
 }
 
 
@@ -361,6 +370,24 @@ def worker(args):
         if wl.get("roundtrip"):
             c5q = c5_build_and_score(torch, np, wm, eng, cfg, x, N, pitch, snr, seed, wl["payload"], stream,
                                      args.cpu_seconds if rank == 0 else 0, first_stream)
+        elif wl.get("idle_db") is not None:
+            # one frame per stream (the synthesiser's first, with its random lead-in and level), zeros behind it, then noise
+            # over everything: sigma^2 = (mean square of the stream's frame) / 10^(idle_db / 10).  add_awgn_device takes its
+            # SNR against the mean square of the WHOLE buffer, of which the frame is frame_len / N.
+            import math
+            frame_len = eng.modulated_length(wl["payload"])
+            lead_max = 10 * spb
+            n0 = min(N, (lead_max + frame_len + 31) // 32 * 32)
+            x.zero_()
+            eng.synth_device(x.data_ptr(), n0, pitch, wl["payload"], seed, lead_max, 0.1, 1.0, stream)
+            torch.cuda.synchronize()
+            ends = np.array([eng.synth_stream_params(seed, s_, lead_max, 0.1, 1.0)[0] for s_ in range(S)], np.int64) + frame_len
+            d_end = torch.as_tensor(ends, device="cuda")
+            c0 = int(ends.min())
+            if c0 < n0:   # what the synthesiser put behind each stream's first frame
+                cols = torch.arange(c0, n0, device="cuda")
+                x[:, c0:n0] *= (cols[None, :] < d_end[:, None])
+            eng.add_awgn_device(x.data_ptr(), N, pitch, wl["idle_db"] - 10.0 * math.log10(N / float(frame_len)), seed ^ 0xA36, stream)
         else:
             eng.synth_device(x.data_ptr(), N, pitch, wl["payload"], seed, 10 * spb, 0.1, 1.0, stream)
             if snr is not None:
@@ -415,6 +442,22 @@ def worker(args):
 
     elapsed, n_launch, kernel_ms = measure(sync, dist, eng, step, args.steps, args.warmup, dev)
 
+    # ---- the shader clock the device holds under this load: a one-wave probe (fskhip_clock_probe_*) started
+    # first, a few more steps of the same work behind it.  Outside the timed region on purpose: the probe's wave takes a slot
+    # that one workgroup of a full-device launch has to wait for.
+    clock_ghz = None
+    if rank == 0 and not dry:
+        try:
+            per_step_ms = elapsed / args.steps * 1e3
+            k_probe = max(2, min(6, int(250.0 / max(per_step_ms, 1e-3)) + 1))
+            eng.clock_probe_begin(min(2000.0, 0.8 * k_probe * per_step_ms))
+            for _ in range(k_probe):
+                step()
+            sync()
+            clock_ghz, _covered = eng.clock_probe_end()
+        except Exception as ex:
+            print("clock probe failed: %s" % ex, file=sys.stderr)
+
     # ---- N > 1: the strong-scaling shape of the same job (BASELINE config #3 as written), same line -------------------
     strong = None
     if world > 1 and not strong_only:
@@ -454,6 +497,27 @@ def worker(args):
     side = {}
     if rank == 0 and world == 1 and not args.no_side and args.precision == "f32" and cfgs is None and not dry and c5q is None:
         k_side = max(2, min(args.steps, 4))
+        # (0) one GPU's share of BASELINE configs #3 (65 536 streams over eight GPUs = 8 192) and #5 (16 384 over eight = 2 048):
+        # the strong-scaling estimate in the driver's own record (VERDICT r03 "missing" 3).  Same signal, same length: the first
+        # rows of the resident batch.
+        try:
+            shares = {}
+            for s_share in (8192, 2048):
+                if s_share >= S:
+                    continue
+                es = wm.FSKEngine(s_share, cfg, device=local_rank, precision=prec)
+
+                def step_s():
+                    es.demodulate_device(x.data_ptr(), N, pitch, out.data_ptr(), out_pitch, counts.data_ptr(), eod.data_ptr(), 0, stream)
+                step_s()
+                nl, ms = timed_steps(sync, es, step_s, k_side)
+                r = s_share * N * nl / (ms / 1e3) / 1e6
+                shares[str(s_share)] = {"Msamples_per_s": round(r, 1), "frac_of_hbm_peak": round(r * 4 / 1e3 / HBM_PEAK_GBS, 4),
+                                        "kernel": es.last_kernel(), "x8_GPUs_Msamples_per_s": round(8 * r, 1)}
+                es.close()
+            side["per_gpu_share"] = shares
+        except Exception as ex:
+            side["per_gpu_share"] = {"error": str(ex)}
         # (1) what exactness costs: the fp64 parity path (op for op with the reference) on the same batch, 1/10 of the length
         try:
             n64 = max(1024, (N // 10) // 32 * 32)
@@ -530,7 +594,7 @@ def worker(args):
 
     def committed(name):
         """a committed profile of THIS kernel (profiles/<round>_<name>.json): the newest round that has one"""
-        for rnd in ("r03", "r02"):
+        for rnd in ("r04", "r03", "r02"):
             pth = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
             if os.path.exists(pth):
                 with open(pth) as fh:
@@ -549,19 +613,35 @@ def worker(args):
     # the ceiling that actually binds: vector instruction issue.  The instruction mix is a committed PMC profile of this
     # kernel (like the traffic figure); the rate is this run's.
     issue = None
+    priced = None
     ij, isrc = committed("issue")
+    clk = clock_ghz if clock_ghz else CLOCK_GHZ
+    clk_note = ("measured in this run: one-wave probe, delta s_memtime / delta s_memrealtime x 100 MHz over extra steps of the same work "
+                "behind the timed region") if clock_ghz else "NOT measured in this run: the part's maximum"
     if ij is not None:
         ns = avg_kernel_s / N * 1e9
         groups = (S + 63) // 64
         valu_per_s = ij["insts_per_group_sample"]["valu"] * groups * N / avg_kernel_s
-        peak = SIMDS * CLOCK_GHZ * 1e9 / 2.0
+        peak = SIMDS * clk * 1e9 / 2.0
         issue = {"bound": "valu_issue", "achieved": round(valu_per_s / 1e9, 1), "peak": round(peak / 1e9, 1), "unit": "Ginst/s",
-                 "frac": round(valu_per_s / peak, 4),
+                 "frac": round(valu_per_s / peak, 4), "clock_ghz_measured": round(clock_ghz, 3) if clock_ghz else None,
+                 "clock_note": clk_note,
                  "insts_per_group_sample": ij["insts_per_group_sample"],
                  "measured_ns_per_sample": round(ns, 1),
-                 "peak_definition": "%d SIMD-32 x one wave64 vector instruction per 2 cycles at %.1f GHz" % (SIMDS, CLOCK_GHZ),
+                 "peak_definition": "%d SIMD-32 x one wave64 vector instruction per 2 cycles at %.3f GHz" % (SIMDS, clk),
                  "source": isrc + " (rocprofv3 --pmc SQ_INSTS_* pass of this kernel; instructions per 64-stream group and input "
                                   "sample x this run's rate)"}
+        pc = ij.get("class_priced_cycles_per_group_sample")
+        if pc:
+            # SIMD cycles the vector + scalar work of one group-sample is priced at (tools/isa_classes.py's classes: full rate 2,
+            # half rate 4, transcendental 8, scalar 2 cycles) against the SIMD cycles one group-sample may take at this rate
+            avail = ns * clk * SIMDS / groups
+            priced = {"bound": "valu_class_priced", "achieved": round(pc, 1), "peak": round(avail, 1),
+                      "unit": "SIMD cycles per group-sample (priced / available)", "frac": round(pc / avail, 4),
+                      "source": ij.get("class_priced_source", isrc)}
+    hbm_frac = achieved / HBM_PEAK_GBS
+    fr = {"hbm": hbm_frac, "valu_issue": issue["frac"] if issue else 0.0, "valu_class_priced": priced["frac"] if priced else 0.0}
+    binding = max(fr, key=lambda k_: fr[k_])
 
     if rank == 0:
         line = {
@@ -590,8 +670,9 @@ def worker(args):
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kernel_name, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                "binding_bound": "valu_issue",
+                "binding_bound": binding,
                 "valu_issue": issue,
+                "valu_class_priced": priced,
                 "binding_note": "the kernel is bound by SIMD time -- vector instruction issue (half-rate and transcendental "
                                 "classes included) plus the cycles every branch / LDS / memory instruction costs its wave -- "
                                 "not by HBM (DESIGN.md section 5): `frac` is the HBM fraction BASELINE.json's metric asks "

@@ -260,6 +260,14 @@ int fskhip_synchronize(fskhip_engine *e);
 int fskhip_timing_begin(fskhip_engine *e);
 int fskhip_timing_end(fskhip_engine *e, uint32_t *n_launches, double *total_ms);
 
+/* The shader clock the device holds under load (measurement aid, no reference counterpart): begin launches a one-wave
+ * kernel on a stream of its own that stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around spin_ms of
+ * sleeping; end waits for it and returns delta(s_memtime) / delta(s_memrealtime) x 0.1 GHz and the milliseconds it really
+ * covered.  Start it first and launch the work to be observed behind it, on other streams -- NOT around a timed region: the
+ * probe's wave takes a slot that one workgroup of a full-device launch then has to wait for. */
+int fskhip_clock_probe_begin(fskhip_engine *e, double spin_ms);
+int fskhip_clock_probe_end(fskhip_engine *e, double *shader_ghz, double *covered_ms);
+
 const char *fskhip_last_error(void);
 int fskhip_abi_version(void);
 int fskhip_device_count(void);

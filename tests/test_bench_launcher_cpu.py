@@ -38,7 +38,7 @@ def test_self_launch_two_ranks_dry_engine():
     assert st["total_streams"] == 4096 and st["streams_per_gpu"] == 2048
     assert st["Msamples_per_s"] > 0
     assert "dry-run" in d["data"]
-    assert d["roofline"]["binding_bound"] == "valu_issue"
+    assert d["roofline"]["binding_bound"] in ("hbm", "valu_issue", "valu_class_priced")   # (the ceiling this run came closest to)
 
 
 def test_single_rank_dry_engine_has_no_launcher_hop():

@@ -471,6 +471,40 @@ def test_fp32_vs_fp64_engines_deviation_rate_full_size():
         gen.close()
 
 
+def test_short_odd_calls_do_not_take_the_engine_off_the_block_kernel():
+    """VERDICT r03 #6.  A 6-sample call leaves the amplitude ring three pushes into a quad, a 17-sample call then leaves the
+    /2 decimator mid-pair and the next buffer on a 4-byte boundary.  Round 3 then kept the engine on round 2's kernels (or
+    the per-sample kernel) for the rest of its life; now the head of the next call realigns both (fsk_api.hip) and BASELINE
+    config #3's full-length call runs on the block kernel: its bytes are those of one call over the whole stream and of
+    the oracle."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    S, N = 65536, 480000 + 6 + 17
+    P = N + 1                                   # row pitch in floats: a multiple of four (the tile path's only layout condition)
+    gen = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    try:
+        d_x = gen.device_malloc(S * P * 4)
+    except Exception as ex:
+        pytest.skip("cannot hold 126 GB: %s" % ex)
+    gen.synth_device(d_x, N, P, 100, SEED + 3, 400, 0.1, 1.0)
+    gen.synchronize()
+    eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    rows, eod = _demod_schedule(eng, d_x, N, P, [6, 17, 480000])
+    assert eng.last_kernel().startswith("fsk::demod_blk_kernel"), eng.last_kernel()
+    eng.close()
+    eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    rows1, eod1 = _demod_schedule(eng, d_x, N, P, [N])
+    eng.close()
+    assert _digest(rows, eod) == _digest(rows1, eod1)
+    row = np.empty(P, np.float32)
+    for s in list(range(0, S, S // 8)) + [S - 1]:
+        gen.d2h(row, d_x + s * P * 4)
+        ob, oe = po.OracleCore(BELL).demodulate(row[:N])
+        assert rows[s] == ob and int(eod[s]) == oe, s
+    gen.device_free(d_x)
+    gen.close()
+
+
 @pytest.mark.parametrize("S", [64, 200])
 def test_odd_call_lengths_and_unaligned_buffers_stay_on_the_fp32_arithmetic(S):
     """Calls of odd lengths leave a decimator pair open and the next call's buffer on a 4-byte boundary: the head / tile /

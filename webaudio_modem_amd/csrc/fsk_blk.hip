@@ -286,8 +286,26 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
   }
   __syncthreads();
   const uint32_t simd = (__builtin_amdgcn_s_getreg(0xF804) >> 4) & 3u;
-  const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)((simd + ctr[4]) & 3u));
+  // The part a wave WANTS follows its SIMD; the part it GETS is settled among the four waves through LDS, so that every
+  // part is played exactly once whatever the placement (were two waves of a workgroup ever placed on one
+  // SIMD -- co-resident kernels, CU masking, another firmware -- a part would be missing and the others would wait for
+  // its counter forever).  Every wave posts its wish, then all four evaluate the same rule on the same four words: in wave
+  // order, a wave takes its wish if no earlier wave has it, else the lowest part still free.  One LDS write and one
+  // barrier per kernel; with the usual one-wave-per-SIMD placement every wave gets its wish.
+  if (lane == 0) ctr[8 + wave] = (simd + ctr[4]) & 3u;      // (ctr[8..11]: the first words of zmail, initialised after this)
+  __syncthreads();
+  uint32_t role = 0;
+  {
+    uint32_t taken = 0;
+    for (uint32_t w = 0; w <= wave; w++) {
+      uint32_t want = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctr[8 + w]) & 3u;
+      if (taken & (1u << want)) want = (uint32_t)__builtin_ctz(~taken & 15u);
+      taken |= 1u << want;
+      role = want;
+    }
+  }
   const uint32_t wgj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ctr[4] & 3u));
+  __syncthreads();                                          // (zmail is written below)
 
   uint32_t push_e = 0;             // the entry to put behind the queue's tail: the slice after the one just completed
 #pragma unroll 1

@@ -1,7 +1,7 @@
-// fsk_f64math.h -- lean double-precision elementary functions for the fp64 demodulator (fsk_demod.hip, fsk_x64.hip):
+// fsk_f64math.h -- lean double-precision elementary functions for the fp64 demodulator (fsk_demod.hip):
 // sin/cos of an NCO phase in [0, 2 pi] and atan2 of a finite I/Q pair, branch-free, each within ~1 ulp of the correctly
 // rounded value.  The reference calls Math.cos / Math.sin / Math.atan2 (fsk.ts:229-230, 251); V8's are an fdlibm port,
-// the oracle's are glibc's, the device library's are ocml's -- three implementations that already differ from each other
+// the CPU restatement's are glibc's, the device library's are ocml's -- three implementations that already differ from each other
 // in the last ulp, which is why fp64 intermediates are compared at 1e-12.  What the device
 // library's versions cost is their generality: argument reduction for any magnitude (Payne-Hanek loops), special cases,
 // 60-120 instructions and a dozen branches per call, three calls per input sample -- 80 % of the fp64 kernel's time

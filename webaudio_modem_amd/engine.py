@@ -279,6 +279,16 @@ class FSKEngine:
     def synchronize(self):
         _lib.check(self._L.fskhip_synchronize(self._h))
 
+    def clock_probe_begin(self, spin_ms):
+        """start the shader-clock probe (include/fskhip.h); launch the work to observe behind it on other streams"""
+        _lib.check(self._L.fskhip_clock_probe_begin(self._h, float(spin_ms)))
+
+    def clock_probe_end(self):
+        """-> (shader clock in GHz, milliseconds the probe covered)"""
+        ghz, ms = C.c_double(), C.c_double()
+        _lib.check(self._L.fskhip_clock_probe_end(self._h, C.byref(ghz), C.byref(ms)))
+        return ghz.value, ms.value
+
     def timing_begin(self):
         _lib.check(self._L.fskhip_timing_begin(self._h))
 
