@@ -97,6 +97,8 @@ def build_parser():
                     help="also launch the read-pattern probe kernel this many times (FETCH_SIZE calibration)")
     ap.add_argument("--pitch-pad", type=int, default=0, help="extra floats of row pitch (experiments)")
     ap.add_argument("--snr-db", type=float, default=None, help="add AWGN at this SNR (overrides the workload's)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="fskhip_set_option for every engine of this run (measurements: kernel=two-wave, blk_y_slots=12, ...)")
     ap.add_argument("--dry-engine", action="store_true",
                     help="launcher / aggregation test without a GPU: gloo backend and a stand-in engine that only sleeps "
                          "(tests/test_bench_launcher_cpu.py); the line says so in `data`")
@@ -321,6 +323,10 @@ def worker(args):
     wm = None
     if not dry:
         import webaudio_modem_amd as wm
+        if args.opt:
+            import webaudio_modem_amd.engine as wme
+            bench_opts = dict(o.split("=", 1) for o in args.opt)
+            wme.option_hook = lambda n_streams, precision: bench_opts
 
     wl = WORKLOADS[args.workload]
     cfg = wl["cfg"]

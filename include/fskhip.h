@@ -260,6 +260,19 @@ int fskhip_synchronize(fskhip_engine *e);
 int fskhip_timing_begin(fskhip_engine *e);
 int fskhip_timing_end(fskhip_engine *e, uint32_t *n_launches, double *total_ms);
 
+/* Tuning and test switches, by name; call right after fskhip_create (FSKHIP_E_INVALID once the engine has demodulated,
+ * for unknown names and for values that are not numbers or out of range).  None changes a result: every choice computes
+ * the same bytes (tests/test_gpu_parity.py runs the goldens through each kernel).  The library reads no environment
+ * variable.
+ *   "kernel"         auto | auto-r02 | four-wave | two-wave | one-wave   which whole-tile fp32 kernel (default auto)
+ *   "force_generic"  0 | 1          never a whole-tile kernel: the sample-serial kernel only
+ *   "blk_y_slots"    6 .. 28, even  depth of the four-wave kernel's first ring (checked against the LDS it needs)
+ *   "blk_min_tiles"  n              calls with fewer whole tiles stay off the four-wave kernel
+ *   "blk_resident"   n >= 1         treat the device as holding n workgroups at once (time-sliced launches on small batches)
+ *   "slice_tiles"    n >= 1 | off   tiles per time slice of a persistent launch
+ *   "host_slab"      n              samples per time slab of fskhip_demodulate_host's pipeline (0 = no pipeline) */
+int fskhip_set_option(fskhip_engine *e, const char *name, const char *value);
+
 /* The shader clock the device holds under load (measurement aid, no reference counterpart): begin launches a one-wave
  * kernel on a stream of its own that stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around spin_ms of
  * sleeping; end waits for it and returns delta(s_memtime) / delta(s_memrealtime) x 0.1 GHz and the milliseconds it really

@@ -11,6 +11,13 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+# The tests pin kernels and launch shapes with FSKHIP_* environment variables (monkeypatch.setenv); the library and the
+# package read none -- tools/envopts.py maps them to fskhip_set_option() calls on every engine a test creates.
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import envopts  # noqa: E402
+
+envopts.install()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -152,20 +152,38 @@ def test_whole_tile_kernels_never_spill():
     for name, v in fused.items():
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
         assert v["VGPRs"] <= 168, (name, v)
-    pipe = {k: v for k, v in res.items() if "demod_pipe_kernel" in k}    # (not demod_pipe3_kernel)
+    pipe = {k: v for k, v in res.items() if "demod_pipe_kernel" in k}
     assert len(pipe) == 4
     for name, v in pipe.items():
-        assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
-        assert v["VGPRs"] <= 256, (name, v)
-    pipe3 = {k: v for k, v in res.items() if "demod_pipe3_kernel" in k}
-    assert len(pipe3) == 4
-    for name, v in pipe3.items():
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (name, v)
         assert v["VGPRs"] <= 256, (name, v)
     # the registers the asm prefetch lands in are never touched while a load may still be in flight
     assert check_isa.prefetch_register_hazards() == []
     assert check_isa.pipe_prefetch_hazards() == []
-    assert check_isa.pipe_prefetch_hazards(r"_ZN3fsk18demod_pipe3_kernel") == []
     # the four-wave block kernel (fsk_blk.hip): within 128 VGPRs, no scratch access inside the per-tile loops, the
     # asynchronous hand-off counter read's registers untouched until a wait covers it
     assert check_isa.blk_checks() == []
+
+
+def test_time_sliced_launches_hand_every_field_on_with_device_scope_policy():
+    """a time slice of fsk_blk.hip's persistent launch hands its state to a slice that may run on another XCD
+    (another L2).  That is only correct if EVERY access to what is handed on carries the device-scope cache policy (COH =
+    kCohSc1 under SL): one helper instantiated without the template argument would leave one field stale, intermittently.
+    The helpers take COH as a template argument (default 0 for the other kernels); here every instantiation of one of them
+    in fsk_blk.hip must name it, the PIPE_* state macros expand to `COH` by themselves, and the kernel defines COH from SL."""
+    import re
+    src = open(os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_blk.hip"), encoding="utf-8").read()
+    assert "constexpr int COH = SL ? kCohSc1 : 0;" in src
+    src = re.sub(r"//[^\n]*", "", src)          # (code only)
+    helpers = ["pipe_free0", "front_load", "back_load", "back_pair", "pipe_store", "ist_load", "ist_store", "back_reset"]
+    for h in helpers:
+        for m in re.finditer(r"\b%s\s*(<[^>(]*>)?\s*\(" % h, src):
+            targs = m.group(1) or ""
+            assert "COH" in targs, "fsk_blk.hip: %s instantiated without COH: %r" % (h, src[m.start():m.start() + 60])
+    dev = open(os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_pipe_dev.h"), encoding="utf-8").read()
+    for macro in ("PIPE_RLOAD", "PIPE_ILOAD", "PIPE_RSTORE", "PIPE_ISTORE"):
+        line = [l for l in dev.splitlines() if l.startswith("#define " + macro)][0]
+        assert re.search(r", COH\)+$", line.rstrip()), line
+    # the helpers that reach state through other helpers pass it down
+    for inner in ("ist_store<COH>", "ist_load<COH>", "back_reset<UNI, COH>"):
+        assert inner in dev, inner

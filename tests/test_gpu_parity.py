@@ -34,11 +34,11 @@ def _check_status(st, ref, tol, agc_gain):
         assert st["agcGain"] == pytest.approx(agc_gain, rel=max(tol, 1e-12) * 10)
 
 
-# the fp32 path has four kernels for whole tiles: four waves per 64 streams with a block-batched back wave (round 3, the
-# default wherever dsSPB is a multiple of 4), and the round-2 kernels with one, two and three waves per group, which stay
-# for the other configurations and as the per-sample reference of the block path.  FSKHIP_SPLIT pins one of them at
-# engine creation.
-GOLDEN_VARIANTS = PRECISIONS + [("f32-one-wave", 0, 1e-5), ("f32-three-wave", 0, 1e-5), ("f32-four-wave", 0, 1e-5)]
+# the fp32 path has three kernels for whole tiles: four waves per 64 streams with a block-batched back wave (round 3, the
+# default wherever dsSPB is a multiple of 4), and the round-2 kernels with one and two waves per group, which stay for the
+# other configurations and as the per-sample reference of the block path.  FSKHIP_SPLIT (mapped to fskhip_set_option's
+# "kernel" by tests/conftest.py) pins one of them at engine creation.
+GOLDEN_VARIANTS = PRECISIONS + [("f32-one-wave", 0, 1e-5), ("f32-four-wave", 0, 1e-5)]
 
 
 @pytest.mark.parametrize("pname,prec,tol", GOLDEN_VARIANTS)
@@ -47,8 +47,6 @@ def test_demod_matches_reference_golden(name, pname, prec, tol, monkeypatch):
     import webaudio_modem_amd as wm
     if pname == "f32-one-wave":
         monkeypatch.setenv("FSKHIP_SPLIT", "0")
-    elif pname == "f32-three-wave":
-        monkeypatch.setenv("FSKHIP_SPLIT", "3")
     elif pname == "f32-four-wave":
         monkeypatch.setenv("FSKHIP_SPLIT", "4")
     elif pname == "f32":

@@ -104,7 +104,7 @@ def prefetch_register_hazards():
 
 
 def pipe_prefetch_hazards(symbol=r"_ZN3fsk17demod_pipe_kernel"):
-    """The two-wave kernel's front wave (and the three-wave kernel's first wave: symbol=_ZN3fsk18demod_pipe3_kernel) keeps
+    """The two-wave kernel's front wave keeps
     three register sets of asm-issued tile loads in flight (unrolled by three).
     In its tile loop (everything after the prologue's `s_waitcnt vmcnt(0)` up to the epilogue's) a register of a set may
     only be read after the `s_waitcnt vmcnt(N)` placed in front of that set's ds_write_b128 staging, and only by it."""
@@ -240,7 +240,7 @@ def blk_checks():
 
 
 if __name__ == "__main__":
-    for name, what in prefetch_register_hazards() + pipe_prefetch_hazards() + pipe_prefetch_hazards(r"_ZN3fsk18demod_pipe3_kernel") + blk_checks():
+    for name, what in prefetch_register_hazards() + pipe_prefetch_hazards() + blk_checks():
         print("HAZARD", name[:50], what)
         sys.exit(2)
     r = kernel_resources()

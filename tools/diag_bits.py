@@ -6,6 +6,10 @@ import sys, os, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import webaudio_modem_amd as wm
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import envopts  # noqa: E402  (FSKHIP_* variables -> fskhip_set_option)
+envopts.install()
 x = np.load(sys.argv[1]).astype(np.float32)
 cfg = json.loads(sys.argv[2])
 lo, hi = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (0, 0)

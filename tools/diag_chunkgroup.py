@@ -6,6 +6,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import webaudio_modem_amd as wm
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import envopts  # noqa: E402  (FSKHIP_* variables -> fskhip_set_option)
+envopts.install()
 from test_gpu_fullsize import BELL
 # the 64-stream group of tests/test_gpu_fullsize.py's 262144-stream batch in which stream 96606 lost an 'eod' with the
 # four-wave kernel (round 3: the correction's hand-over was posted only 20 samples ahead while the discriminator wave can

@@ -5,6 +5,10 @@ import sys, os, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import webaudio_modem_amd as wm
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import envopts  # noqa: E402  (FSKHIP_* variables -> fskhip_set_option)
+envopts.install()
 from oracle import pyoracle as po
 x = np.load(sys.argv[1]).astype(np.float32)
 cfg = json.loads(sys.argv[2])
@@ -29,9 +33,8 @@ def run(name, env, prec):
               " ".join("%s=%s/%s" % (k[:6], (round(st[k], 6) if isinstance(st[k], float) else st[k]), (round(ost[k], 6) if isinstance(ost[k], float) else int(ost[k]))) for k in KEYS), flag))
         off += n
     eng.close()
-only = os.environ.get("REPLAY_ONLY", "generic,fused,pipe,pipe3").split(",")
+only = os.environ.get("REPLAY_ONLY", "generic,fused,pipe,blk").split(",")
 if "generic" in only: run("generic f32", {"FSKHIP_FORCE_GENERIC": "1"}, wm.PRECISION_F32)
 if "f64" in only: run("generic f64", {}, wm.PRECISION_F64)
 if "fused" in only: run("fused", {"FSKHIP_SPLIT": "0"}, wm.PRECISION_F32)
 if "pipe" in only: run("pipe", {"FSKHIP_SPLIT": "1"}, wm.PRECISION_F32)
-if "pipe3" in only: run("pipe3", {"FSKHIP_SPLIT": "3"}, wm.PRECISION_F32)

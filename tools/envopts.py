@@ -1,0 +1,33 @@
+"""FSKHIP_* environment variables -> fskhip_set_option() names (tests/conftest.py and the measurement tools install this as
+webaudio_modem_amd.engine.option_hook; the package and libfskhip.so themselves read no environment variable).
+
+  FSKHIP_SPLIT=0|1|4|a|b      kernel = one-wave | two-wave | four-wave | auto | auto-r02
+  FSKHIP_FORCE_GENERIC=1      force_generic
+  FSKHIP_BLK_YSLOTS=<n>       blk_y_slots          FSKHIP_BLK_MIN_TILES=<n>   blk_min_tiles
+  FSKHIP_BLK_RESIDENT=<n>     blk_resident         FSKHIP_SLICE_TILES=<n>|off slice_tiles
+  FSKHIP_HOST_SLAB=<n>        host_slab
+"""
+import os
+
+_KERNEL = {"0": "one-wave", "1": "two-wave", "4": "four-wave", "a": "auto", "b": "auto-r02"}
+
+
+def from_env(n_streams=None, precision=None):
+    o = {}
+    sp = os.environ.get("FSKHIP_SPLIT")
+    if sp:
+        o["kernel"] = _KERNEL[sp[0]]
+    if os.environ.get("FSKHIP_FORCE_GENERIC", "")[:1] == "1":
+        o["force_generic"] = 1
+    for env, name in (("FSKHIP_BLK_YSLOTS", "blk_y_slots"), ("FSKHIP_BLK_MIN_TILES", "blk_min_tiles"),
+                      ("FSKHIP_BLK_RESIDENT", "blk_resident"), ("FSKHIP_SLICE_TILES", "slice_tiles"),
+                      ("FSKHIP_HOST_SLAB", "host_slab")):
+        v = os.environ.get(env)
+        if v is not None and v != "":
+            o[name] = v
+    return o
+
+
+def install():
+    import webaudio_modem_amd.engine as eng
+    eng.option_hook = from_env

@@ -2,6 +2,10 @@ import sys, os, time, json
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 import webaudio_modem_amd as wm
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import envopts  # noqa: E402  (FSKHIP_* variables -> fskhip_set_option)
+envopts.install()
 from webaudio_modem_amd import _lib
 cfg = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
 st = torch.cuda.Stream(); sh = st.cuda_stream

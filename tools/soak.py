@@ -11,6 +11,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import webaudio_modem_amd as wm  # noqa: E402
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import envopts  # noqa: E402  (FSKHIP_* variables -> fskhip_set_option)
+envopts.install()
 from oracle import pyoracle as po  # noqa: E402
 
 CONFIGS = [
@@ -79,7 +83,7 @@ def main(budget=None, seed=None, max_rounds=None):
         if target and os.environ.get("SOAK_FORCE_PREC"):
             prec = int(os.environ["SOAK_FORCE_PREC"])
         S = int(rng.choice([1, 2, 63, 64, 65, 100, 130, 192, 257]))
-        os.environ["FSKHIP_SPLIT"] = "0134"[int(rng.integers(4))]   # one / two / three / four waves per 64-stream group
+        os.environ["FSKHIP_SPLIT"] = "014"[int(rng.integers(3))]   # one / two / four waves per 64-stream group
         if target and os.environ.get("SOAK_FORCE_SPLIT"):
             os.environ["FSKHIP_SPLIT"] = os.environ["SOAK_FORCE_SPLIT"]
         os.environ["FSKHIP_SPLIT_LAST"] = os.environ["FSKHIP_SPLIT"]

@@ -14,6 +14,10 @@ import webaudio_modem_amd._lib as L
 if sys.argv[3] != "-": L.LIB_PATH = sys.argv[3]
 import torch
 import webaudio_modem_amd as wm
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import envopts  # noqa: E402  (FSKHIP_* variables -> fskhip_set_option)
+envopts.install()
 S, N = int(sys.argv[1]), int(sys.argv[2])
 wl = os.environ.get("VAR_WORKLOAD", "c3")
 cfg = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200) if wl == "c3" else dict(baudRate=300, markFrequency=1070, spaceFrequency=1270)

@@ -32,13 +32,10 @@ hipError_t launch_demod_tail(bool writeback, bool append, int parity0, const Dem
                              float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream);
 size_t demod_pipe_lds_bytes(const DemodParams &P);
-size_t demod_pipe3_lds_bytes(const DemodParams &P);
-hipError_t launch_demod_pipe3(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
-                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts, uint32_t *eod_counts,
-                              hipStream_t stream);
 size_t demod_fused_lds_bytes(const DemodParams &P);
 // fsk_blk.hip: four waves per group, block-batched back wave
 size_t demod_blk_lds_bytes(const DemodParams &P);
+size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots);
 bool demod_blk_applicable(const DemodParams &P);
 hipError_t set_blk_lds_limit(const DemodParams &P);
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
@@ -183,18 +180,18 @@ struct fskhip_engine {
   std::vector<uint64_t> base_calls, base_samples;
   bool ds_uniform = true;
   uint32_t ds_parity = 0;        // downsample.counter shared by all streams while ds_uniform
-  bool force_generic = false;    // FSKHIP_FORCE_GENERIC=1: never use the fast kernel (tests)
-  bool use_split = false;        // two waves per 64-stream group (demod_split_kernel): batches of fewer than two waves per SIMD
+  // what fskhip_set_option() can change (tests and measurements; none changes a result)
+  bool force_generic = false;    // "force_generic": never a whole-tile kernel
+  bool use_split = false;        // two waves per 64-stream group (demod_pipe_kernel): batches of fewer than two waves per SIMD
   uint32_t split_cus = 256;
-  bool split_forced = false;     // FSKHIP_SPLIT was set: skip the residency check too
-  bool use_split3 = false;       // three waves per group (demod_pipe3_kernel): at most two groups per CU
-  bool use_blk = true;          // four waves per group with the block-batched back wave (demod_blk_kernel, fsk_blk.hip): the default
-                                 // wherever it applies (dsSPB a multiple of 4, >= 8); FSKHIP_SPLIT = 0 / 1 / 3 pins an older kernel
+  bool split_forced = false;     // "kernel" pinned one: skip the residency checks too
+  bool use_blk = true;           // four waves per group with the block-batched back wave (demod_blk_kernel, fsk_blk.hip): the default
+                                 // wherever it applies (dsSPB a multiple of 4, >= 8)
   uint32_t blk_resident = 0;     // workgroups of demod_blk_kernel the device holds at once; larger batches run it persistent, in time slices
-  uint32_t blk_min_tiles = 0;    // calls with fewer whole tiles than this stay with round 2's kernels (the four-wave pipeline's fill and
-                                 // drain cost more than it saves on them); FSKHIP_BLK_MIN_TILES
-  uint32_t blk_y_slots = 6;      // half tiles in the block kernel's y ring: as deep as the LDS allows at this batch size (FSKHIP_BLK_YSLOTS pins it)
-  uint32_t blk_slice_tiles = 0;  // FSKHIP_SLICE_TILES: tiles per time slice (0 = the kernel file's default, "off" = never slice)
+  uint32_t blk_min_tiles = 0;    // calls with fewer whole tiles than this stay with round 2's kernels
+  uint32_t blk_y_slots = 6;      // half tiles in the block kernel's y ring: as deep as the LDS allows at this batch size
+  uint32_t blk_slice_tiles = 0;  // tiles per time slice (0 = the kernel file's default, 0xFFFFFFFF = never slice)
+  size_t host_slab = (size_t)-1; // samples per time slab of fskhip_demodulate_host's pipeline ((size_t)-1 = ~96 MB, 0 = no pipeline)
   bool last_sliced = false;
   uint64_t pushes = 0;           // decimated samples since create (lock-step engines): the amplitude ring's write position
   bool gen_odd = false;          // fp32: the last generic-kernel launch left a decimator pair open (its partial sums are in
@@ -234,7 +231,7 @@ size_t engine_max_bytes(const fskhip_engine *e, size_t n_per_stream) {
 // everything fskhip_demodulate_device's choice of launches depends on besides its arguments
 uint32_t engine_launch_key(const fskhip_engine *e) {
   return (e->ds_uniform ? 1u : 0u) | (e->ds_parity << 1) | (e->force_generic ? 4u : 0u) | (e->timing ? 8u : 0u) |
-         (e->use_split ? 32u : 0u) | (e->gen_odd ? 64u : 0u) | (e->use_split3 ? 128u : 0u) | (e->P.quality ? 256u : 0u) |
+         (e->use_split ? 32u : 0u) | (e->gen_odd ? 64u : 0u) | (e->P.quality ? 256u : 0u) |
          (e->S.trace_stream != 0xFFFFFFFFu ? 16u : 0u) | (e->use_blk ? 512u : 0u) | ((uint32_t)(e->pushes & 3u) << 10);
 }
 void engine_note_replayed_call(fskhip_engine *e, size_t n) {
@@ -365,30 +362,16 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   fskhip_engine *e = new (std::nothrow) fskhip_engine();
   if (!e) return fail(FSKHIP_E_NOMEM, "out of host memory");
   e->device = device; e->precision = precision; e->n_streams = n_streams; e->cfg0 = c0;
-  if (const char *fg = getenv("FSKHIP_FORCE_GENERIC")) e->force_generic = fg[0] == '1';
   {
-    // below two waves per SIMD the one-wave-per-group kernel cannot hide its own dependency stalls; the split kernel
-    // gives every group two instruction streams (measured, Gsamples/s one-wave -> split: 16 -> 21 at 4 096 streams,
-    // 254 -> 307 at 65 536, 328 -> 356 at 98 304, 383 -> 399 at 114 688, equal at 131 072), as long as all its
-    // workgroups' LDS tiles fit on the CUs at once.  FSKHIP_SPLIT=0/1 overrides (tests, measurements).
+    // below two waves per SIMD the one-wave-per-group kernel cannot hide its own dependency stalls; the two-wave kernel
+    // gives every group two instruction streams, as long as all its workgroups' LDS tiles fit on the CUs at once.
+    // (Round 2's choice; since round 3 the four-wave kernel takes every call it applies to.)
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     const uint32_t n_blocks = (n_streams + 63) / 64;
     e->use_split = n_blocks < (uint32_t)cus * 8u;  // < 2 waves per SIMD (4 SIMDs per CU)
     e->split_cus = (uint32_t)cus;
-    // two groups per CU: the two-wave kernel would leave every SIMD one wave, with nothing to cover its LDS round trips; a
-    // third instruction stream per group gives half the SIMDs a second wave (measured: 32 768 streams 245 -> 275
-    // Gsamples/s; at one group per CU or fewer every wave is alone either way and the extra hand-off buys nothing)
-    e->use_split3 = e->use_split && n_blocks > (uint32_t)cus && n_blocks <= (uint32_t)cus * 2u;
-    if (const char *sp = getenv("FSKHIP_SPLIT")) {    // tests / measurements: 0 = one wave, 1 = two, 3 = three per group, 4 = three with the block back
-      e->use_split = sp[0] == '1' || sp[0] == '3' || sp[0] == '4'; e->use_split3 = sp[0] == '3'; e->use_blk = sp[0] == '4';
-      e->split_forced = true;
-      if (sp[0] == 'a' || sp[0] == 'b') {   // 'auto' spelled out; 'b' = auto without the block kernel (round 2's choice)
-        e->use_blk = sp[0] == 'a'; e->split_forced = false; e->use_split = n_blocks < (uint32_t)cus * 8u;
-        e->use_split3 = e->use_split && n_blocks > (uint32_t)cus && n_blocks <= (uint32_t)cus * 2u;
-      }
-    }
   }
 
   // calculateParameters (fsk.ts:426-444), in doubles like the reference
@@ -625,10 +608,6 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   if (e->demod_ok && precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(P)) {
     CREATE_TRY(set_blk_lds_limit(P));
     demod_blk_plan(P, e->n_blocks, device, &e->blk_y_slots, &e->blk_resident);
-    if (const char *ys = getenv("FSKHIP_BLK_YSLOTS")) e->blk_y_slots = (uint32_t)strtoul(ys, nullptr, 10);   // measurements
-    if (const char *mt = getenv("FSKHIP_BLK_MIN_TILES")) e->blk_min_tiles = (uint32_t)strtoul(mt, nullptr, 10);
-    if (const char *rw = getenv("FSKHIP_BLK_RESIDENT")) e->blk_resident = (uint32_t)strtoul(rw, nullptr, 10);   // tests: a "device" this small
-    if (const char *sl = getenv("FSKHIP_SLICE_TILES")) e->blk_slice_tiles = sl[0] == 'o' ? 0xFFFFFFFFu : (uint32_t)strtoul(sl, nullptr, 10);
     if (e->blk_resident && e->n_blocks > e->blk_resident) {
       CREATE_TRY(hipMalloc((void **)&e->S.blk_q, sizeof(uint32_t) * demod_blk_queue_words(e->n_blocks)));
     }
@@ -661,6 +640,73 @@ int fskhip_carry_over(fskhip_engine *dst, const fskhip_engine *src) {
   dst->base_calls = src->base_calls;
   dst->base_samples = src->base_samples;
   return FSKHIP_OK;
+}
+
+// Tuning and test switches (include/fskhip.h).  Everything here only chooses among kernels / launch shapes that compute the
+// same bytes; the library itself reads no environment variable (the switches used to be
+// unvalidated getenv() calls inside fskhip_create).
+int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
+  if (!e || !name || !value) return fail(FSKHIP_E_INVALID, "fskhip_set_option: null argument");
+  if (e->calls != 0 || e->total_samples != 0) return fail(FSKHIP_E_INVALID, "fskhip_set_option(%s): the engine has demodulated already (set options right after fskhip_create)", name);
+  const std::string k(name), v(value);
+  auto number = [&](uint64_t lo, uint64_t hi, uint64_t *out) -> int {
+    if (v.empty() || v.find_first_not_of("0123456789") != std::string::npos || v.size() > 12)
+      return fail(FSKHIP_E_INVALID, "fskhip_set_option(%s): '%s' is not a number", name, value);
+    const uint64_t x = strtoull(v.c_str(), nullptr, 10);
+    if (x < lo || x > hi) return fail(FSKHIP_E_INVALID, "fskhip_set_option(%s): %s outside [%llu, %llu]", name, value, (unsigned long long)lo, (unsigned long long)hi);
+    *out = x;
+    return FSKHIP_OK;
+  };
+  uint64_t x = 0;
+  int rc = FSKHIP_OK;
+  if (k == "kernel") {          // which whole-tile kernel fp32 lock-step calls use
+    const uint32_t n_blocks = e->n_blocks;
+    if (v == "auto") { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; }
+    else if (v == "auto-r02") { e->use_blk = false; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; }
+    else if (v == "four-wave") { e->use_blk = true; e->use_split = true; e->split_forced = true; }
+    else if (v == "two-wave") { e->use_blk = false; e->use_split = true; e->split_forced = true; }
+    else if (v == "one-wave") { e->use_blk = false; e->use_split = false; e->split_forced = true; }
+    else return fail(FSKHIP_E_INVALID, "fskhip_set_option(kernel): '%s' is none of auto, auto-r02, four-wave, two-wave, one-wave", value);
+    return FSKHIP_OK;
+  }
+  if (k == "force_generic") {
+    if ((rc = number(0, 1, &x)) != FSKHIP_OK) return rc;
+    e->force_generic = x != 0;
+    return FSKHIP_OK;
+  }
+  if (k == "host_slab") {
+    if ((rc = number(0, 1ull << 40, &x)) != FSKHIP_OK) return rc;
+    e->host_slab = (size_t)x;
+    return FSKHIP_OK;
+  }
+  const bool blk = e->demod_ok && e->precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(e->P);
+  if (k == "blk_y_slots" || k == "blk_min_tiles" || k == "blk_resident" || k == "slice_tiles") {
+    if (!blk) return FSKHIP_OK;                       // (the four-wave kernel does not apply to this engine: nothing to tune)
+    if (k == "blk_y_slots") {
+      if ((rc = number(6, 28, &x)) != FSKHIP_OK) return rc;
+      if (x & 1u) return fail(FSKHIP_E_INVALID, "fskhip_set_option(blk_y_slots): %s is odd (a tile is two slots)", value);
+      if (demod_blk_lds_bytes(e->P, (uint32_t)x) > 160 * 1024)
+        return fail(FSKHIP_E_INVALID, "fskhip_set_option(blk_y_slots): %s slots need %zu B of LDS (> 160 KiB) at dsSPB %u", value,
+                    demod_blk_lds_bytes(e->P, (uint32_t)x), e->P.d);
+      e->blk_y_slots = (uint32_t)x;
+    } else if (k == "blk_min_tiles") {
+      if ((rc = number(0, 1u << 30, &x)) != FSKHIP_OK) return rc;
+      e->blk_min_tiles = (uint32_t)x;
+    } else if (k == "blk_resident") {                 // tests: a "device" that holds only this many workgroups at once
+      if ((rc = number(1, 1u << 20, &x)) != FSKHIP_OK) return rc;
+      e->blk_resident = (uint32_t)x;
+      if (e->n_blocks > e->blk_resident && !e->S.blk_q) {
+        HIP_TRY(hipSetDevice(e->device));
+        HIP_TRY(hipMalloc((void **)&e->S.blk_q, sizeof(uint32_t) * demod_blk_queue_words(e->n_blocks)));
+      }
+    } else {
+      if (v == "off") { e->blk_slice_tiles = 0xFFFFFFFFu; return FSKHIP_OK; }
+      if ((rc = number(1, 1u << 24, &x)) != FSKHIP_OK) return rc;
+      e->blk_slice_tiles = (uint32_t)x;
+    }
+    return FSKHIP_OK;
+  }
+  return fail(FSKHIP_E_INVALID, "fskhip_set_option: unknown option '%s'", name);
 }
 
 uint32_t fskhip_n_streams(const fskhip_engine *e) { return e ? e->n_streams : 0; }
@@ -726,7 +772,6 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
         app = true;
       }
       if (n_fast) {
-        const size_t pipe3_lds = demod_pipe3_lds_bytes(e->P);
         const size_t blk_lds = demod_blk_lds_bytes(e->P);
         // the block kernel stores amplitudes a quad at a time: the ring's write position at its first sample must be a
         // multiple of four (it is unless earlier calls had odd lengths: those calls then stay with the per-sample kernels)
@@ -748,10 +793,6 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
               "fsk::demod_blk_kernel<true, false, false>", "fsk::demod_blk_kernel<true, false, true>",
               "fsk::demod_blk_kernel<true, true, false>", "fsk::demod_blk_kernel<true, true, true>"};
           e->last_kernel = names[(wb ? 4 : 0) + (e->P.uni_cfg ? 2 : 0) + (e->last_sliced ? 1 : 0)];   // <writeback, uniform, time-sliced>
-        } else if (two_wave && e->use_split3 && pipe3_lds <= 160 * 1024 && (wgs_per_cu * pipe3_lds <= 160 * 1024 || e->split_forced)) {
-          HIP_TRY(launch_demod_pipe3(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
-          e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_pipe3_kernel<true, true>" : "fsk::demod_pipe3_kernel<true, false>")
-                              : (e->P.uni_cfg ? "fsk::demod_pipe3_kernel<false, true>" : "fsk::demod_pipe3_kernel<false, false>");
         } else if (two_wave) {
           HIP_TRY(launch_demod_pipe(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
           e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_pipe_kernel<true, true>" : "fsk::demod_pipe_kernel<true, false>")
@@ -809,8 +850,7 @@ int fskhip_demodulate_host(fskhip_engine *e, float *samples, size_t n, size_t pi
   size_t slab = ((size_t)96 << 20) / (S * sizeof(float));
   slab = slab < 4096 ? 4096 : slab;
   slab &= ~(size_t)15;
-  const char *env = getenv("FSKHIP_HOST_SLAB");          // measurement / test override (samples per slab; 0 = no pipeline)
-  if (env) slab = (size_t)strtoull(env, nullptr, 10) & ~(size_t)15;
+  if (e->host_slab != (size_t)-1) slab = e->host_slab & ~(size_t)15;   // fskhip_set_option("host_slab"): tests / measurements
   const bool piped = slab > 0 && n > slab + slab / 2;
   const size_t len0 = piped ? slab + slab / 2 : n;    // (the last slab of a pipelined call takes the remainder, < 1.5 slabs)
   // device copies keep a row pitch that is a multiple of 4 floats so the 16-B tile loads apply.  A stream whose /2

@@ -18,6 +18,10 @@ static constexpr int kFastTile = 16;
 // Only those launches use it (template parameter COH of the state helpers, 0 everywhere else): between launches the
 // kernel boundary does the job, and the write-through costs -- a 128-sample FSKProcessor quantum moves about as many
 // bytes of state as of samples and ran 0.20 instead of 0.14 ms when every kernel carried it.
+// INVARIANT (tests/test_abi.py greps for it): inside fsk_blk.hip every helper that touches handed-on state is instantiated
+// with the kernel's COH, and a field added to the state must go through those helpers (PIPE_* / ist_* / back_*): an access
+// without it would be stale on another XCD only now and then.  The hand-over itself: every storing wave's `s_waitcnt
+// vmcnt(0)`, the workgroup's barrier, then the queue push (MI355X_MICROARCH.md, "valid forms": all stores and loads sc1).
 static constexpr int kCohSc1 = 16;
 static constexpr uint32_t kStarted = 0xFFFFFFFFu;  // thr_eff while a frame is started (matched_min is <= 0xFFFFFFFE)
 

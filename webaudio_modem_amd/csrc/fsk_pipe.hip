@@ -42,8 +42,8 @@
 //   demod_pipe_kernel   two waves per 64-stream group: wave 0 front, wave 1 back, hand-off through an LDS ring of
 //                       8-sample half tiles with producer/consumer counters (no barrier in the loop).  For batches
 //                       that give a SIMD fewer than ~3 waves (BASELINE configs #2, #3, #5).
-//   demod_pipe3_kernel  three waves per group (AGC + pre-filter | mixer + low-pass + discriminator | back) for batches
-//                       of two groups per CU, where a third instruction stream gives SIMDs a second wave.
+//   (demod_pipe3_kernel, three waves per group, was retired in round 4: fsk_blk.hip's four-wave kernel covers every
+//                       batch size it was selected for.)
 //   demod_fused_kernel  the same two halves called back to back by one wave, pair by pair through registers, for
 //                       batches large enough to fill the SIMDs with one wave per group.
 //   demod_tail_kernel   the same arithmetic one sample at a time: heads and tails of calls, traced engines, engines with
@@ -335,311 +335,6 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
 }
 
 // ================================================================================================================
-// Three waves per 64-stream group, for batches that leave most SIMDs idle (up to two groups per CU: BASELINE config #2's
-// 4 096 streams, config #3 / #5 sharded over eight GPUs).  There the time of a launch is one wave's serial chain --
-// a wave issues one instruction per ~4.9 cycles whatever the other SIMDs do -- so the front is cut once more where
-// nothing feeds back: wave 0 loads, stages and runs AGC + pre-filter, wave 1 mixes, low-passes and evaluates the
-// speculative discriminator, wave 2 is the back wave of demod_pipe_kernel unchanged.  Same arithmetic (front_agc_bp +
-// front_mix_lp = front_sample), so the bytes are those of the other kernels.  At 65 536 streams and up the SIMDs are
-// the limit and the extra LDS hand-off only costs (398 vs 412 Gsamples/s when it was tried there).
-// LDS: stage [4][65] v4f | ring [kPipeSlots][6][64] v4f | yring [kPipeSlots][2][64] v4f | fin [2][64] v4f | zt [2][8] v4f |
-//      poly [d][64] u32 | counters [4] | zmail [64] u32
-// ================================================================================================================
-template <bool WB, bool UNI>
-__global__ __launch_bounds__(192) void demod_pipe3_kernel(
-    DemodParams P, DemodState S, float *__restrict__ samples, size_t n, size_t pitch, int append,
-    uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
-    uint32_t *__restrict__ eod_counts) {
-  FSK_ABL_INIT
-  FSK_STAMP_DECL
-  extern __shared__ float4 lds[];
-  v4f *stage = reinterpret_cast<v4f *>(lds);
-  v4f *ring = stage + 4 * kSlotStride;
-  v4f *yring = ring + kPipeSlots * kSlotV4;               // wave 0 -> wave 1: pre-filter outputs, [slot][quad][lane]
-  v4f *fin = yring + kPipeSlots * 2 * 64;
-  v4f *zt = fin + 2 * 64;
-  uint32_t *poly = reinterpret_cast<uint32_t *>(zt + 2 * 8);
-  uint32_t *ctr = poly + 64u * P.d;                       // [0] wave 1 produced, [1] wave 2 consumed, [2] wave 0 produced, [3] wave 1 consumed
-  uint32_t *zmail = ctr + 4;
-  uint32_t *gpoly = (uint32_t *)S.poly + (size_t)blockIdx.x * P.d * 64u;
-
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t stream = blockIdx.x * 64u + lane;
-  const PipeCtx C = pipe_ctx(P, S, stream);
-  const size_t n_tiles = n / kFastTile;
-  const uint32_t nh = 2u * (uint32_t)n_tiles;               // half tiles
-  const uint64_t inc = UNI ? (((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo) : S.nco_inc[C.row4 >> 2];
-  const uint64_t free0 = pipe_free0<UNI>(C);
-
-  if (threadIdx.x == 0) { ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; }
-  if (wave == 1) {
-    const FastMem &M = C.M;
-    const uint32_t fld = C.fld, row4 = C.row4;
-    zmail[lane] = zmail_init(PIPE_ILOAD(zr_dph));
-  }
-  __syncthreads();
-
-  if (wave == 0) {
-    // ------------------------------------------------------------------------------ loads, AGC, pre-filter
-    FrontLane F;
-    FrontK K;
-    front_load<UNI>(F, K, P, S, C);
-    const uint32_t sub_row = lane >> 2, chunk = lane & 3;
-    const uint32_t rows_here = P.n_streams - blockIdx.x * 64u < 64u ? P.n_streams - blockIdx.x * 64u : 64u;
-    v4i in_rsrc;
-    {
-      const uint64_t base = reinterpret_cast<uint64_t>(samples + (size_t)blockIdx.x * 64u * pitch);
-      in_rsrc.x = (int)(uint32_t)base;
-      in_rsrc.y = (int)(uint32_t)(base >> 32);
-      in_rsrc.z = (int)(uint32_t)(rows_here * pitch * 4u);
-      in_rsrc.w = 0x00020000;
-    }
-    const uint32_t in_voff = (uint32_t)((sub_row * pitch + 4u * chunk) * 4u);
-    const uint32_t in_row16 = (uint32_t)(16u * pitch * 4u);
-    const uint32_t st_slot = chunk * kSlotStride + sub_row;
-    // tile prefetch exactly as in demod_pipe_kernel (three register sets, hand-counted waits)
-#define PIPE_BLOAD4(dst, rows16, soff)                                                                      \
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(in_voff + (rows16) * in_row16), \
-               "s"(in_rsrc), "s"(soff) : "memory")
-    auto load_tile = [&](size_t t, v4f &a, v4f &b, v4f &c, v4f &d) {
-      const uint32_t tn = (uint32_t)((t < n_tiles ? t : n_tiles - 1) * kFastTile * 4u);
-      PIPE_BLOAD4(a, 0u, tn); PIPE_BLOAD4(b, 1u, tn); PIPE_BLOAD4(c, 2u, tn); PIPE_BLOAD4(d, 3u, tn);
-    };
-    v4f a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the state loads above are complete, the count starts clean
-    load_tile(0, a0, a1, a2, a3);
-    load_tile(1, b0, b1, b2, b3);
-    load_tile(2, c0, c1, c2, c3);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
-                 "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
-    uint32_t consumed = 0, slot_i = 0;
-    auto do_tile = [&](uint32_t t, v4f &r0, v4f &r1, v4f &r2, v4f &r3) {
-      if (WB) asm volatile("s_waitcnt vmcnt(16)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
-      stage[st_slot] = r0; stage[st_slot + 16] = r1; stage[st_slot + 32] = r2; stage[st_slot + 48] = r3;
-      load_tile((size_t)t + 3, r0, r1, r2, r3);
-#pragma unroll 1
-      for (uint32_t hf = 0; hf < 2; hf++) {
-        const uint32_t hidx = 2u * t + hf;
-        if (hidx - consumed >= kPipeSlots) {
-          FSK_STAMP_W0
-          while (hidx - consumed >= kPipeSlots) {           // y ring full: wait for wave 1
-            consumed = lds_peek(&ctr[3]);
-            if (hidx - consumed >= kPipeSlots) __builtin_amdgcn_s_sleep(1);
-          }
-          FSK_STAMP_W1
-        }
-        v4f *slot = yring + slot_i * 2u * 64u;
-        slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
-#pragma unroll
-        for (uint32_t cc = 0; cc < 2; cc++) {
-          const uint32_t c = 2u * hf + cc;
-          const v4f x4 = stage[c * kSlotStride + lane];
-          const float xin[4] = {x4.x, x4.y, x4.z, x4.w};
-          float xs[4], y[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) { if (FSK_ABL(0)) xs[j] = y[j] = xin[j]; else front_agc_bp(F, K, xin[j], xs[j], y[j]); }
-          slot[cc * 64u + lane] = (v4f){y[0], y[1], y[2], y[3]};
-          if (WB) {
-            if (C.valid)
-              *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + (size_t)t * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
-          }
-        }
-        lds_post(&ctr[2], hidx + 1u);
-      }
-    };
-    const uint32_t nt = (uint32_t)n_tiles;
-    FSK_STAMP_BEGIN
-    for (uint32_t t = 0; t < nt; t += 3) {
-      do_tile(t, a0, a1, a2, a3);
-      if (t + 1 < nt) do_tile(t + 1, b0, b1, b2, b3);
-      if (t + 2 < nt) do_tile(t + 2, c0, c1, c2, c3);
-    }
-    FSK_STAMP_END(0)
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
-                 "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
-#undef PIPE_BLOAD4
-    {
-      const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
-      const FastMem &M = C.M;
-      const uint32_t fld = C.fld;
-      PIPE_RSTORE(agc_gain, F.g);
-      PIPE_RSTORE(bp_x1, F.bx1); PIPE_RSTORE(bp_x2, F.bx2); PIPE_RSTORE(bp_y1, F.by1); PIPE_RSTORE(bp_y2, F.by2);
-    }
-  } else if (wave == 1) {
-    // ------------------------------------------------------------------------------ mixer, I/Q low-pass, discriminator
-    FrontLane F;
-    FrontK K;
-    front_load<UNI>(F, K, P, S, C);
-    float wre = 1.f, wim = 0.f;
-    if (!UNI) {
-      const __amdgpu_buffer_rsrc_t cf_rsrc = C.cf_rsrc;
-      const uint32_t fld = C.fld, row4 = C.row4;
-      wre = (float)PIPE_CLOAD(CF_w1_re); wim = (float)PIPE_CLOAD(CF_w1_im);
-    }
-    uint64_t zacc = free0 + inc * (uint64_t)(lane & 15u);
-    uint64_t tacc = free0;
-    const uint64_t inc16 = inc * 16u;
-    uint32_t consumed = 0, produced = 0, slot_i = 0, yslot_i = 0;
-    float zr = 1.f, zi = 0.f;
-    const v4f *ztile = zt;
-    FSK_STAMP_BEGIN
-    for (uint32_t hidx = 0; hidx < nh; hidx++) {
-      if (!(hidx & 1u)) {                                     // a new tile: its sixteen NCO phasors (see demod_pipe_kernel)
-        const uint32_t t = hidx >> 1;
-        ztile = zt + (t & 1u) * 8u;
-        if (UNI) {
-          float pc, ps;
-          nco_phasor(zacc, pc, ps);
-          reinterpret_cast<f2 *>(zt + (t & 1u) * 8u)[lane & 15u] = (f2){pc, ps};
-          zacc += inc16;
-        } else {
-          nco_phasor(tacc, zr, zi);
-          tacc += inc16;
-        }
-      }
-      if (produced <= hidx || hidx - consumed >= kPipeSlots) {
-        FSK_STAMP_W0
-        while (produced <= hidx) {                            // wave 0's half tile
-          produced = lds_peek(&ctr[2]);
-          if (produced <= hidx) __builtin_amdgcn_s_sleep(1);
-        }
-        while (hidx - consumed >= kPipeSlots) {               // ring full: wait for the back wave
-          consumed = lds_peek(&ctr[1]);
-          if (hidx - consumed >= kPipeSlots) __builtin_amdgcn_s_sleep(1);
-        }
-        FSK_STAMP_W1
-      }
-      const v4f *yslot = yring + yslot_i * 2u * 64u;
-      yslot_i = yslot_i + 1u == kPipeSlots ? 0u : yslot_i + 1u;
-      v4f *slot = ring + slot_i * kSlotV4;
-      slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
-      const uint32_t zj = zmail[lane];
-      const uint64_t zh = __builtin_amdgcn_ballot_w64(zj - 4u * hidx < 4u);
-#pragma unroll
-      for (uint32_t cc = 0; cc < 2; cc++) {
-        const uint32_t c = 2u * (hidx & 1u) + cc;
-        const v4f y4 = yslot[cc * 64u + lane];
-        const uint32_t pb = 4u * hidx + 2u * cc;
-        float zc[4], zs[4];
-        if (UNI) {
-          const v4f z01 = ztile[c * 2u], z23 = ztile[c * 2u + 1u];
-          zc[0] = z01.x; zs[0] = z01.y; zc[1] = z01.z; zs[1] = z01.w;
-          zc[2] = z23.x; zs[2] = z23.y; zc[3] = z23.z; zs[3] = z23.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            zc[j] = zr; zs[j] = zi;
-            const float nr = __builtin_fmaf(-zi, wim, zr * wre), ni = __builtin_fmaf(zi, wre, zr * wim);
-            zr = nr; zi = ni;
-          }
-        }
-        const float y[4] = {y4.x, y4.y, y4.z, y4.w};
-        float oi[4], oq[4];
-        if (FSK_ABL(1)) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) oi[j] = oq[j] = y[j] + zc[j];
-        } else if (__builtin_expect(zh != 0ull, 0)) {
-          asm volatile("s_nop 0");
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (!(j & 1)) front_zero(F, zj == pb + (uint32_t)(j >> 1));
-            front_mix_lp(F, K, y[j], zc[j], zs[j], oi[j], oq[j]);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; j++) front_mix_lp(F, K, y[j], zc[j], zs[j], oi[j], oq[j]);
-        }
-        const float u0i = oi[0] + oi[1], u0q = oq[0] + oq[1], u1i = oi[2] + oi[3], u1q = oq[2] + oq[3];
-        float am0 = u0i, am1 = u1i, p0 = u0q, p1 = u1q;
-        if (!FSK_ABL(1)) {
-          p0 = atan2_amp_fma(u0q, u0i, am0, K.tiny, K.sgn);
-          p1 = atan2_amp_fma(u1q, u1i, am1, K.tiny, K.sgn);
-        }
-        slot[cc * 64u + lane] = y4;
-        slot[(2u + cc) * 64u + lane] = (v4f){u0i, u0q, u1i, u1q};
-        slot[(4u + cc) * 64u + lane] = (v4f){p0, am0, p1, am1};
-      }
-      lds_post(&ctr[0], hidx + 1u);                           // for the back wave
-      lds_post(&ctr[3], hidx + 1u);                           // the y slot is free again
-    }
-    FSK_STAMP_END(1)
-    fin[lane] = (v4f){F.ix1, F.ix2, F.iy, F.iv};
-    fin[64u + lane] = (v4f){F.qx1, F.qx2, F.qy, F.qv};
-    lds_post(&ctr[0], nh + 1u);
-  } else {
-    // ---------------------------------------------------------------------------------------------- back
-    BackLane B;
-    BackK K;
-    back_load<UNI>(B, K, P, S, C, stream, out_counts, eod_counts, append);
-    const FastMem &M = C.M;
-    const uint32_t fld = C.fld, row4 = C.row4;
-    for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
-    BackU X;
-    X.k = 0; X.kv = 0; X.free0 = free0; X.zmail = zmail; X.cmail = nullptr;
-    X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) ? kDirectPairs : 0u;
-    X.zlive = __builtin_amdgcn_ballot_w64((B.dph < kHandPairs) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
-    asm volatile("" : "+v"(X.kv));
-    X.phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
-    const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
-    const uint32_t amp_quad_bytes = P.n_streams * 16u;
-    X.amp_soff = amp_soff_of(amp_pos0, amp_quad_bytes);
-    const uint32_t amp_wrap = (P.amp_cap >> 2) * amp_quad_bytes;
-    const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
-    uint32_t produced = 0, slot_i = 0;
-    FSK_STAMP_BEGIN
-    for (uint32_t t = 0; t < nh; t++) {
-      if (produced <= t) {
-        FSK_STAMP_W0
-        while (produced <= t) {
-          produced = lds_peek(&ctr[0]);
-          if (produced <= t) __builtin_amdgcn_s_sleep(1);
-        }
-        FSK_STAMP_W1
-      }
-      const v4f *slot = ring + slot_i * kSlotV4;
-      slot_i = slot_i + 1u == kPipeSlots ? 0u : slot_i + 1u;
-#pragma unroll
-      for (uint32_t c = 0; c < 2; c++) {
-        const v4f u4 = slot[(2u + c) * 64u + lane];
-        const v4f pa = slot[(4u + c) * 64u + lane];
-        const uint32_t ph0 = X.phase, ph1 = (X.phase + 1 == P.d) ? 0u : X.phase + 1;
-        const uint32_t r0 = poly[ph0 * 64u + lane];
-        const uint32_t r1 = poly[ph1 * 64u + lane];
-        const float *yp = reinterpret_cast<const float *>(&slot[c * 64u + lane]);
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          X.k++;
-          X.kv += 1u;
-          X.phase = h ? ph1 : ph0;
-          if (!FSK_ABL(2))
-            back_pair<UNI, true>(B, K, P, S, M, &poly[X.phase * 64u + lane], lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X, h ? u4.z : u4.x,
-                                 h ? u4.w : u4.y, yp + 2 * h, h ? r1 : r0, inc, h ? pa.z : pa.x, h ? pa.w : pa.y);
-          amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
-        }
-        X.phase = (ph1 + 1 == P.d) ? 0u : ph1 + 1;
-      }
-      lds_post(&ctr[1], t + 1u);
-    }
-    FSK_STAMP_END(2)
-    while (produced <= nh) {
-      produced = lds_peek(&ctr[0]);
-      if (produced <= nh) __builtin_amdgcn_s_sleep(1);
-    }
-    FrontLane F;
-    {
-      const v4f fi = fin[lane], fq = fin[64u + lane];
-      F.ix1 = fi.x; F.ix2 = fi.y; F.iy = fi.z; F.iv = fi.w;
-      F.qx1 = fq.x; F.qx2 = fq.y; F.qy = fq.z; F.qv = fq.w;
-      F.g = F.bx1 = F.bx2 = F.by1 = F.by2 = 0.f;
-    }
-    for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
-    pipe_store<UNI>(F, false, B, P, C, stream, out_counts, n, X.k, X.k % P.cadence, X.phase, amp_pos_of(X.amp_soff, amp_quad_bytes), inc, free0);
-  }
-}
-
-// ================================================================================================================
 // One wave per 64-stream group: the same two halves, pair by pair through registers.
 // LDS: stage [4][65] v4f | zt [2][8] v4f | poly [d][64] u32 | zmail [64] u32
 // ================================================================================================================
@@ -879,7 +574,6 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
 size_t demod_pipe_lds_bytes(const DemodParams &P) {
   return sizeof(float4) * (4 * kSlotStride + kPipeSlots * kSlotV4 + 2 * 64 + 2 * 8) + sizeof(uint32_t) * (64u * P.d + 4u + 64u);
 }
-size_t demod_pipe3_lds_bytes(const DemodParams &P) { return demod_pipe_lds_bytes(P) + sizeof(float4) * kPipeSlots * 2 * 64; }
 size_t demod_fused_lds_bytes(const DemodParams &P) { return sizeof(float4) * (4 * kSlotStride + 2 * 8) + sizeof(uint32_t) * 64u * (P.d + 1u); }
 
 hipError_t set_pipe_lds_limit(size_t pipe_bytes) {
@@ -890,12 +584,6 @@ hipError_t set_pipe_lds_limit(size_t pipe_bytes) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_bytes);
   FSK_ATTR(false, false) FSK_ATTR(false, true) FSK_ATTR(true, false) FSK_ATTR(true, true)
 #undef FSK_ATTR
-#define FSK_ATTR3(WBV, UNIV)                                                                                     \
-  if (e == hipSuccess && pipe_bytes + sizeof(float4) * kPipeSlots * 2 * 64 <= 160 * 1024)                        \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_pipe3_kernel<WBV, UNIV>),                      \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pipe_bytes + sizeof(float4) * kPipeSlots * 2 * 64));
-  FSK_ATTR3(false, false) FSK_ATTR3(false, true) FSK_ATTR3(true, false) FSK_ATTR3(true, true)
-#undef FSK_ATTR3
   return e;
 }
 
@@ -922,22 +610,6 @@ hipError_t launch_demod_pipe(bool writeback, bool append, const DemodParams &P, 
   if (writeback) { if (uni) FSK_LAUNCH_PIPE(true, true); else FSK_LAUNCH_PIPE(true, false); }
   else { if (uni) FSK_LAUNCH_PIPE(false, true); else FSK_LAUNCH_PIPE(false, false); }
 #undef FSK_LAUNCH_PIPE
-  return hipGetLastError();
-}
-
-hipError_t launch_demod_pipe3(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
-                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
-                              uint32_t *eod_counts, hipStream_t stream) {
-  const uint32_t blocks = (P.n_streams + 63u) / 64u;
-  const size_t lds = demod_pipe3_lds_bytes(P);
-  set_ablate();
-#define FSK_LAUNCH_PIPE3(WBV, UNIV)                                                                          \
-  hipLaunchKernelGGL((demod_pipe3_kernel<WBV, UNIV>), dim3(blocks), dim3(192), lds, stream, P, S, samples, n, pitch, \
-                     append ? 1 : 0, out, out_pitch, out_counts, eod_counts)
-  const bool uni = P.uni_cfg != 0;
-  if (writeback) { if (uni) FSK_LAUNCH_PIPE3(true, true); else FSK_LAUNCH_PIPE3(true, false); }
-  else { if (uni) FSK_LAUNCH_PIPE3(false, true); else FSK_LAUNCH_PIPE3(false, false); }
-#undef FSK_LAUNCH_PIPE3
   return hipGetLastError();
 }
 

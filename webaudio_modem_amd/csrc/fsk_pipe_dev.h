@@ -737,7 +737,10 @@ __device__ inline void lds_peek4_begin(const uint32_t *ctr, v4u32 &c) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(c) : "v"((uint32_t)(uintptr_t)ctr) : "memory");
 }
 __device__ inline uint32_t lds_peek4_get(v4u32 &c, int i) {
-  asm volatile("" : "+v"(c));
+  // (the wait is this helper's own: every caller has an lds_post -- which waits -- between begin and get, so it is
+  // already satisfied and costs nothing; it makes the dependency structural instead of a property of the callers,
+  // ADVICE r03.  tools/check_isa.py still proves from the ISA that nothing touches the registers before a wait.)
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c));
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)(i == 0 ? c.x : i == 1 ? c.y : i == 2 ? c.z : c.w));
 }
 __device__ inline void lds_post(uint32_t *p, uint32_t v) {

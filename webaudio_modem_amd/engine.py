@@ -95,14 +95,21 @@ def pinned_empty(shape, dtype=np.float32):
 _PINNED_OWNERS = {}
 
 
+# Called with (n_streams, precision) by every new FSKEngine; returns a dict of fskhip_set_option() names -> values to apply on
+# top of the `options` argument, or None.  The package sets nothing here and reads no environment variable; the test suite
+# (tests/conftest.py) and the measurement tools (tools/envopts.py) install a hook that maps their FSKHIP_* variables.
+option_hook = None
+
+
 class FSKEngine:
     """S FSKCore instances on one GPU.
 
     configs: one FSKConfig dict (shared) or a list of S dicts that differ only in
     markFrequency / spaceFrequency / preFilterBandwidth (BASELINE config #4).
+    options: tuning / test switches by name (include/fskhip.h, fskhip_set_option); none changes a result.
     """
 
-    def __init__(self, n_streams, configs=None, device=0, precision=PRECISION_F32):
+    def __init__(self, n_streams, configs=None, device=0, precision=PRECISION_F32, options=None):
         L = _lib.lib()
         if isinstance(configs, (list, tuple)):
             if len(configs) != n_streams:
@@ -122,6 +129,19 @@ class FSKEngine:
         self.n_streams = n_streams
         self.device = device
         self.precision = precision
+        opts = dict(options or {})
+        if option_hook is not None:
+            opts.update(option_hook(n_streams, precision) or {})
+        try:
+            for k, v in opts.items():
+                self.set_option(k, v)
+        except Exception:
+            self.close()
+            raise
+
+    def set_option(self, name, value):
+        """fskhip_set_option (include/fskhip.h): before the first demodulate call"""
+        _lib.check(self._L.fskhip_set_option(self._h, str(name).encode(), str(value).encode()))
 
     def close(self):
         if getattr(self, "_h", None):
