@@ -266,12 +266,17 @@ int fskhip_timing_end(fskhip_engine *e, uint32_t *n_launches, double *total_ms);
  * variable.
  *   "kernel"         auto | auto-r02 | four-wave | two-wave | one-wave   which whole-tile fp32 kernel (default auto)
  *   "force_generic"  0 | 1          never a whole-tile kernel: the sample-serial kernel only
- *   "blk_y_slots"    6 .. 28, even  depth of the four-wave kernel's first ring (checked against the LDS it needs)
+ *   "blk_y_slots"    6 .. 28        depth of the four-wave kernel's first ring (checked against the LDS it needs)
  *   "blk_min_tiles"  n              calls with fewer whole tiles stay off the four-wave kernel
  *   "blk_resident"   n >= 1         treat the device as holding n workgroups at once (time-sliced launches on small batches)
  *   "slice_tiles"    n >= 1 | off   tiles per time slice of a persistent launch
  *   "host_slab"      n              samples per time slab of fskhip_demodulate_host's pipeline (0 = no pipeline) */
 int fskhip_set_option(fskhip_engine *e, const char *name, const char *value);
+
+/* Diagnostics (tools/diag_*.py): one stream's per-stream state words as the kernels carry them between launches, in
+ * fsk_params.h's RF_* / IF_* order (an implementation detail, not a contract); n_real / n_int return the field counts. */
+int fskhip_debug_state(fskhip_engine *e, uint32_t stream, double *real_out, uint32_t real_cap, uint32_t *int_out,
+                       uint32_t int_cap, uint32_t *n_real, uint32_t *n_int);
 
 /* The shader clock the device holds under load (measurement aid, no reference counterpart): begin launches a one-wave
  * kernel on a stream of its own that stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around spin_ms of

@@ -99,6 +99,8 @@ _SYMBOLS = [
     ("fskhip_memcpy_d2h", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("fskhip_synchronize", C.c_int, [_P]),
     ("fskhip_set_option", C.c_int, [_P, C.c_char_p, C.c_char_p]),
+    ("fskhip_debug_state", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32,
+                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("fskhip_clock_probe_begin", C.c_int, [_P, C.c_double]),
     ("fskhip_clock_probe_end", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("fskhip_timing_begin", C.c_int, [_P]),

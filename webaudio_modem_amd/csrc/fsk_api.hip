@@ -684,7 +684,6 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
     if (!blk) return FSKHIP_OK;                       // (the four-wave kernel does not apply to this engine: nothing to tune)
     if (k == "blk_y_slots") {
       if ((rc = number(6, 28, &x)) != FSKHIP_OK) return rc;
-      if (x & 1u) return fail(FSKHIP_E_INVALID, "fskhip_set_option(blk_y_slots): %s is odd (a tile is two slots)", value);
       if (demod_blk_lds_bytes(e->P, (uint32_t)x) > 160 * 1024)
         return fail(FSKHIP_E_INVALID, "fskhip_set_option(blk_y_slots): %s slots need %zu B of LDS (> 160 KiB) at dsSPB %u", value,
                     demod_blk_lds_bytes(e->P, (uint32_t)x), e->P.d);
@@ -1193,6 +1192,29 @@ int fskhip_trace_read(fskhip_engine *e, double *amp, double *post, uint8_t *bit,
   if (post && m) HIP_TRY(hipMemcpy(post, e->S.trace_post, sizeof(double) * m, hipMemcpyDeviceToHost));
   if (bit && m) HIP_TRY(hipMemcpy(bit, e->S.trace_bit, m, hipMemcpyDeviceToHost));
   *n = m;
+  return FSKHIP_OK;
+}
+
+// Diagnostics: one stream's raw state words as the kernels carry them between launches (fsk_params.h: RF_* / IF_* order).
+int fskhip_debug_state(fskhip_engine *e, uint32_t stream, double *real_out, uint32_t real_cap, uint32_t *int_out, uint32_t int_cap,
+                       uint32_t *n_real, uint32_t *n_int) {
+  if (!e || stream >= e->n_streams) return fail(FSKHIP_E_INVALID, "fskhip_debug_state: bad engine / stream");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t n = e->n_streams;
+  for (uint32_t f = 0; f < (uint32_t)RF_COUNT && real_out && f < real_cap; f++) {
+    if (e->precision == FSKHIP_PRECISION_F64) {
+      HIP_TRY(hipMemcpy(&real_out[f], (const double *)e->S.rs + (size_t)f * n + stream, sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+      float v = 0;
+      HIP_TRY(hipMemcpy(&v, (const float *)e->S.rs + (size_t)f * n + stream, sizeof(float), hipMemcpyDeviceToHost));
+      real_out[f] = (double)v;
+    }
+  }
+  for (uint32_t f = 0; f < (uint32_t)IF_COUNT && int_out && f < int_cap; f++)
+    HIP_TRY(hipMemcpy(&int_out[f], e->S.is + (size_t)f * n + stream, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (n_real) *n_real = (uint32_t)RF_COUNT;
+  if (n_int) *n_int = (uint32_t)IF_COUNT;
   return FSKHIP_OK;
 }
 

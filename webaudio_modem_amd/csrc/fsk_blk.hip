@@ -821,6 +821,14 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     if (B.dph >= kHandPairs) {                                // the correction as the discriminator wave left it
       const v4f qz = fin[128u + lane];
       B.qai = qz.x; B.qaq = qz.y; B.qbi = qz.z; B.qbq = qz.w;
+      // ... unless the hand-over sample is the FIRST of the next launch (or time slice): this wave has let go of the
+      // correction (zr_dph reached kHandPairs with the launch's last sample) and the discriminator wave has not taken it
+      // yet -- it is still in the mailbox.  (Round 4: found by the idle-bank test, where streams reset every 140
+      // decimated samples; a launch boundary there used to drop the un-retired correction and an 'eod' moved.)
+      if (cmail[lane] == X.k) {
+        B.qai = __builtin_bit_cast(float, cmail[64u + lane]); B.qaq = __builtin_bit_cast(float, cmail[128u + lane]);
+        B.qbi = __builtin_bit_cast(float, cmail[192u + lane]); B.qbq = __builtin_bit_cast(float, cmail[256u + lane]);
+      }
     }
     {
       uint32_t ph = phase0;

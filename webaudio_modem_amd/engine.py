@@ -299,6 +299,13 @@ class FSKEngine:
     def synchronize(self):
         _lib.check(self._L.fskhip_synchronize(self._h))
 
+    def debug_state(self, stream):
+        """(real words, integer words) of one stream's carried state, fsk_params.h order (diagnostics)"""
+        r, i = (C.c_double * 128)(), (C.c_uint32 * 128)()
+        nr, ni = C.c_uint32(), C.c_uint32()
+        _lib.check(self._L.fskhip_debug_state(self._h, stream, r, 128, i, 128, C.byref(nr), C.byref(ni)))
+        return list(r[:nr.value]), list(i[:ni.value])
+
     def clock_probe_begin(self, spin_ms):
         """start the shader-clock probe (include/fskhip.h); launch the work to observe behind it on other streams"""
         _lib.check(self._L.fskhip_clock_probe_begin(self._h, float(spin_ms)))
