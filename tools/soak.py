@@ -119,6 +119,10 @@ def main(budget=None, seed=None, max_rounds=None):
         sigs = [np.concatenate([np.zeros(int(rng.integers(0, 300)), np.float32)] +
                                [oracles[s].modulate(p) * np.float32(rng.uniform(0.05, 1.0)) for p in payloads[s]]) for s in range(S)]
         N = max(len(x) for x in sigs) + int(rng.integers(0, 200))
+        # round 4: a third of the rounds get an idle tail behind the frames (with the noise below: a receiver that fires
+        # 'eod' and resets every samplesForEOD decimated samples, on its own schedule per stream -- the regime whose launch
+        # boundaries lost a ZIR hand-over in the four-wave kernel).  Drawn from the knob generator: the main stream stays as it was.
+        N += int(krng.choice([0, 0, 3000, 9000]))
         x = np.zeros((S, N), np.float32)
         for s in range(S):
             x[s, :len(sigs[s])] = sigs[s]
