@@ -97,6 +97,8 @@ def build_parser():
                     help="also launch the read-pattern probe kernel this many times (FETCH_SIZE calibration)")
     ap.add_argument("--pitch-pad", type=int, default=0, help="extra floats of row pitch (experiments)")
     ap.add_argument("--snr-db", type=float, default=None, help="add AWGN at this SNR (overrides the workload's)")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="skip the shader-clock probe and its extra steps (profiler passes: their kernel statistics then hold the timed launches only)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="fskhip_set_option for every engine of this run (measurements: kernel=two-wave, blk_y_slots=12, ...)")
     ap.add_argument("--dry-engine", action="store_true",
@@ -452,7 +454,7 @@ def worker(args):
     # first, a few more steps of the same work behind it.  Outside the timed region on purpose: the probe's wave takes a slot
     # that one workgroup of a full-device launch has to wait for.
     clock_ghz = None
-    if rank == 0 and not dry:
+    if rank == 0 and not dry and not args.no_clock_probe:
         try:
             per_step_ms = elapsed / args.steps * 1e3
             k_probe = max(2, min(6, int(250.0 / max(per_step_ms, 1e-3)) + 1))

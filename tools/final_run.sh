@@ -17,12 +17,12 @@ timeout 600 python bench.py --precision f64 --steps 2 --warmup 1 --no-side --cpu
 timeout 600 python bench.py --streams 8192 --no-side > $F/bench_8192.txt 2>&1
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$F/stats -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-side > $R/$F/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$F/stats -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-side --no-clock-probe > $R/$F/stats.log 2>&1
 cd $R
 C="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES"
-timeout 400 bash tools/pmc.sh r04f_insts "$C" --seconds 1 --steps 3 --warmup 2 --no-side > $F/pmc_insts.txt 2>&1
-timeout 400 bash tools/pmc.sh r04f_fetch "FETCH_SIZE" --seconds 1 --steps 3 --warmup 2 --no-side > $F/pmc_fetch.txt 2>&1
-timeout 400 bash tools/pmc.sh r04f_write "WRITE_SIZE" --seconds 1 --steps 3 --warmup 2 --no-side > $F/pmc_write.txt 2>&1
+timeout 400 bash tools/pmc.sh r04f_insts "$C" --seconds 1 --steps 3 --warmup 2 --no-side --no-clock-probe > $F/pmc_insts.txt 2>&1
+timeout 400 bash tools/pmc.sh r04f_fetch "FETCH_SIZE" --seconds 1 --steps 3 --warmup 2 --no-side --no-clock-probe > $F/pmc_fetch.txt 2>&1
+timeout 400 bash tools/pmc.sh r04f_write "WRITE_SIZE" --seconds 1 --steps 3 --warmup 2 --no-side --no-clock-probe > $F/pmc_write.txt 2>&1
 timeout 400 bash tools/pmc.sh r04f_clock "GRBM_GUI_ACTIVE" --seconds 10 --steps 3 --warmup 1 --no-side > $F/pmc_clock.txt 2>&1
 find $F/stats -name "*kernel_stats.csv" -exec cp {} $F/kernel_stats.csv \;
 rm -rf $F/stats gpurun_out/pmc_r04f_*/
