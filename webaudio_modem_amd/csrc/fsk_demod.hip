@@ -748,12 +748,9 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
     Real amp0, post0, amp1, post1;
     const bool bit0 = discriminate(L, C, fi[0] + fi[1], fq[0] + fq[1], amp0, post0);
     bool bit1 = discriminate(L, C, fi[2] + fi[3], fq[2] + fq[3], amp1, post1);
-    // one copy of the state machine, run twice (keeps the kernel and its live ranges small)
-#pragma unroll 1
-    for (int p = 0; p < 2; p++) {
-      const Real amp = p ? amp1 : amp0;
-      const Real post = p ? post1 : post0;
-      const bool bit = p ? bit1 : bit0;
+    // the state machine for both decimated samples.  fp32: one copy run twice (keeps the kernel and its live ranges small:
+    // two waves per SIMD); fp64 (one wave per SIMD, registers to spare): two copies, no per-iteration selects
+    auto fsm = [&](int p, Real amp, Real post, bool bit) {
       trace_put(amp, post, bit);
       const bool rst = downsampled_bit<Real, PolyT, FRAC>(L, P, S, poly, poly_u, R, need, ring_base, amp_base, lane,
                                                           row, valid, true, bit, amp, O, post);
@@ -765,11 +762,120 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
           bit1 = discriminate(L, C, gi2 + gi3, gq2 + gq3, amp1, post1);
         }
       }
+    };
+    if (sizeof(Real) == 8) {
+      fsm(0, amp0, post0, bit0);
+      fsm(1, amp1, post1, bit1);
+    } else {
+#pragma unroll 1
+      for (int p = 0; p < 2; p++) fsm(p, p ? amp1 : amp0, p ? post1 : post0, p ? bit1 : bit0);
     }
+  };
+
+  // fp64, round 4: SIXTEEN samples at a time with the frame state machine restated per block, as fsk_blk.hip does for the
+  // fp32 path.  One wave per SIMD pays ~35 cycles for every branch instruction and exposes every LDS round trip, and the
+  // per-sample state machine above makes two wave-uniform tests and an LDS read-modify-write per decimated sample.  Here the
+  // sixteen front ends and eight discriminators run as one branch-free block (speculatively: nothing is committed), then the
+  // eight decimated samples go through integer logic with ONE exit test for everything that is not plain bit clocking --
+  // an 'eod' (bounded from above: the run a wholly silent block would end with), a sync candidate at any of the eight
+  // samples, a bad start or stop bit, the clock running down without a frame.  A block that trips it is undone (the lane's
+  // state is a copy) and goes through block4 four times: the per-sample order with real resets, unchanged.  The block path
+  // itself restates fsk.ts:278-375 for a lane without such an event: at most ONE bit decision falls into a block (they
+  // are dsSPB >= 8 decimated samples apart -- the caller checks), at sample jd = bit_wait on entry.
+  // Returns false if the block has to be redone.
+  auto block16 = [&](const float (&x)[16], float (&wbv)[16]) -> bool {
+    const Lane<Real> L0 = L;                                   // everything this block may touch (poly / amplitude ring / output: written at the end)
+    Real amp[8], post[8];
+    uint32_t w = 0;                                             // slicer bits, sample 1 in bit 7
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      Real fi0, fq0, fi1, fq1;
+      const float y0 = pre_stage(L, C, agc_on, x[2 * j], wbv[2 * j]);
+      mix_lp<true>(L, C, y0, fi0, fq0);
+      const float y1 = pre_stage(L, C, agc_on, x[2 * j + 1], wbv[2 * j + 1]);
+      mix_lp<true>(L, C, y1, fi1, fq1);
+      const bool bit = discriminate(L, C, fi0 + fi1, fq0 + fq1, amp[j], post[j]);
+      w = (w << 1) | (bit ? 1u : 0u);
+    }
+    // ---- processDownsampledBit x 8 (fsk.ts:278-344), integer part
+    const PolyT qn = (PolyT)~P.pat_q, mask = (PolyT)P.pat_mask;
+    PolyT reg[8];
+    uint32_t ph = R.phase;
+    uint32_t matched = L.matched;
+    bool rare = false;
+    uint32_t last_loud = 0;                                     // 1..8, 0 = none in this block
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const PolyT rold = poly[ph * 64u + lane];
+      const PolyT r = (PolyT)(rold << 1) | (PolyT)((w >> (7 - j)) & 1u);   // syncSamplesBuffer.put(bit)
+      reg[j] = r;
+      matched += popc((PolyT)((r ^ qn) & mask));
+      matched -= popc((PolyT)((rold ^ qn) & mask));
+      rare |= matched >= L.thr_eff;                             // a sync candidate (whether on the search cadence: the per-sample path looks)
+      last_loud = (amp[j] < L.sil_thr) ? last_loud : (uint32_t)(j + 1);    // fsk.ts:285
+      ph = (ph + 1 == P.d) ? 0u : ph + 1;
+    }
+    // 'eod' (fsk.ts:288): no run inside the block is longer than the one a wholly silent block would end with
+    rare |= L.sil_cnt + 8u >= P.eod_min;
+    // ---- bit clock (fsk.ts:331-341): the decision, if one falls into this block, at sample jd
+    const int32_t wait0 = (int32_t)L.bit_wait;
+    const bool started = L.started != 0;
+    const bool md = started & (wait0 <= 8);
+    rare |= !started & (wait0 <= 8);                            // the clock ran down without a frame (parked again by the per-sample path)
+    rare |= started & (wait0 < 1);                              // right after a sync (decided with the first sample; at dsSPB 8 a second decision would follow)
+    const uint32_t jd = wait0 < 1 ? 1u : (uint32_t)wait0;      // (0 right after a sync: decided with the first sample)
+    const uint32_t hi = w >> ((8u - jd) & 31u);                 // bits of samples 1 .. jd
+    const uint32_t ones = L.bit_acc + popc(hi & 0xFFu);
+    const uint32_t cnt = L.bit_reload - (uint32_t)(wait0 - (int32_t)jd);   // bitAccumCount at the decision
+    const uint32_t b = (2u * ones > cnt) ? 1u : 0u;             // fsk.ts:336
+    const uint32_t pos = L.bit_pos;
+    const bool is_stop = pos == P.stop_pos;
+    rare |= md & (((pos == 0) & (b != 0)) | (is_stop & (b == 0)));   // bad start bit (fsk.ts:352-355) / bad stop bit (363-366)
+    if (__ballot(rare)) { L = L0; return false; }               // (w, amplitudes, registers: dropped; nothing was written)
+    // ---- commit
+    ph = R.phase;
+    uint32_t apos[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      poly[ph * 64u + lane] = reg[j];
+      ph = (ph + 1 == P.d) ? 0u : ph + 1;
+      apos[j] = R.amp_pos;
+      R.amp_pos = (R.amp_pos + 1 == P.amp_cap) ? 0u : R.amp_pos + 1;
+      if (TRACE) trace_put(amp[j], post[j], ((w >> (7 - j)) & 1u) != 0);
+    }
+    if (valid) {                                                // syncAmplitudeBuffer.put x 8
+#pragma unroll
+      for (int j = 0; j < 8; j++) S.amp_ring[amp_index(apos[j], row, P.n_streams)] = (float)amp[j];
+    }
+    R.phase = ph;
+    R.k += 8;
+    L.matched = matched;
+    L.gsc += 8;
+    L.cad_ctr = (L.cad_ctr + 8u) % P.cadence;
+    L.sil_cnt = last_loud ? 8u - last_loud : L.sil_cnt + 8u;
+    const uint32_t tot = popc(w & 0xFFu), nhi = popc(hi & 0xFFu);
+    const bool emit = md & is_stop;                             // (b == 1: a bad stop bit left through the exit above)
+    L.bit_acc = md ? tot - nhi : L.bit_acc + tot;
+    L.bit_reload = md ? (uint32_t)(wait0 - (int32_t)jd) + P.d : L.bit_reload;
+    L.bit_wait = md ? (uint32_t)(wait0 - 8) + P.d : (uint32_t)(wait0 - 8);
+    // data bits MSB first (see downsampled_bit)
+    L.byte_cur |= md ? (b << ((8u - pos) & 31u)) : 0u;
+    L.bit_pos = md ? (is_stop ? 0u : pos + 1u) : pos;
+    if (__ballot(emit)) {
+      if (emit) {                                               // fsk.ts:367-368
+        if (valid && O.out_cnt < O.out_pitch) O.out_row[O.out_cnt] = (uint8_t)L.byte_cur;
+        O.out_cnt++;
+        L.byte_cur = 0;
+      }
+    }
+    return true;
   };
 
   // (fp64: the four-sample block runs the NCO as a rotation, which needs omega < 2 pi in every lane -- any real configuration)
   const bool fast = UNI && (__builtin_amdgcn_readfirstlane((int)L.ds_cnt) == 0) && nco_rot_ok(C);
+  // the sixteen-sample block: fp64 only (registers: one wave per SIMD), at most one bit decision per eight decimated samples, none
+  // of the opt-in estimates (they hook the per-sample state machine)
+  const bool fast16 = fast && sizeof(Real) == 8 && P.d >= 8 && P.cadence > 0 && !P.quality;
   bool cur_fast = n > 0 && tile_is_fast(0);
   if (cur_fast) load_tile_fast(0);
   for (size_t t0 = 0; t0 < n; t0 += kTile) {
@@ -792,6 +898,29 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
       float xv[4] = {v4.x, v4.y, v4.z, v4.w};
       float wb[4];
       const uint32_t lim = tile_len - 4u * c < 4u ? tile_len - 4u * c : 4u;
+      if (sizeof(Real) == 8 && !FRAC && fast16 && (c & 3u) == 0u && 4u * c + 16u <= tile_len) {
+        float x16[16], wb16[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float4 u4 = stage[(c + q) * kSlotStride + lane];
+          x16[4 * q] = u4.x; x16[4 * q + 1] = u4.y; x16[4 * q + 2] = u4.z; x16[4 * q + 3] = u4.w;
+        }
+        if (!block16(x16, wb16)) {                               // something rare in these sixteen samples: the per-sample order
+#pragma unroll 1
+          for (int q = 0; q < 4; q++) {
+            float xq[4] = {x16[4 * q], x16[4 * q + 1], x16[4 * q + 2], x16[4 * q + 3]}, wq[4];
+            block4(xq, wq);
+            wb16[4 * q] = wq[0]; wb16[4 * q + 1] = wq[1]; wb16[4 * q + 2] = wq[2]; wb16[4 * q + 3] = wq[3];
+          }
+        }
+        if (writeback && valid) {
+          float *dst = samples + (size_t)row * pitch + t0 + 4u * c;
+#pragma unroll
+          for (int k = 0; k < 16; k++) dst[k] = wb16[k];
+        }
+        c += 3;
+        continue;
+      }
       if (fast && lim == 4u) {
         block4(xv, wb);
       } else {
