@@ -776,26 +776,37 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         // something rare in the tile at t: sample by sample from its entry state (the round-2 path, unchanged)
         if (X.zlive != 0u) { FSK_STAMP_COUNT(1) } else { FSK_STAMP_COUNT(3) }
         blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
+        // (round 4: a half tile's inputs -- ring entries, pre-filter outputs, polyphase registers, the NCO phasors wave 0 left
+        // in LDS -- are read up front and its four decimated samples run unrolled on registers: the per-sample order and
+        // arithmetic are back_pair's as before, but the wave no longer waits out four LDS round trips and two loop branches
+        // per decimated sample, nor re-evaluates the phasors of the direct instance with v_cos / v_sin)
+        const v4f *ztile = zt + ((t >> 1) & ZTM) * 8u;
 #pragma unroll 1
         for (uint32_t hh = 0; hh < 2; hh++) {
           const v4f *slot = ring + slot_i * kBlkSlotV4;
           const v4f *yslot = yring + (t % NY) * 2u * 64u;    // (wave 0 wrote half tile t of this launch there)
-#pragma unroll 1
-          for (uint32_t c = 0; c < 2; c++) {
-            const v4f u4 = slot[c * 64u + lane];             // pair sums where this wave's own span covers the lane, else (phase, magnitude)
-            const v4f pa = u4;
-            const float *yp = reinterpret_cast<const float *>(&yslot[c * 64u + lane]);
+          const v4f ua = slot[lane], ub = slot[64u + lane];  // pair sums where this wave's own span covers the lane, else (phase, magnitude)
+          const v4f ya = yslot[lane], yb = yslot[64u + lane];
+          const uint4 rq = *reinterpret_cast<const uint4 *>(prow + pidx);
+          v4f zq[4] = {};
+          if (UNI) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-              X.k++;
-              X.kv += 1u;
-              uint32_t *ps = prow + pidx + 2u * c + (uint32_t)h;
-              const uint32_t r_old = *ps;
-              back_pair<UNI, true, false, true, COH>(B, K, P, S, M, ps, lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
-                                                h ? u4.z : u4.x, h ? u4.w : u4.y, yp + 2 * h, r_old, inc, h ? pa.z : pa.x, h ? pa.w : pa.y);
-              amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
-            }
+            for (int i = 0; i < 4; i++) zq[i] = ztile[4u * hh + (uint32_t)i];
           }
+          const float uv[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
+          const float yv[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+          const uint32_t ro[4] = {rq.x, rq.y, rq.z, rq.w};
+          uint32_t rn[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            X.k++;
+            X.kv += 1u;
+            const float zph[4] = {zq[j].x, zq[j].y, zq[j].z, zq[j].w};
+            back_pair<UNI, true, false, true, COH>(B, K, P, S, M, &rn[j], lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
+                                              uv[2 * j], uv[2 * j + 1], &yv[2 * j], ro[j], inc, uv[2 * j], uv[2 * j + 1], UNI ? zph : nullptr);
+            amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
+          }
+          *reinterpret_cast<uint4 *>(prow + pidx) = make_uint4(rn[0], rn[1], rn[2], rn[3]);
           slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
           pidx = pidx + 4u >= P.d ? 0u : pidx + 4u;
           t++;

@@ -301,7 +301,7 @@ __device__ inline float disc_post(BackLane &B, const BackK &K, float ph, float &
 // wave's own).  One function for the per-sample path (back_pair) and the block path's own-span blocks (fsk_blk.hip).
 template <bool UNI, bool HAND>
 __device__ inline void zir_step(BackLane &B, const BackK &K, BackU &X, float Ui, float Uq, const float *ypair, uint64_t inc,
-                                uint32_t lane, float &ph, float &amp) {
+                                uint32_t lane, float &ph, float &amp, const float *zph = nullptr) {
   const uint32_t dph0 = B.dph;
   float wi = Ui - B.qai, wq = Uq - B.qaq;
   {
@@ -316,10 +316,14 @@ __device__ inline void zir_step(BackLane &B, const BackK &K, BackU &X, float Ui,
     if (B.dph < kDirectPairs) {
       const float y0 = ypair[0], y1 = ypair[1];
       const uint32_t n0 = 2u * (X.k - 1u);
-      // the front's phasors of these two samples, evaluated the same way (nco_phasor)
+      // the front's phasors of these two samples: evaluated the same way (nco_phasor), or -- zph, fsk_blk.hip with a uniform
+      // configuration -- the very values wave 0 evaluated for the tile and left in LDS (c0, s0, c1, s1)
       float c0, s0, c1, s1;
-      nco_phasor(X.free0 + inc * (uint64_t)n0, c0, s0);
-      nco_phasor(X.free0 + inc * (uint64_t)(n0 + 1u), c1, s1);
+      if (zph) { c0 = zph[0]; s0 = zph[1]; c1 = zph[2]; s1 = zph[3]; }
+      else {
+        nco_phasor(X.free0 + inc * (uint64_t)n0, c0, s0);
+        nco_phasor(X.free0 + inc * (uint64_t)(n0 + 1u), c1, s1);
+      }
       float di, dq;
       {
         const float mi = y0 * c0, mq = y0 * s0;
@@ -412,7 +416,8 @@ template <bool UNI, bool PA = false, bool TRC = false, bool HAND = false, int CO
 __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams &P, const DemodState &S, const FastMem &M,
                                  uint32_t *pslot, uint32_t lane, __amdgpu_buffer_rsrc_t amp_rsrc, uint8_t *out,
                                  uint32_t out_pitch, uint32_t *eod_counts, BackU &X, float Ui, float Uq,
-                                 const float *ypair, uint32_t r_old, uint64_t inc, float ph_u = 0.f, float amp_u = 0.f) {
+                                 const float *ypair, uint32_t r_old, uint64_t inc, float ph_u = 0.f, float amp_u = 0.f,
+                                 const float *zph = nullptr) {
   // ---- ZIR correction: w = U - q, q advances by its two-term recurrence.  Skipped (exactly: U - 0 = U) while no lane of
   // the wave carries a correction.
   // Phase and magnitude are evaluated on U first (by the front wave already, in the two-wave kernel) and stand unless the
@@ -421,7 +426,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   float amp, ph;
   if (PA) { ph = ph_u; amp = amp_u; }
   else ph = atan2_amp_fma(Uq, Ui, amp, K.tiny, K.sgn);
-  if (__builtin_expect(X.zlive != 0u, 0)) zir_step<UNI, HAND>(B, K, X, Ui, Uq, ypair, inc, lane, ph, amp);
+  if (__builtin_expect(X.zlive != 0u, 0)) zir_step<UNI, HAND>(B, K, X, Ui, Uq, ypair, inc, lane, ph, amp, zph);
   // ---- discriminator (fsk.ts:251-264)
   const float f = disc_post(B, K, ph, amp);
   // slicer (fsk.ts:264): f > 0  <=>  sign bit of 0 - f  (f = +-0 gives +0, i.e. bit 0)
