@@ -14,19 +14,31 @@ import webaudio_modem_amd._lib as L
 if sys.argv[3] != "-": L.LIB_PATH = sys.argv[3]
 import torch
 import webaudio_modem_amd as wm
-import os as _os, sys as _sys
-_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
-import envopts  # noqa: E402  (FSKHIP_* variables -> fskhip_set_option)
+sys.path.insert(0, os.path.join(%r, "tools"))
+import envopts  # (FSKHIP_* variables -> fskhip_set_option)
 envopts.install()
 S, N = int(sys.argv[1]), int(sys.argv[2])
 wl = os.environ.get("VAR_WORKLOAD", "c3")
-cfg = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200) if wl == "c3" else dict(baudRate=300, markFrequency=1070, spaceFrequency=1270)
+cfg = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200) if wl in ("c3", "idle") else dict(baudRate=300, markFrequency=1070, spaceFrequency=1270)
 eng = wm.FSKEngine(S, cfg, precision=wm.PRECISION_F32)
 st = torch.cuda.current_stream().cuda_stream
 x = torch.empty((S, N), dtype=torch.float32, device="cuda")
 op = eng.max_bytes(N)
 out = torch.zeros((S, op), dtype=torch.uint8, device="cuda"); cnt = torch.empty(S, dtype=torch.int32, device="cuda")
-eng.synth_device(x.data_ptr(), N, N, 100 if wl == "c3" else 32, 0xF5C0DE, 400, 0.1, 1.0, st)
+if wl == "idle":      # bench.py --workload idle: one frame per stream, then a floor 30 dB under it
+    import math, numpy as np
+    fl = eng.modulated_length(100)
+    n0 = min(N, (400 + fl + 31) // 32 * 32)
+    x.zero_()
+    eng.synth_device(x.data_ptr(), n0, N, 100, 0xF5C0DE, 400, 0.1, 1.0, st)
+    torch.cuda.synchronize()
+    ends = np.array([eng.synth_stream_params(0xF5C0DE, s_, 400, 0.1, 1.0)[0] for s_ in range(S)], np.int64) + fl
+    c0 = int(ends.min())
+    if c0 < n0:
+        x[:, c0:n0] *= (torch.arange(c0, n0, device="cuda")[None, :] < torch.as_tensor(ends, device="cuda")[:, None])
+    eng.add_awgn_device(x.data_ptr(), N, N, 30.0 - 10.0 * math.log10(N / float(fl)), 0xF5C0DE ^ 0xA36, st)
+else:
+    eng.synth_device(x.data_ptr(), N, N, 100 if wl == "c3" else 32, 0xF5C0DE, 400, 0.1, 1.0, st)
 torch.cuda.synchronize()
 def step():
     eng.demodulate_device(x.data_ptr(), N, N, out.data_ptr(), op, cnt.data_ptr(), 0, 0, st)
@@ -91,7 +103,7 @@ if os.environ.get("VAR_STAMPS"):
         print("STAMP wave %%d: loop %%.0f cycles/sample (min %%.0f max %%.0f over groups), waiting %%.1f %%%% of it (min %%.1f max %%.1f), busy %%.0f cycles/sample"
               %% (w, tot.mean() / N, tot.min() / N, tot.max() / N, 100 * (wait / tot).mean(), 100 * (wait / tot).min(), 100 * (wait / tot).max(),
                  (tot - wait).mean() / N))
-''' % ROOT
+''' % (ROOT, ROOT)
 S, N = int(sys.argv[1]), int(sys.argv[2])
 for spec in sys.argv[3:]:
     head, _, envs = spec.partition(":")
