@@ -777,3 +777,51 @@ def test_config1_polarity_bank_never_syncs():
     assert sum(len(r) for r in rows) <= S // 8       # (nothing, but for the odd false sync the reference has too)
     gen.device_free(d_x)
     gen.close()
+
+
+@pytest.mark.parametrize("kernel", ["four-wave", "two-wave", "one-wave"])
+def test_agc_write_back_on_dword_aligned_tiles(kernel):
+    """Round 4: after an odd-length call the whole tiles of the next start 4, 8 or 12 bytes off a 16-byte boundary (the head only
+    realigns the decimator and the amplitude ring).  With FSKHIP_DEMOD_WRITEBACK_AGC the kernels also STORE 16 bytes per lane
+    there (fsk.ts:55: the input buffer holds the AGC-scaled samples afterwards): the written-back buffer and the bytes must be
+    those of one call, for every whole-tile kernel."""
+    import webaudio_modem_amd as wm
+    S, N = 200, 20011
+    P = N + 1
+    gen = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    d_src = gen.device_malloc(S * P * 4)
+    gen.synth_device(d_src, N, P, 10, SEED + 31, 300, 0.2, 1.0)
+    gen.synchronize()
+    x = np.zeros((S, P), np.float32)
+    gen.d2h(x, d_src)
+    results = []
+    for schedule in ([N], [1, 4096, 3, 8000, 2, 17, 7892]):
+        eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options={"kernel": kernel})
+        d_x = eng.device_malloc(S * P * 4)
+        eng.h2d(d_x, x)
+        op = eng.max_bytes(N)
+        d_out = eng.device_malloc(S * op); d_cnt = eng.device_malloc(S * 4); d_eod = eng.device_malloc(S * 4)
+        out = np.empty((S, op), np.uint8); cnt = np.empty(S, np.uint32)
+        got = [bytearray() for _ in range(S)]
+        off = 0
+        kernels = set()
+        for n in schedule:
+            eng.demodulate_device(d_x + off * 4, n, P, d_out, op, d_cnt, d_eod, flags=wm.DEMOD_WRITEBACK_AGC)
+            eng.synchronize()
+            kernels.add(eng.last_kernel().split("<")[0])
+            eng.d2h(cnt, d_cnt); eng.d2h(out, d_out)
+            for s in range(S):
+                got[s] += out[s, :cnt[s]].tobytes()
+            off += n
+        assert off == N
+        y = np.empty((S, P), np.float32)
+        eng.d2h(y, d_x)
+        results.append(([bytes(g) for g in got], y[:, :N].copy(), kernels))
+        eng.close()
+    assert results[0][0] == results[1][0]
+    assert np.array_equal(results[0][1], results[1][1])
+    assert not np.array_equal(results[0][1], x[:, :N])                    # (something was written back)
+    want = {"four-wave": "demod_blk_kernel", "two-wave": "demod_pipe_kernel", "one-wave": "demod_fused_kernel"}[kernel]
+    assert any(want in k for k in results[1][2]), results[1][2]
+    gen.device_free(d_src)
+    gen.close()

@@ -5,7 +5,8 @@ out=gpurun_out/experiment; mkdir -p $out
 run() {  # $1 = FSKHIP_SPLIT, $2 = library or -
   FSKHIP_SPLIT=$1 timeout 300 python -c "
 import sys, runpy
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
+import envopts; envopts.install()     # FSKHIP_* -> fskhip_set_option
 import webaudio_modem_amd._lib as L
 if '$2' != '-': L.LIB_PATH = '$2'
 sys.argv = ['bench_next.py', '--quanta', '100']

@@ -3,7 +3,7 @@
 Everything that computes goes through libfskhip.so (hand-written HIP for gfx950, C ABI in
 include/fskhip.h).  There is no CPU path in this package.
 """
-from ._lib import FskHipError, PRECISION_F32, PRECISION_F64, LIB_PATH  # noqa: F401
+from ._lib import FskHipError, PRECISION_F32, PRECISION_F64, DEMOD_WRITEBACK_AGC, LIB_PATH  # noqa: F401
 from .engine import FSKEngine, DEFAULT_FSK_CONFIG, make_config, pinned_empty  # noqa: F401
 from .fsk_core import FSKCore, Event, EventEmitter  # noqa: F401
 from .filters import FilterDesign, FilterFactory, FIRFilter, FIRFilterBatch  # noqa: F401
