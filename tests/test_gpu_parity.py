@@ -493,6 +493,35 @@ def test_errors_are_loud():
     eng.close()
 
 
+def test_options_are_validated_and_none_changes_a_result():
+    """fskhip_set_option (round 4: it replaces the library's environment switches): unknown names, values that are not
+    numbers or out of range, a y-ring depth whose LDS does not fit, and options set after the engine has demodulated are
+    FSKHIP_E_INVALID; valid ones choose a kernel / launch shape and leave the bytes alone."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    bell = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
+    for bad in ({"kernel": "fastest"}, {"blk_y_slots": "abc"}, {"blk_y_slots": 4}, {"blk_y_slots": 30}, {"blk_resident": 0},
+                {"slice_tiles": "-3"}, {"force_generic": 2}, {"no_such_option": 1}, {"host_slab": "1e9"}):
+        with pytest.raises(wm.FskHipError) as ei:
+            wm.FSKEngine(64, bell, options=bad)
+        assert ei.value.code == -1, bad
+    o = po.OracleCore(bell)
+    sig = np.concatenate([np.zeros(37, np.float32), o.modulate(b"options"), np.zeros(900, np.float32)])
+    want, _ = po.OracleCore(bell).demodulate(sig)
+    x = np.tile(sig, (130, 1))
+    seen = set()
+    for opts in ({}, {"kernel": "two-wave"}, {"kernel": "one-wave"}, {"kernel": "four-wave", "blk_y_slots": 7},
+                 {"blk_resident": 2, "slice_tiles": 3}, {"force_generic": 1}, {"kernel": "auto-r02"}, {"slice_tiles": "off"}):
+        eng = wm.FSKEngine(130, bell, options=opts)
+        out, eod = eng.demodulate_data(x.copy())
+        assert all(b == want for b in out), opts
+        seen.add(eng.last_kernel().split("<")[0])
+        with pytest.raises(wm.FskHipError):      # too late now
+            eng.set_option("kernel", "auto")
+        eng.close()
+    assert {"fsk::demod_blk_kernel", "fsk::demod_pipe_kernel", "fsk::demod_fused_kernel"} <= seen, seen
+
+
 @pytest.mark.parametrize("pname,prec,tol", PRECISIONS)
 def test_single_stream_reset_at_odd_decimator_phase(pname, prec, tol):
     """Regression (tools/soak.py): a one-stream engine reset while its /2 decimator is mid-pair.  The device restarts the
