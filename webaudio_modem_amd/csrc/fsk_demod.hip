@@ -582,6 +582,103 @@ __device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// eight decimated samples through the frame state machine at once (fp64 kernels, round 4)
+// ------------------------------------------------------------------------------------------------
+// processDownsampledBit x 8 + processByte (fsk.ts:278-375) for a block whose amplitudes, post-filter outputs and slicer
+// bits (w: sample 1 in bit 7) are there already -- the integer part, with ONE exit test for everything that is not plain
+// bit clocking: a possible 'eod' (bounded from above: the run a wholly silent block would end with), a sync candidate at
+// any of the eight samples, a bad start or stop bit, a clock that ran down without a frame or stands at zero right after a
+// sync.  Returns false, with nothing touched, if the block has to be redone in the per-sample order; otherwise commits:
+// polyphase registers, amplitude ring, counters, at most ONE bit decision (they are dsSPB >= 8 decimated samples apart:
+// the caller checks) at sample jd = bit_wait on entry, a completed byte.
+template <typename Real, typename PolyT, bool TRACE>
+__device__ inline bool block_fsm8(Lane<Real> &L, const DemodParams &P, const DemodState &S, PolyT *poly, RingPos &R, OutCtx &O,
+                                  uint32_t lane, uint32_t row, uint32_t stream, bool valid, const Real (&amp)[8], const Real (&post)[8],
+                                  uint32_t w) {
+  const PolyT qn = (PolyT)~P.pat_q, mask = (PolyT)P.pat_mask;
+  PolyT reg[8];
+  uint32_t ph = R.phase;
+  uint32_t matched = L.matched;
+  bool rare = false;
+  uint32_t last_loud = 0;                                     // 1..8, 0 = none in this block
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const PolyT rold = poly[ph * 64u + lane];
+    const PolyT r = (PolyT)(rold << 1) | (PolyT)((w >> (7 - j)) & 1u);   // syncSamplesBuffer.put(bit)
+    reg[j] = r;
+    matched += popc((PolyT)((r ^ qn) & mask));
+    matched -= popc((PolyT)((rold ^ qn) & mask));
+    rare |= matched >= L.thr_eff;                             // a sync candidate (whether on the search cadence: the per-sample path looks)
+    last_loud = (amp[j] < L.sil_thr) ? last_loud : (uint32_t)(j + 1);    // fsk.ts:285
+    ph = (ph + 1 == P.d) ? 0u : ph + 1;
+  }
+  // 'eod' (fsk.ts:288): no run inside the block is longer than the one a wholly silent block would end with
+  rare |= L.sil_cnt + 8u >= P.eod_min;
+  // ---- bit clock (fsk.ts:331-341): the decision, if one falls into this block, at sample jd
+  const int32_t wait0 = (int32_t)L.bit_wait;
+  const bool started = L.started != 0;
+  const bool md = started & (wait0 <= 8);
+  rare |= !started & (wait0 <= 8);                            // the clock ran down without a frame (parked again by the per-sample path)
+  rare |= started & (wait0 < 1);                              // right after a sync (decided with the first sample; at dsSPB 8 a second decision would follow)
+  const uint32_t jd = wait0 < 1 ? 1u : (uint32_t)wait0;
+  const uint32_t hi = w >> ((8u - jd) & 31u);                 // bits of samples 1 .. jd
+  const uint32_t ones = L.bit_acc + popc(hi & 0xFFu);
+  const uint32_t cnt = L.bit_reload - (uint32_t)(wait0 - (int32_t)jd);   // bitAccumCount at the decision
+  const uint32_t b = (2u * ones > cnt) ? 1u : 0u;             // fsk.ts:336
+  const uint32_t pos = L.bit_pos;
+  const bool is_stop = pos == P.stop_pos;
+  rare |= md & (((pos == 0) & (b != 0)) | (is_stop & (b == 0)));   // bad start bit (fsk.ts:352-355) / bad stop bit (363-366)
+  if (__ballot(rare)) return false;
+  // ---- commit
+  ph = R.phase;
+  uint32_t apos[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    poly[ph * 64u + lane] = reg[j];
+    ph = (ph + 1 == P.d) ? 0u : ph + 1;
+    apos[j] = R.amp_pos;
+    R.amp_pos = (R.amp_pos + 1 == P.amp_cap) ? 0u : R.amp_pos + 1;
+    if (TRACE) {
+      if (stream == S.trace_stream) {
+        const uint32_t kk = *S.trace_n;
+        if (kk < S.trace_cap) {
+          S.trace_amp[kk] = (double)amp[j];
+          S.trace_post[kk] = (double)post[j];
+          S.trace_bit[kk] = (uint8_t)((w >> (7 - j)) & 1u);
+        }
+        *S.trace_n = kk + 1;
+      }
+    }
+  }
+  if (valid) {                                                // syncAmplitudeBuffer.put x 8
+#pragma unroll
+    for (int j = 0; j < 8; j++) S.amp_ring[amp_index(apos[j], row, P.n_streams)] = (float)amp[j];
+  }
+  R.phase = ph;
+  R.k += 8;
+  L.matched = matched;
+  L.gsc += 8;
+  L.cad_ctr = (L.cad_ctr + 8u) % P.cadence;
+  L.sil_cnt = last_loud ? 8u - last_loud : L.sil_cnt + 8u;
+  const uint32_t tot = popc(w & 0xFFu), nhi = popc(hi & 0xFFu);
+  const bool emit = md & is_stop;                             // (b == 1: a bad stop bit left through the exit above)
+  L.bit_acc = md ? tot - nhi : L.bit_acc + tot;
+  L.bit_reload = md ? (uint32_t)(wait0 - (int32_t)jd) + P.d : L.bit_reload;
+  L.bit_wait = md ? (uint32_t)(wait0 - 8) + P.d : (uint32_t)(wait0 - 8);
+  // data bits MSB first (see downsampled_bit)
+  L.byte_cur |= md ? (b << ((8u - pos) & 31u)) : 0u;
+  L.bit_pos = md ? (is_stop ? 0u : pos + 1u) : pos;
+  if (__ballot(emit)) {
+    if (emit) {                                               // fsk.ts:367-368
+      if (valid && O.out_cnt < O.out_pitch) O.out_row[O.out_cnt] = (uint8_t)L.byte_cur;
+      O.out_cnt++;
+      L.byte_cur = 0;
+    }
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------------------
 // fp32 kernels are capped at 128 VGPRs (4 waves/SIMD): the chain is VALU-bound and one wave per
@@ -797,77 +894,7 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
       const bool bit = discriminate(L, C, fi0 + fi1, fq0 + fq1, amp[j], post[j]);
       w = (w << 1) | (bit ? 1u : 0u);
     }
-    // ---- processDownsampledBit x 8 (fsk.ts:278-344), integer part
-    const PolyT qn = (PolyT)~P.pat_q, mask = (PolyT)P.pat_mask;
-    PolyT reg[8];
-    uint32_t ph = R.phase;
-    uint32_t matched = L.matched;
-    bool rare = false;
-    uint32_t last_loud = 0;                                     // 1..8, 0 = none in this block
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const PolyT rold = poly[ph * 64u + lane];
-      const PolyT r = (PolyT)(rold << 1) | (PolyT)((w >> (7 - j)) & 1u);   // syncSamplesBuffer.put(bit)
-      reg[j] = r;
-      matched += popc((PolyT)((r ^ qn) & mask));
-      matched -= popc((PolyT)((rold ^ qn) & mask));
-      rare |= matched >= L.thr_eff;                             // a sync candidate (whether on the search cadence: the per-sample path looks)
-      last_loud = (amp[j] < L.sil_thr) ? last_loud : (uint32_t)(j + 1);    // fsk.ts:285
-      ph = (ph + 1 == P.d) ? 0u : ph + 1;
-    }
-    // 'eod' (fsk.ts:288): no run inside the block is longer than the one a wholly silent block would end with
-    rare |= L.sil_cnt + 8u >= P.eod_min;
-    // ---- bit clock (fsk.ts:331-341): the decision, if one falls into this block, at sample jd
-    const int32_t wait0 = (int32_t)L.bit_wait;
-    const bool started = L.started != 0;
-    const bool md = started & (wait0 <= 8);
-    rare |= !started & (wait0 <= 8);                            // the clock ran down without a frame (parked again by the per-sample path)
-    rare |= started & (wait0 < 1);                              // right after a sync (decided with the first sample; at dsSPB 8 a second decision would follow)
-    const uint32_t jd = wait0 < 1 ? 1u : (uint32_t)wait0;      // (0 right after a sync: decided with the first sample)
-    const uint32_t hi = w >> ((8u - jd) & 31u);                 // bits of samples 1 .. jd
-    const uint32_t ones = L.bit_acc + popc(hi & 0xFFu);
-    const uint32_t cnt = L.bit_reload - (uint32_t)(wait0 - (int32_t)jd);   // bitAccumCount at the decision
-    const uint32_t b = (2u * ones > cnt) ? 1u : 0u;             // fsk.ts:336
-    const uint32_t pos = L.bit_pos;
-    const bool is_stop = pos == P.stop_pos;
-    rare |= md & (((pos == 0) & (b != 0)) | (is_stop & (b == 0)));   // bad start bit (fsk.ts:352-355) / bad stop bit (363-366)
-    if (__ballot(rare)) { L = L0; return false; }               // (w, amplitudes, registers: dropped; nothing was written)
-    // ---- commit
-    ph = R.phase;
-    uint32_t apos[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      poly[ph * 64u + lane] = reg[j];
-      ph = (ph + 1 == P.d) ? 0u : ph + 1;
-      apos[j] = R.amp_pos;
-      R.amp_pos = (R.amp_pos + 1 == P.amp_cap) ? 0u : R.amp_pos + 1;
-      if (TRACE) trace_put(amp[j], post[j], ((w >> (7 - j)) & 1u) != 0);
-    }
-    if (valid) {                                                // syncAmplitudeBuffer.put x 8
-#pragma unroll
-      for (int j = 0; j < 8; j++) S.amp_ring[amp_index(apos[j], row, P.n_streams)] = (float)amp[j];
-    }
-    R.phase = ph;
-    R.k += 8;
-    L.matched = matched;
-    L.gsc += 8;
-    L.cad_ctr = (L.cad_ctr + 8u) % P.cadence;
-    L.sil_cnt = last_loud ? 8u - last_loud : L.sil_cnt + 8u;
-    const uint32_t tot = popc(w & 0xFFu), nhi = popc(hi & 0xFFu);
-    const bool emit = md & is_stop;                             // (b == 1: a bad stop bit left through the exit above)
-    L.bit_acc = md ? tot - nhi : L.bit_acc + tot;
-    L.bit_reload = md ? (uint32_t)(wait0 - (int32_t)jd) + P.d : L.bit_reload;
-    L.bit_wait = md ? (uint32_t)(wait0 - 8) + P.d : (uint32_t)(wait0 - 8);
-    // data bits MSB first (see downsampled_bit)
-    L.byte_cur |= md ? (b << ((8u - pos) & 31u)) : 0u;
-    L.bit_pos = md ? (is_stop ? 0u : pos + 1u) : pos;
-    if (__ballot(emit)) {
-      if (emit) {                                               // fsk.ts:367-368
-        if (valid && O.out_cnt < O.out_pitch) O.out_row[O.out_cnt] = (uint8_t)L.byte_cur;
-        O.out_cnt++;
-        L.byte_cur = 0;
-      }
-    }
+    if (!block_fsm8<Real, PolyT, TRACE>(L, P, S, poly, R, O, lane, row, stream, valid, amp, post, w)) { L = L0; return false; }
     return true;
   };
 
@@ -961,6 +988,8 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
     if (eod_counts) eod_counts[stream] = O.eod_cnt;
   }
 }
+
+
 
 
 // (The round-1 whole-tile kernels that lived here -- demod_fast_kernel, demod_split_kernel -- are replaced by
