@@ -22,8 +22,9 @@ extern "C" {
 #endif
 
 /* 2: fskhip_max_bytes, fskhip_last_kernel.  3: fskhip_carry_over, fskhip_host_alloc / _free, the pipelined
- * fskhip_demodulate_host, fskhip_enable_signal_quality / fskhip_get_signal_quality (additions only). */
-#define FSKHIP_ABI_VERSION 3
+ * fskhip_demodulate_host, fskhip_enable_signal_quality / fskhip_get_signal_quality.  4: fskhip_set_option (the library reads no
+ * environment variable any more), fskhip_clock_probe_begin / _end, fskhip_debug_state (additions only). */
+#define FSKHIP_ABI_VERSION 4
 #define FSKHIP_MAX_PATTERN_BYTES 16
 
 enum {
