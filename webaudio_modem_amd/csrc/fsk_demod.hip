@@ -260,22 +260,38 @@ __device__ inline double biquad64(double b0, double b1, double b2, double a1, do
 // AGC + pre-filter for one input sample (fsk.ts:52-76, 202): returns the pre-filter's Float32Array
 // output.  Neither stage is touched by resetState().
 __device__ inline float pre_stage(Lane<double> &L, const Consts<double> &C, bool agc_on, float xin, float &agc_out) {
-  float xs = xin;
-  if (agc_on) {
-    xs = (float)((double)xin * L.agc_gain);  // samples[i] *= gain : Float32Array store
-    // (one division and two selects instead of the reference's two branches: the same operations on the same values in
-    // every case -- level == 0 divides to +inf and is discarded -- and a divergent branch costs a lone wave ~35 cycles)
-    double level = fabs((double)xs);
-    const double target = 0.5 / level;
+  // Always executed: with the AGC disabled the host sets both rates to 0 and the gain stays 1, which makes this block an
+  // exact no-op (x * 1; g + (t - g) * 0 = g; clamp(1) = 1) -- and one division and two selects instead of the reference's
+  // two branches: the same operations on the same values in every case.  The divisor is made 1 where the level is 0 (the
+  // result is discarded there) so that the compiler has no unused quotient to jump around: a branch instruction, taken or
+  // not, costs a lone wave ~35 cycles, and this chain is the kernel's longest per sample.
+  (void)agc_on;
+  const float xs = (float)((double)xin * L.agc_gain);  // samples[i] *= gain : Float32Array store
+  {
+    const double level = fabs((double)xs);
+    const double target = 0.5 / (level > 0.0 ? level : 1.0);
     const double rate = level > 0.5 ? C.agc_att : C.agc_rel;
-    const double gn = L.agc_gain + (target - L.agc_gain) * rate;
+    double gn = L.agc_gain + (target - L.agc_gain) * rate;
+    asm volatile("" : "+v"(gn));   // (evaluated for every lane: without this hipcc sinks the whole update into an `if (level > 0)`)
     L.agc_gain = level > 0.0 ? gn : L.agc_gain;
-    double g = L.agc_gain < 10.0 ? L.agc_gain : 10.0;
+    const double g = L.agc_gain < 10.0 ? L.agc_gain : 10.0;
     L.agc_gain = g > 0.1 ? g : 0.1;
   }
   agc_out = xs;
   // preFilter.processBuffer: f64 state, f32 result (filters.ts:81-87)
-  return (float)biquad64(C.bp_b0, 0.0, -C.bp_b0, C.bp_a1, C.bp_a2, L.bp_x1, L.bp_x2, L.bp_y1, L.bp_y2, (double)xs);
+  // (b1 = 0: the reference's `out += 0 * x[n-1]` adds +-0 to a sum that is never -0 -- it starts from +0 -- and leaves it
+  // unchanged for every finite x[n-1], so the term's multiply and add are not issued)
+  {
+    const double x = (double)xs;
+    double out = 0.0;
+    out += C.bp_b0 * x;
+    out += -C.bp_b0 * L.bp_x2;
+    out -= C.bp_a1 * L.bp_y1;
+    out -= C.bp_a2 * L.bp_y2;
+    L.bp_x2 = L.bp_x1; L.bp_x1 = x;
+    L.bp_y2 = L.bp_y1; L.bp_y1 = out;
+    return (float)out;
+  }
 }
 
 // NCO mix + I/Q low-pass for one pre-filtered sample (fsk.ts:228-238): the part resetState() zeroes.
@@ -324,8 +340,13 @@ __device__ inline bool discriminate(Lane<double> &L, const Consts<double> &C, do
   double phase = atan2_lean(avg_q, avg_i);     // (fsk_f64math.h: within 1.5 ulp of Math.atan2)
   amp = sqrt(avg_i * avg_i + avg_q * avg_q);
   double dphi = phase - L.last_phase;
-  if (dphi > PI) dphi -= 2.0 * PI;
-  else if (dphi < -PI) dphi += 2.0 * PI;
+  {
+    // fsk.ts:255-257 as two selects (both candidates evaluated for every lane: the `if / else if` compiled to two exec-masked
+    // branches per decimated sample, ~35 cycles each for a lone wave)
+    double dm = dphi - 2.0 * PI, dp = dphi + 2.0 * PI;
+    asm volatile("" : "+v"(dm), "+v"(dp));
+    dphi = dphi > PI ? dm : (dphi < -PI ? dp : dphi);
+  }
   L.last_phase = phase;
   double f = biquad64(C.lp_b0, C.lp_b1, C.lp_b2, C.lp_a1, C.lp_a2, L.po_x1, L.po_x2, L.po_y1, L.po_y2, dphi);
   post = f;

@@ -64,7 +64,7 @@ FSK_HD double atan2_lean(double y, double x) {
   const double hi = k2 ? 7.85398163397448278999e-01 : (k1 ? 4.63647609000806093515e-01 : 0.0);   // atan(1), atan(1/2)
   const double lo = k2 ? 3.06161699786838301793e-17 : (k1 ? 2.26987774529616870924e-17 : 0.0);
   const double num = f64_fma(-cc, mx, mn), den = f64_fma(cc, mn, mx);
-  const double t = den > 0.0 ? num / den : 0.0;
+  const double t = num / (den > 0.0 ? den : 1.0);                              // ((0, 0): 0 / 1; no unused quotient for the compiler to jump around)
   const double z = t * t, w = z * z;
   double s1 = 1.62858201153657823623e-02;                                      // aT[10]
   s1 = f64_fma(s1, w, 4.97687799461593236017e-02);                             // aT[8]
