@@ -150,6 +150,9 @@ class DryEngine:
     def last_kernel(self):
         return "dry_engine"
 
+    def blk_lanes(self):
+        return 0
+
     def demodulate_device(self, *a, **k):
         dt = 1e-3 * (1 + self.n_streams / 65536.0)
         time.sleep(dt)
@@ -410,6 +413,7 @@ def worker(args):
     step()
     sync()
     kernel_name = eng.last_kernel()
+    lanes_main = eng.blk_lanes() if "demod_blk_kernel" in kernel_name else None
     first_counts = np.zeros(S, np.int64) if dry else counts.cpu().numpy().astype(np.int64)
     cpu_obj = None
     parity_ok = True
@@ -485,10 +489,11 @@ def worker(args):
         sync()
         el2, nl2, kms2 = measure(sync, dist, e2, step2, args.steps, args.warmup, dev)
         k2 = e2.last_kernel()
+        lanes2 = e2.blk_lanes()
         e2.close()
         v2 = float(args.streams) * N * args.steps / el2 / 1e6
         strong = {"total_streams": args.streams, "streams_per_gpu": S2, "Msamples_per_s": round(v2, 1),
-                  "ms_per_step": round(el2 / args.steps * 1e3, 3), "kernel": k2,
+                  "ms_per_step": round(el2 / args.steps * 1e3, 3), "kernel": k2, "streams_per_workgroup": lanes2,
                   "avg_kernel_ms_rank0": round(kms2 / max(1, nl2), 4),
                   "frac_of_hbm_peak_per_gpu": round(v2 / world * 4 / 1e3 / HBM_PEAK_GBS, 4),
                   "note": "BASELINE config #3 as written: %d streams in total, contiguous blocks of %d per GPU, no collective" % (args.streams, S2)}
@@ -521,7 +526,8 @@ def worker(args):
                 nl, ms = timed_steps(sync, es, step_s, k_side)
                 r = s_share * N * nl / (ms / 1e3) / 1e6
                 shares[str(s_share)] = {"Msamples_per_s": round(r, 1), "frac_of_hbm_peak": round(r * 4 / 1e3 / HBM_PEAK_GBS, 4),
-                                        "kernel": es.last_kernel(), "x8_GPUs_Msamples_per_s": round(8 * r, 1)}
+                                        "kernel": es.last_kernel(), "streams_per_workgroup": es.blk_lanes(),
+                                        "x8_GPUs_Msamples_per_s": round(8 * r, 1)}
                 es.close()
             side["per_gpu_share"] = shares
         except Exception as ex:
@@ -676,7 +682,8 @@ def worker(args):
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": kernel_name, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
+                "kernel": kernel_name, "streams_per_workgroup": lanes_main,
+                "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                 "binding_bound": binding,
                 "valu_issue": issue,

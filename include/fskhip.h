@@ -23,8 +23,9 @@ extern "C" {
 
 /* 2: fskhip_max_bytes, fskhip_last_kernel.  3: fskhip_carry_over, fskhip_host_alloc / _free, the pipelined
  * fskhip_demodulate_host, fskhip_enable_signal_quality / fskhip_get_signal_quality.  4: fskhip_set_option (the library reads no
- * environment variable any more), fskhip_clock_probe_begin / _end, fskhip_debug_state (additions only). */
-#define FSKHIP_ABI_VERSION 4
+ * environment variable any more), fskhip_clock_probe_begin / _end, fskhip_debug_state.  5: fskhip_blk_lanes, option
+ * "blk_lanes" (additions only). */
+#define FSKHIP_ABI_VERSION 5
 #define FSKHIP_MAX_PATTERN_BYTES 16
 
 enum {
@@ -124,6 +125,13 @@ size_t fskhip_max_bytes(const fskhip_engine *e, size_t n_per_stream);
  * ("" before the first call): measurement harnesses report it instead of guessing the dispatch.
  */
 const char *fskhip_last_kernel(const fskhip_engine *e);
+
+/*
+ * Streams per workgroup of the four-wave whole-tile kernel for this engine: 64 (a whole wave), or 32 / 16 / 8 when the
+ * batch is too small to give every compute unit a 64-stream group ("narrow groups": more, narrower workgroups use the
+ * idle CUs; results are identical).  0 if that kernel does not apply to the engine.  For measurement harnesses.
+ */
+uint32_t fskhip_blk_lanes(const fskhip_engine *e);
 
 /*
  * demodulateData(samples) (fsk.ts:190-222) for every stream: `samples` is [n_streams][pitch]
@@ -269,6 +277,7 @@ int fskhip_timing_end(fskhip_engine *e, uint32_t *n_launches, double *total_ms);
  *   "force_generic"  0 | 1          never a whole-tile kernel: the sample-serial kernel only
  *   "blk_y_slots"    6 .. 28        depth of the four-wave kernel's first ring (checked against the LDS it needs)
  *   "blk_min_tiles"  n              calls with fewer whole tiles stay off the four-wave kernel
+ *   "blk_lanes"      auto|64|32|16|8 streams per workgroup of the four-wave kernel (auto: the widest that gives every workgroup its own CU)
  *   "blk_resident"   n >= 1         treat the device as holding n workgroups at once (time-sliced launches on small batches)
  *   "slice_tiles"    n >= 1 | off   tiles per time slice of a persistent launch
  *   "host_slab"      n              samples per time slab of fskhip_demodulate_host's pipeline (0 = no pipeline) */

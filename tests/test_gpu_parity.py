@@ -38,7 +38,9 @@ def _check_status(st, ref, tol, agc_gain):
 # default wherever dsSPB is a multiple of 4), and the round-2 kernels with one and two waves per group, which stay for the
 # other configurations and as the per-sample reference of the block path.  FSKHIP_SPLIT (mapped to fskhip_set_option's
 # "kernel" by tests/conftest.py) pins one of them at engine creation.
-GOLDEN_VARIANTS = PRECISIONS + [("f32-one-wave", 0, 1e-5), ("f32-four-wave", 0, 1e-5)]
+# (round 4: the four-wave kernel cuts batches that would leave CUs idle into groups of 32 / 16 / 8 streams -- a one-stream
+# golden runs on an 8-lane group by default; "f32-four-wave-64" pins whole-wave groups)
+GOLDEN_VARIANTS = PRECISIONS + [("f32-one-wave", 0, 1e-5), ("f32-four-wave", 0, 1e-5), ("f32-four-wave-64", 0, 1e-5)]
 
 
 @pytest.mark.parametrize("pname,prec,tol", GOLDEN_VARIANTS)
@@ -49,6 +51,9 @@ def test_demod_matches_reference_golden(name, pname, prec, tol, monkeypatch):
         monkeypatch.setenv("FSKHIP_SPLIT", "0")
     elif pname == "f32-four-wave":
         monkeypatch.setenv("FSKHIP_SPLIT", "4")
+    elif pname == "f32-four-wave-64":
+        monkeypatch.setenv("FSKHIP_SPLIT", "4")
+        monkeypatch.setenv("FSKHIP_BLK_LANES", "64")
     elif pname == "f32":
         monkeypatch.setenv("FSKHIP_SPLIT", "1")
     g = golden()
@@ -493,6 +498,73 @@ def test_errors_are_loud():
     eng.close()
 
 
+def test_narrow_groups_leave_every_stream_exactly_as_whole_waves_do():
+    """Round 4: batches too small to give every CU a 64-stream group run the four-wave kernel in groups of 32 / 16 / 8
+    streams (fskhip_blk_lanes; fsk_blk.hip, launch_demod_blk).  The state arrays are indexed by stream and the polyphase
+    registers blocked by 64, so group width must not show anywhere: 150 streams (a ragged last group at every width) with
+    their own payloads, lead-ins, levels and noise, a ragged call schedule with AGC write-back, per width -- bytes and eod
+    against the oracle, and the written-back samples, every status field and the internal state words identical to the
+    whole-wave run's."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    cfg = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
+    S = 150
+    rng = np.random.RandomState(404)
+    sigs = []
+    for s in range(S):
+        o = po.OracleCore(cfg)
+        parts = [np.zeros(rng.randint(0, 300), np.float32)]
+        for _ in range(3):
+            parts += [o.modulate(bytes(rng.randint(0, 256, rng.randint(1, 9)).astype(np.uint8))) * np.float32(rng.uniform(0.1, 1.0)),
+                      np.zeros(rng.randint(50, 2500), np.float32)]
+        sigs.append(np.concatenate(parts))
+    N = max(len(x) for x in sigs)
+    x = np.zeros((S, N), np.float32)
+    for s in range(S):
+        x[s, :len(sigs[s])] = sigs[s]
+    x[S // 2:] += (rng.standard_normal((S - S // 2, N)) * 0.02).astype(np.float32)
+    want, want_eod = [], []
+    for s in range(S):
+        b, e = po.OracleCore(cfg).demodulate(x[s])
+        want.append(b)
+        want_eod.append(e)
+    assert sum(len(w) for w in want) > 2 * S
+    ref = None
+    for lanes in (64, 32, 16, 8, "auto"):
+        eng = wm.FSKEngine(S, cfg, precision=wm.PRECISION_F32, options={"kernel": "four-wave", "blk_lanes": lanes})
+        assert eng.blk_lanes() == (8 if lanes == "auto" else lanes)       # (150 streams: 19 groups of 8 on any device)
+        got = [b""] * S
+        eods = np.zeros(S, np.int64)
+        wb = []
+        off = 0
+        for n in [4096, 16, 1000, 48, 3, 8000, 129, 10 ** 9]:
+            n = min(n, N - off)
+            if n <= 0:
+                break
+            buf = np.ascontiguousarray(x[:, off:off + n])
+            out, eod = eng.demodulate_data(buf, writeback_agc=True)
+            wb.append(buf)
+            for s in range(S):
+                got[s] += out[s]
+            eods += eod
+            off += n
+        assert "demod_blk_kernel" in eng.last_kernel() or "tail" in eng.last_kernel(), eng.last_kernel()
+        state = [eng.debug_state(s) for s in (0, 7, 8, 63, 64, 71, 127, 128, 143, 144, 149)]
+        status = [eng.get_status(s) for s in range(S)]
+        eng.close()
+        for s in range(S):
+            assert got[s] == want[s], (lanes, s)
+            assert int(eods[s]) == want_eod[s], (lanes, s)
+        if ref is None:
+            ref = (wb, state, status)
+        else:
+            for a, b in zip(ref[0], wb):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), lanes
+            for a, b in zip(ref[1], state):
+                assert np.array_equal(np.asarray(a[0]).view(np.uint64), np.asarray(b[0]).view(np.uint64)) and np.array_equal(a[1], b[1]), lanes
+            assert ref[2] == status, lanes
+
+
 def test_options_are_validated_and_none_changes_a_result():
     """fskhip_set_option (round 4: it replaces the library's environment switches): unknown names, values that are not
     numbers or out of range, a y-ring depth whose LDS does not fit, and options set after the engine has demodulated are
@@ -501,6 +573,7 @@ def test_options_are_validated_and_none_changes_a_result():
     from oracle import pyoracle as po
     bell = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
     for bad in ({"kernel": "fastest"}, {"blk_y_slots": "abc"}, {"blk_y_slots": 4}, {"blk_y_slots": 30}, {"blk_resident": 0},
+                {"blk_lanes": 12}, {"blk_lanes": 4}, {"blk_lanes": "wide"},
                 {"slice_tiles": "-3"}, {"force_generic": 2}, {"no_such_option": 1}, {"host_slab": "1e9"}):
         with pytest.raises(wm.FskHipError) as ei:
             wm.FSKEngine(64, bell, options=bad)
@@ -511,7 +584,8 @@ def test_options_are_validated_and_none_changes_a_result():
     x = np.tile(sig, (130, 1))
     seen = set()
     for opts in ({}, {"kernel": "two-wave"}, {"kernel": "one-wave"}, {"kernel": "four-wave", "blk_y_slots": 7},
-                 {"blk_resident": 2, "slice_tiles": 3}, {"force_generic": 1}, {"kernel": "auto-r02"}, {"slice_tiles": "off"}):
+                 {"blk_resident": 2, "slice_tiles": 3}, {"force_generic": 1}, {"kernel": "auto-r02"}, {"slice_tiles": "off"},
+                 {"blk_lanes": 16}, {"blk_lanes": "auto"}, {"blk_lanes": 64, "blk_y_slots": 9}):
         eng = wm.FSKEngine(130, bell, options=opts)
         out, eod = eng.demodulate_data(x.copy())
         assert all(b == want for b in out), opts

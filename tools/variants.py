@@ -50,7 +50,7 @@ eng.timing_begin()
 for _ in range(int(os.environ.get("VAR_STEPS", "4"))): step()   # back to back, state carried on (as bench.py does)
 torch.cuda.synchronize()
 n, ms = eng.timing_end()
-print("RESULT", ms / n, eng.last_kernel().replace(" ", ""), nb, "%%08x" %% crc)
+print("RESULT", ms / n, eng.last_kernel().replace(" ", "") + ("/%%d" %% eng.blk_lanes() if "blk" in eng.last_kernel() else ""), nb, "%%08x" %% crc)
 if os.environ.get("VAR_STAMPS"):
     import ctypes, numpy as np
     f = L.lib().fskdbg_read_stamps_blk if "blk" in eng.last_kernel() else L.lib().fskdbg_read_stamps

@@ -67,6 +67,7 @@ _SYMBOLS = [
     ("fskhip_n_streams", C.c_uint32, [_P]),
     ("fskhip_max_bytes", C.c_size_t, [_P, C.c_size_t]),
     ("fskhip_last_kernel", C.c_char_p, [_P]),
+    ("fskhip_blk_lanes", C.c_uint32, [_P]),
     ("fskhip_demodulate_host", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P, _P, C.c_uint32]),
     ("fskhip_demodulate_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P, _P, C.c_uint32, _P]),
     ("fskhip_modulated_length", C.c_size_t, [_P, C.c_size_t]),

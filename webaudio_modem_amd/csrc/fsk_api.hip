@@ -41,7 +41,8 @@ hipError_t set_blk_lds_limit(const DemodParams &P);
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, uint32_t y_slots,
-                             bool *sliced_out);
+                             uint32_t lanes, bool *sliced_out);
+uint32_t demod_blk_lanes(uint32_t n_streams, int device);
 void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t *y_slots, uint32_t *resident_wgs);
 uint32_t demod_blk_slices(const DemodParams &P, const DemodState &S, size_t n, uint32_t resident_wgs, uint32_t slice_tiles,
                           uint32_t *slice_tiles_out);
@@ -190,6 +191,7 @@ struct fskhip_engine {
   uint32_t blk_resident = 0;     // workgroups of demod_blk_kernel the device holds at once; larger batches run it persistent, in time slices
   uint32_t blk_min_tiles = 0;    // calls with fewer whole tiles than this stay with round 2's kernels
   uint32_t blk_y_slots = 6;      // half tiles in the block kernel's y ring: as deep as the LDS allows at this batch size
+  uint32_t blk_lanes = 64;       // streams per workgroup of demod_blk_kernel: 64, or 32 / 16 / 8 for batches that leave CUs idle (fsk_blk.hip)
   uint32_t blk_slice_tiles = 0;  // tiles per time slice (0 = the kernel file's default, 0xFFFFFFFF = never slice)
   size_t host_slab = (size_t)-1; // samples per time slab of fskhip_demodulate_host's pipeline ((size_t)-1 = ~96 MB, 0 = no pipeline)
   bool last_sliced = false;
@@ -607,7 +609,8 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     CREATE_TRY(set_pipe_lds_limit(demod_pipe_lds_bytes(P)));
   if (e->demod_ok && precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(P)) {
     CREATE_TRY(set_blk_lds_limit(P));
-    demod_blk_plan(P, e->n_blocks, device, &e->blk_y_slots, &e->blk_resident);
+    e->blk_lanes = demod_blk_lanes(n_streams, device);
+    demod_blk_plan(P, (n_streams + e->blk_lanes - 1u) / e->blk_lanes, device, &e->blk_y_slots, &e->blk_resident);
     if (e->blk_resident && e->n_blocks > e->blk_resident) {
       CREATE_TRY(hipMalloc((void **)&e->S.blk_q, sizeof(uint32_t) * demod_blk_queue_words(e->n_blocks)));
     }
@@ -680,7 +683,7 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
     return FSKHIP_OK;
   }
   const bool blk = e->demod_ok && e->precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(e->P);
-  if (k == "blk_y_slots" || k == "blk_min_tiles" || k == "blk_resident" || k == "slice_tiles") {
+  if (k == "blk_y_slots" || k == "blk_min_tiles" || k == "blk_resident" || k == "slice_tiles" || k == "blk_lanes") {
     if (!blk) return FSKHIP_OK;                       // (the four-wave kernel does not apply to this engine: nothing to tune)
     if (k == "blk_y_slots") {
       if ((rc = number(6, 28, &x)) != FSKHIP_OK) return rc;
@@ -688,12 +691,18 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
         return fail(FSKHIP_E_INVALID, "fskhip_set_option(blk_y_slots): %s slots need %zu B of LDS (> 160 KiB) at dsSPB %u", value,
                     demod_blk_lds_bytes(e->P, (uint32_t)x), e->P.d);
       e->blk_y_slots = (uint32_t)x;
+    } else if (k == "blk_lanes") {                    // streams per workgroup: auto (what the device's CU count suggests) | 64 | 32 | 16 | 8
+      if (v == "auto") { e->blk_lanes = demod_blk_lanes(e->n_streams, e->device); return FSKHIP_OK; }
+      if ((rc = number(8, 64, &x)) != FSKHIP_OK) return rc;
+      if (x & (x - 1u)) return fail(FSKHIP_E_INVALID, "fskhip_set_option(blk_lanes): %s is none of auto, 64, 32, 16, 8", value);
+      e->blk_lanes = (uint32_t)x;
     } else if (k == "blk_min_tiles") {
       if ((rc = number(0, 1u << 30, &x)) != FSKHIP_OK) return rc;
       e->blk_min_tiles = (uint32_t)x;
     } else if (k == "blk_resident") {                 // tests: a "device" that holds only this many workgroups at once
       if ((rc = number(1, 1u << 20, &x)) != FSKHIP_OK) return rc;
       e->blk_resident = (uint32_t)x;
+      e->blk_lanes = 64u;                             // (a device that small has no idle CUs to spread narrow groups over)
       if (e->n_blocks > e->blk_resident && !e->S.blk_q) {
         HIP_TRY(hipSetDevice(e->device));
         HIP_TRY(hipMalloc((void **)&e->S.blk_q, sizeof(uint32_t) * demod_blk_queue_words(e->n_blocks)));
@@ -711,6 +720,9 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
 uint32_t fskhip_n_streams(const fskhip_engine *e) { return e ? e->n_streams : 0; }
 size_t fskhip_max_bytes(const fskhip_engine *e, size_t n_per_stream) { return e ? engine_max_bytes(e, n_per_stream) : 0; }
 const char *fskhip_last_kernel(const fskhip_engine *e) { return e ? e->last_kernel : ""; }
+uint32_t fskhip_blk_lanes(const fskhip_engine *e) {
+  return (e && e->demod_ok && e->precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(e->P)) ? e->blk_lanes : 0u;
+}
 
 // append_first: this launch sequence continues a call that has produced output already (a time slab of
 // fskhip_demodulate_host's pipeline); count_call: it is (the first part of) a demodulateData() call of its own
@@ -780,12 +792,12 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
         // pipeline's fill and drain, and round 2's kernels are faster there (262 144 streams x 128-sample quanta, the
         // FSKProcessor loop: 0.195 against 0.247 ms; x 4 096 samples 384 against 370 Gsamples/s:
         // profiles/r03_short_calls.txt)
-        const bool blk_fits = !(e->blk_resident && e->n_blocks > e->blk_resident) ||
+        const bool blk_fits = e->blk_lanes != 64u || !(e->blk_resident && e->n_blocks > e->blk_resident) ||
                               demod_blk_slices(e->P, e->S, n_fast, e->blk_resident, e->blk_slice_tiles, nullptr) >= 2u;
         if (e->use_blk && demod_blk_applicable(e->P) && blk_lds <= 160 * 1024 && (quad_aligned || e->split_forced) &&
             ((blk_fits && n_fast / 16 >= e->blk_min_tiles) || e->split_forced)) {
           HIP_TRY(launch_demod_blk(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
-                                   e->blk_resident, e->blk_slice_tiles, e->blk_y_slots, &e->last_sliced));
+                                   e->blk_resident, e->blk_slice_tiles, e->blk_y_slots, e->blk_lanes, &e->last_sliced));
           static const char *const names[8] = {
               "fsk::demod_blk_kernel<false, false, false>", "fsk::demod_blk_kernel<false, false, true>",
               "fsk::demod_blk_kernel<false, true, false>", "fsk::demod_blk_kernel<false, true, true>",

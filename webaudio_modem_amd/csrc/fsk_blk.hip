@@ -245,6 +245,8 @@ struct BlkSched {
   uint32_t total;                // groups * nslices
   uint32_t y_slots;              // half tiles in the y ring (>= kBlkSlots): how far wave 0 may run ahead of the back wave
   uint32_t zt_tiles;             // tiles of NCO phasors in flight (wave 0 -> wave 1), a power of two > y_slots / 2
+  uint32_t lanes;                // streams per workgroup: 64, or 32 / 16 / 8 for batches that would otherwise leave CUs idle
+                                 // (round 4, "narrow groups": see launch_demod_blk)
 };
 
 template <bool WB, bool UNI, bool SL>
@@ -340,8 +342,13 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
                             : n_call / kFastTile;
   const size_t n = n_tiles * kFastTile;
   const int append = (SL && slice != 0u) ? 1 : append_call;
-  uint32_t *gpoly = (uint32_t *)S.poly + (size_t)grp * P.d * 64u;
-  const uint32_t stream = grp * 64u + lane;
+  // Narrow groups: the workgroup owns streams [grp * W, grp * W + W); lanes W .. 63 are handled exactly as the lanes
+  // beyond the batch's last stream always were (parked on zeros, every store dropped: pipe_ctx, back_load).  The state
+  // arrays, the amplitude ring and the outputs are indexed by stream; only the polyphase registers are blocked by 64.
+  const uint32_t W = Z.lanes, s0 = grp * W;
+  const bool mine = lane < W;
+  uint32_t *gpoly = (uint32_t *)S.poly + (size_t)(s0 >> 6) * P.d * 64u + (s0 & 63u);
+  const uint32_t stream = mine ? s0 + lane : 0xFFFFFFFFu;
   const PipeCtx C = pipe_ctx(P, S, stream);
   const uint32_t nh = 2u * (uint32_t)n_tiles;               // half tiles = blocks
   const uint64_t inc = UNI ? (((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo) : S.nco_inc[C.row4 >> 2];
@@ -384,10 +391,10 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     FrontK K;
     front_load<UNI, COH>(F, K, P, S, C);
     const uint32_t sub_row = lane >> 2, chunk = lane & 3;
-    const uint32_t rows_here = P.n_streams - grp * 64u < 64u ? P.n_streams - grp * 64u : 64u;
+    const uint32_t rows_here = P.n_streams - s0 < W ? P.n_streams - s0 : W;   // (rows beyond: the range check returns zeros)
     v4i in_rsrc;
     {
-      const uint64_t base = reinterpret_cast<uint64_t>(samples + (size_t)grp * 64u * pitch);
+      const uint64_t base = reinterpret_cast<uint64_t>(samples + (size_t)s0 * pitch);
       in_rsrc.x = (int)(uint32_t)base;
       in_rsrc.y = (int)(uint32_t)(base >> 32);
       in_rsrc.z = (int)(uint32_t)(rows_here * pitch * 4u);
@@ -690,7 +697,9 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     {
       uint32_t ph = phase0;
       for (uint32_t i = 0; i < P.d; i++) {                    // rotate: LDS index 0 = the register of the first push
-        poly[lane * PS + i] = COH ? __hip_atomic_load(&gpoly[ph * 64u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gpoly[ph * 64u + lane];
+        uint32_t r = 0u;
+        if (mine) r = COH ? __hip_atomic_load(&gpoly[ph * 64u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gpoly[ph * 64u + lane];
+        poly[lane * PS + i] = r;
         ph = ph + 1u == P.d ? 0u : ph + 1u;
       }
     }
@@ -844,8 +853,10 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     {
       uint32_t ph = phase0;
       for (uint32_t i = 0; i < P.d; i++) {
-        if (COH) __hip_atomic_store(&gpoly[ph * 64u + lane], poly[lane * PS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else gpoly[ph * 64u + lane] = poly[lane * PS + i];
+        if (mine) {
+          if (COH) __hip_atomic_store(&gpoly[ph * 64u + lane], poly[lane * PS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else gpoly[ph * 64u + lane] = poly[lane * PS + i];
+        }
         ph = ph + 1u == P.d ? 0u : ph + 1u;
       }
     }
@@ -936,17 +947,33 @@ uint32_t demod_blk_slices(const DemodParams &P, const DemodState &S, size_t n, u
                          slice_tiles_out);
 }
 
+// Narrow groups (round 4).  A workgroup's pace is its slowest wave's instruction stream and does not depend on how many
+// of the 64 lanes carry a stream; a batch of fewer than 64 x (compute units) streams leaves whole CUs idle while the
+// groups it does have run at that pace (4 096 streams: 64 workgroups on 256 CUs).  Such a batch is cut into groups of
+// 32, 16 or 8 streams instead -- the widest that still gives every workgroup a CU of its own -- and the idle lanes are
+// the price of using the idle CUs.  Above 64 x CUs streams the groups are whole waves as before.
+uint32_t demod_blk_lanes(uint32_t n_streams, int device) {
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return 64u;
+  for (uint32_t w = 8u; w < 64u; w *= 2u)
+    if ((n_streams + w - 1u) / w <= (uint32_t)cus) return w;
+  return 64u;
+}
+
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, uint32_t y_slots,
-                             bool *sliced_out) {
-  const uint32_t blocks = (P.n_streams + 63u) / 64u;
+                             uint32_t lanes, bool *sliced_out) {
+  lanes = (lanes == 8u || lanes == 16u || lanes == 32u) ? lanes : 64u;
+  const uint32_t blocks = (P.n_streams + lanes - 1u) / lanes;
   y_slots = y_slots < kBlkSlots ? kBlkSlots : y_slots > kBlkYMax ? kBlkYMax : y_slots;
   const size_t lds = demod_blk_lds_bytes(P, y_slots);
   set_ablate_blk();
-  BlkSched Z = {nullptr, blocks, 1u, 0u, 0u, y_slots, blk_zt_tiles(y_slots)};
+  BlkSched Z = {nullptr, blocks, 1u, 0u, 0u, y_slots, blk_zt_tiles(y_slots), lanes};
   uint32_t st = 0;
-  const uint32_t ns = demod_blk_slices(P, S, n, resident_wgs, slice_tiles, &st);
+  // (time slices are for batches beyond one round of whole-wave groups; narrow groups are never sliced -- the queue is
+  // sized for 64-stream groups)
+  const uint32_t ns = lanes == 64u ? demod_blk_slices(P, S, n, resident_wgs, slice_tiles, &st) : 1u;
   const bool sliced = ns >= 2u;
   if (sliced) {
     Z.q = S.blk_q; Z.nslices = ns; Z.slice_tiles = st; Z.total = blocks * ns;

@@ -167,6 +167,10 @@ class FSKEngine:
         """Name of the kernel the last demodulate_device call launched for its whole tiles (fskhip_last_kernel)."""
         return (self._L.fskhip_last_kernel(self._h) or b"").decode()
 
+    def blk_lanes(self):
+        """Streams per workgroup of the four-wave kernel for this engine (fskhip_blk_lanes): 64, 32, 16, 8, or 0."""
+        return int(self._L.fskhip_blk_lanes(self._h))
+
     def demodulate_data(self, samples, writeback_agc=False, out_pitch=None):
         """samples: float32 [S, N] (host).  Returns (list of bytes per stream, eod counts ndarray).
 
