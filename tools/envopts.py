@@ -21,7 +21,7 @@ def from_env(n_streams=None, precision=None):
         o["force_generic"] = 1
     for env, name in (("FSKHIP_BLK_YSLOTS", "blk_y_slots"), ("FSKHIP_BLK_MIN_TILES", "blk_min_tiles"),
                       ("FSKHIP_BLK_RESIDENT", "blk_resident"), ("FSKHIP_SLICE_TILES", "slice_tiles"),
-                      ("FSKHIP_BLK_LANES", "blk_lanes"),
+                      ("FSKHIP_BLK_LANES", "blk_lanes"), ("FSKHIP_BLK_RESETS", "blk_resets"),
                       ("FSKHIP_HOST_SLAB", "host_slab")):
         v = os.environ.get(env)
         if v is not None and v != "":

@@ -41,7 +41,7 @@ hipError_t set_blk_lds_limit(const DemodParams &P);
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, uint32_t y_slots,
-                             uint32_t lanes, bool *sliced_out);
+                             uint32_t lanes, uint32_t medium, bool *sliced_out);
 uint32_t demod_blk_lanes(uint32_t n_streams, int device);
 void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t *y_slots, uint32_t *resident_wgs);
 uint32_t demod_blk_slices(const DemodParams &P, const DemodState &S, size_t n, uint32_t resident_wgs, uint32_t slice_tiles,
@@ -191,6 +191,7 @@ struct fskhip_engine {
   uint32_t blk_resident = 0;     // workgroups of demod_blk_kernel the device holds at once; larger batches run it persistent, in time slices
   uint32_t blk_min_tiles = 0;    // calls with fewer whole tiles than this stay with round 2's kernels
   uint32_t blk_y_slots = 6;      // half tiles in the block kernel's y ring: as deep as the LDS allows at this batch size
+  uint32_t blk_medium = 1;       // blocks that hold an 'eod' take the block path with resets (fsk_blk.hip, blk_medium); false: the per-sample path
   uint32_t blk_lanes = 64;       // streams per workgroup of demod_blk_kernel: 64, or 32 / 16 / 8 for batches that leave CUs idle (fsk_blk.hip)
   uint32_t blk_slice_tiles = 0;  // tiles per time slice (0 = the kernel file's default, 0xFFFFFFFF = never slice)
   size_t host_slab = (size_t)-1; // samples per time slab of fskhip_demodulate_host's pipeline ((size_t)-1 = ~96 MB, 0 = no pipeline)
@@ -325,7 +326,7 @@ int fskhip_destroy(fskhip_engine *e) {
   (void)hipDeviceSynchronize();
   void *bufs[] = {e->S.rs, e->S.is, e->S.poly, e->S.amp_ring, (void *)e->S.coef, (void *)e->S.nco_inc, e->d_samples,
                   e->d_samples2, e->d_out, e->d_counts, e->d_eod, e->d_lens, e->d_payloads, e->d_status, e->d_sigma,
-                  e->S.trace_amp, e->S.trace_post, e->S.trace_bit, e->S.trace_n, e->S.poly_u, e->S.cu_ctr, e->S.blk_q, e->d_clock};
+                  e->S.trace_amp, e->S.trace_post, e->S.trace_bit, e->S.trace_n, e->S.poly_u, e->S.cu_ctr, e->S.blk_q, e->S.blk_stash, e->d_clock};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (auto ev : e->ev) (void)hipEventDestroy(ev);
@@ -609,6 +610,7 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     CREATE_TRY(set_pipe_lds_limit(demod_pipe_lds_bytes(P)));
   if (e->demod_ok && precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(P)) {
     CREATE_TRY(set_blk_lds_limit(P));
+    CREATE_TRY(hipMalloc((void **)&e->S.blk_stash, sizeof(float) * 28u * (size_t)n_streams));
     e->blk_lanes = demod_blk_lanes(n_streams, device);
     demod_blk_plan(P, (n_streams + e->blk_lanes - 1u) / e->blk_lanes, device, &e->blk_y_slots, &e->blk_resident);
     if (e->blk_resident && e->n_blocks > e->blk_resident) {
@@ -670,6 +672,11 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
     else if (v == "two-wave") { e->use_blk = false; e->use_split = true; e->split_forced = true; }
     else if (v == "one-wave") { e->use_blk = false; e->use_split = false; e->split_forced = true; }
     else return fail(FSKHIP_E_INVALID, "fskhip_set_option(kernel): '%s' is none of auto, auto-r02, four-wave, two-wave, one-wave", value);
+    return FSKHIP_OK;
+  }
+  if (k == "blk_resets") {      // 1: the four-wave kernel's block path takes resets (default), 0: such blocks go sample by sample
+    if ((rc = number(0, 2, &x)) != FSKHIP_OK) return rc;   // (2, tests: run it, then restore the entry state and redo the block sample by sample)
+    e->blk_medium = (uint32_t)x;
     return FSKHIP_OK;
   }
   if (k == "force_generic") {
@@ -797,7 +804,7 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
         if (e->use_blk && demod_blk_applicable(e->P) && blk_lds <= 160 * 1024 && (quad_aligned || e->split_forced) &&
             ((blk_fits && n_fast / 16 >= e->blk_min_tiles) || e->split_forced)) {
           HIP_TRY(launch_demod_blk(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
-                                   e->blk_resident, e->blk_slice_tiles, e->blk_y_slots, e->blk_lanes, &e->last_sliced));
+                                   e->blk_resident, e->blk_slice_tiles, e->blk_y_slots, e->blk_lanes, e->blk_medium, &e->last_sliced));
           static const char *const names[8] = {
               "fsk::demod_blk_kernel<false, false, false>", "fsk::demod_blk_kernel<false, false, true>",
               "fsk::demod_blk_kernel<false, true, false>", "fsk::demod_blk_kernel<false, true, true>",

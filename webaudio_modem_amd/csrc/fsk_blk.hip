@@ -46,7 +46,7 @@
 // Batches beyond one round of resident workgroups run persistently over (group, time slice) items: BlkSched below.
 // LDS: stage [4][65] v4f (the final-state hand-over fin [3][64] over it) | yring [y_slots][2][64] v4f, y_slots = 6 .. 28 by
 //      what the batch leaves (demod_blk_plan) | xring [6][2][64] v4f | zt [8 or 16][8] v4f | poly [64][PS] u32 |
-//      counters [8] | zmail [64] u32 | cmail [6][64] u32
+//      counters [8] | zmail [64] u32 | cmail [7][64] u32
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -82,21 +82,57 @@ __host__ __device__ inline uint32_t blk_poly_stride(uint32_t d) {
   return (s & 4u) ? s : s + 4u;
 }
 
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
 struct BlkK {                    // block-level constants, VGPRs
   uint32_t stop_m1;              // 2^stop_pos - 1: sreg > stop_m1 <=> all data bits in
   uint32_t sh9;                  // stop_pos - 9: byte = (sreg >> sh9) & 0xFF
   uint32_t ff;                   // 0xFF
 };
 
-// The fast path of one block (a tile: eight decimated samples).  Works on copies (Bn, rp, bq, nq): the caller commits
-// them only if the returned flag word has its sign bit clear in every lane.  kv0 = pushes before the block.
+// Bit clock of one block (fsk.ts:335-341) and processByte (346-375), evaluated once from the block's eight slicer bits w
+// (sample 1 in bit kBlk - 1): a lane decides at most one bit per block, at sample jd = nextBitSampleIndex - k0.  Shared by
+// the fast block path and the one that takes resets.  Returns the bad start / stop bit flags (sign bit = rare), md = all
+// ones in the lanes that decide a bit in this block.
 static constexpr int kBlk = 8;                     // decimated samples per block
+__device__ inline uint32_t blk_clock(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t kv0, uint32_t w, uint32_t &bq,
+                                     uint32_t &nq, uint32_t &md_out) {
+  uint32_t jd = Bn.T - kv0;                        // 1..kBlk in this block; 0 right after a sync (nextBitSampleIndex = k)
+  jd -= neg_mask(jd - 1u);                         // 0 -> 1
+  const uint32_t md = neg_mask(jd - (uint32_t)(kBlk + 1));   // all ones <=> a decision falls into this block
+  const uint32_t hi = w >> (((uint32_t)kBlk - jd) & 31u);    // the slicer bits of samples 1..jd (garbage without a decision: masked)
+  const uint32_t nhi = (uint32_t)__builtin_popcount(hi);
+  const uint32_t ones = nhi + Bn.acc;
+  const uint32_t tot = (uint32_t)__builtin_popcount(w);
+  const uint32_t kvd = kv0 + jd;
+  const uint32_t b = sign_bit((kvd - Bn.tlast) - ones - ones);               // 2 * bitAccumulator > bitAccumCount
+  const uint32_t s0 = Bn.sreg;
+  const uint32_t s1 = s0 + s0 + b;
+  // processByte (fsk.ts:346-375) at the decision
+  const uint32_t m_start = neg_mask(s0 - 2u);                                // waiting for the start bit
+  const uint32_t m_stop = neg_mask(Q.stop_m1 - s0);                          // all data bits in: stop (or parity) position
+  const uint32_t bm = 0u - b;
+  const uint32_t good = md & m_stop & bm;                                    // a byte completes
+  Bn.acc = tot + (Bn.acc & ~md) - (nhi & md);
+  Bn.T += K.d & md;
+  Bn.tlast = (Bn.tlast & ~md) | (kvd & md);
+  Bn.sreg = (s0 & ~md) | (s1 & md & ~good) | (1u & good);
+  const uint32_t byte = (s0 >> Q.sh9) & Q.ff;
+  bq = (bq & ~good) | (((bq << 8) | byte) & good);
+  nq -= good;
+  md_out = md;
+  return md & ((m_stop & ~bm) | (m_start & bm));                             // bad stop bit / bad start bit
+}
+
+// The fast path of one block (a tile: eight decimated samples).  Works on copies (Bn, rp, bq, nq): the caller commits
+// them only if the returned flag word has its sign bit clear in every lane.  kv0 = pushes before the block.  hard_out:
+// the same without the 'eod' bound -- a sync candidate or a bad start / stop bit, which only the per-sample path takes.
 __device__ inline uint32_t blk_fast(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t kv0, const v4f (&pa)[4],
-                                    uint32_t (&rp)[kBlk], float (&am)[kBlk], uint32_t &bq, uint32_t &nq) {
+                                    uint32_t (&rp)[kBlk], float (&am)[kBlk], uint32_t &bq, uint32_t &nq, uint32_t &hard_out) {
   const float phs[kBlk] = {pa[0].x, pa[0].z, pa[1].x, pa[1].z, pa[2].x, pa[2].z, pa[3].x, pa[3].z};
   am[0] = pa[0].y; am[1] = pa[0].w; am[2] = pa[1].y; am[3] = pa[1].w;
   am[4] = pa[2].y; am[5] = pa[2].w; am[6] = pa[3].y; am[7] = pa[3].w;
-  uint32_t w = 0, rare = 0;
+  uint32_t w = 0, hard = 0;
   // inside the block the correlator's count is carried as its distance to the threshold and the last loud sample as its
   // index relative to the block (1 .. kBlk, or <= 0 for "before it"): the per-sample test is then one operation and the
   // sample index an inline constant
@@ -114,7 +150,7 @@ __device__ inline uint32_t blk_fast(BackLane &Bn, const BackK &K, const BlkK &Q,
     rp[j] = r;
     dm += (uint32_t)__builtin_popcount((r ^ K.qn) & K.mask);
     dm -= (uint32_t)__builtin_popcount((rold ^ K.qn) & K.mask);
-    rare |= ~dm;                                                             // sign set <=> matched >= thr_eff (sync candidate)
+    hard |= ~dm;                                                             // sign set <=> matched >= thr_eff (sync candidate)
     const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, am[j] - Bn.thr));   // fsk.ts:285
     lsr = (lsr & silent) | ((uint32_t)(j + 1) & ~silent);
     w = __builtin_amdgcn_alignbit(w, nf, 31);                                // sample 1 ends up in bit kBlk - 1
@@ -123,33 +159,210 @@ __device__ inline uint32_t blk_fast(BackLane &Bn, const BackK &K, const BlkK &Q,
   Bn.ls = lsr + kv0;
   // 'eod' (fsk.ts:288): no silence run inside the block is longer than the one a wholly silent block would end with
   // (eod_m1 - ((kv0 + kBlk) - ls at entry))
-  rare |= K.eod_m1 - (uint32_t)kBlk + lsr0;
-  // ---- bit clock, once per block (fsk.ts:335-341): decision at sample jd of the block
-  uint32_t jd = Bn.T - kv0;                        // 1..kBlk in this block; 0 right after a sync (nextBitSampleIndex = k)
-  jd -= neg_mask(jd - 1u);                         // 0 -> 1
-  const uint32_t md = neg_mask(jd - (uint32_t)(kBlk + 1));   // all ones <=> a decision falls into this block
-  const uint32_t hi = w >> (((uint32_t)kBlk - jd) & 31u);    // the slicer bits of samples 1..jd (garbage without a decision: masked)
-  const uint32_t nhi = (uint32_t)__builtin_popcount(hi);
-  const uint32_t ones = nhi + Bn.acc;
-  const uint32_t tot = (uint32_t)__builtin_popcount(w);
-  const uint32_t kvd = kv0 + jd;
-  const uint32_t b = sign_bit((kvd - Bn.tlast) - ones - ones);               // 2 * bitAccumulator > bitAccumCount
-  const uint32_t s0 = Bn.sreg;
-  const uint32_t s1 = s0 + s0 + b;
-  // processByte (fsk.ts:346-375) at the decision
-  const uint32_t m_start = neg_mask(s0 - 2u);                                // waiting for the start bit
-  const uint32_t m_stop = neg_mask(Q.stop_m1 - s0);                          // all data bits in: stop (or parity) position
-  const uint32_t bm = 0u - b;
-  const uint32_t good = md & m_stop & bm;                                    // a byte completes
-  rare |= md & ((m_stop & ~bm) | (m_start & bm));                            // bad stop bit / bad start bit
-  Bn.acc = tot + (Bn.acc & ~md) - (nhi & md);
-  Bn.T += K.d & md;
-  Bn.tlast = (Bn.tlast & ~md) | (kvd & md);
-  Bn.sreg = (s0 & ~md) | (s1 & md & ~good) | (1u & good);
-  const uint32_t byte = (s0 >> Q.sh9) & Q.ff;
-  bq = (bq & ~good) | (((bq << 8) | byte) & good);
-  nq -= good;
-  return rare;
+  const uint32_t soft = K.eod_m1 - (uint32_t)kBlk + lsr0;
+  // ---- bit clock, once per block (fsk.ts:335-341)
+  uint32_t md;
+  hard |= blk_clock(Bn, K, Q, kv0, w, bq, nq, md);
+  hard_out = hard;
+  return hard | soft;
+}
+
+// ---- The block path that takes resets (round 4) --------------------------------------------------------------------
+// A block that holds an 'eod' (resetState(), fsk.ts:175-188, 288-291) or a lane inside this wave's own span after one
+// used to be redone by back_pair, sample by sample: ~276 instructions and ~30 branches per decimated sample from a wave
+// that, on an idle receiver bank (every stream fires an 'eod' each samplesForEOD decimated samples on its own schedule:
+// 3.7 resets per tile and group), is the only busy one of its group.  This is the same arithmetic as ONE straight-line
+// sequence per decimated sample for all lanes, every condition a mask:
+//   * the correction's recurrence, the zero-started ("direct") instance on the tile's pre-filter outputs and the NCO
+//     phasors wave 0 left in LDS, the formation of the correction's start values at zr_dph 24 / 25 (zir_step, op for op),
+//     and the lanes' own discriminator where their span is this wave's (zr_dph < kHandPairs);
+//   * disc_post, slicer, correlator, silence run as in blk_fast; 'eod' is tested exactly, per sample, and resetState()
+//     applied under its mask: post filter, direct instance, zr_dph, lastPhase = the free-running frame's phase at that
+//     sample (thf8: eight values per tile, evaluated by one lane each), silence run, search threshold;
+//   * what a reset writes to memory and to the other waves' mailboxes is NOT done here: the sample of the reset (E.jr) and
+//     of the start values' formation (E.jc, with the values) are returned, and the caller performs them once per tile,
+//     before it releases the tile's ring slots (the other waves cannot have passed the points the mailboxes name: the
+//     lag constants' static_asserts);
+//   * the bit clock once per block (blk_clock), for lanes without a reset in it.
+// Everything else -- a sync candidate, a bad start / stop bit, a second reset or a reset plus a bit decision of one lane in
+// one block -- sets the returned word's sign bit: the caller puts the entry state back and redoes the block sample by sample.
+struct MedEv {
+  uint32_t jr;                   // 1..8: resetState() ran at the end of this sample of the block; 0 = no reset
+  uint32_t jc;                   // 1..8: the correction's start values were formed at this sample; 0 = not in this block
+  float cai, caq, cbi, cbq;      // those values (zq_a, zq_b right after their formation)
+};
+__device__ inline uint32_t bsel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+__device__ inline float bself(uint32_t m, float a, float b) {
+  return __builtin_bit_cast(float, bsel(m, __builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b)));
+}
+__device__ inline float bzero(uint32_t keep, float a) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, a) & keep); }
+__device__ inline uint32_t eq_mask(uint32_t v, uint32_t c) { return neg_mask((v ^ c) - 1u); }   // all ones <=> v == c (small values)
+
+// The entry state of a block that blk_medium is about to work on IN PLACE (a copy in registers would not fit beside it:
+// the kernel's 128-VGPR budget), as seven 16-byte stores per lane to a buffer of the engine's: fire and forget -- read back
+// (med_unstash) only if the block turns out to need the per-sample path.  Everything blk_medium writes.
+__device__ inline void med_stash(const BackLane &B, __amdgpu_buffer_rsrc_t rs, uint32_t avoff, uint32_t fld16) {
+#define FSK_ST4(i, a, b, c, d) \
+  __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, c), __builtin_bit_cast(uint32_t, d)}, rs, avoff, (i) * fld16, 0)
+  FSK_ST4(0u, B.qai, B.qaq, B.qbi, B.qbq);
+  FSK_ST4(1u, B.px1, B.px2, B.py, B.pv);
+  FSK_ST4(2u, B.last_phase, B.thf, B.dph, B.matched);
+  FSK_ST4(3u, B.dix1, B.dix2, B.diy, B.dvi);
+  FSK_ST4(4u, B.dqx1, B.dqx2, B.dqy, B.dqv);
+  FSK_ST4(5u, B.q0i, B.q0q, B.thr_eff, B.ls);
+  FSK_ST4(6u, B.acc, B.T, B.tlast, B.sreg);
+#undef FSK_ST4
+}
+__device__ inline void med_unstash(BackLane &B, __amdgpu_buffer_rsrc_t rs, uint32_t avoff, uint32_t fld16) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const v4u r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, avoff, 0u, kCohSc1);
+  const v4u r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, avoff, fld16, kCohSc1);
+  const v4u r2 = __builtin_amdgcn_raw_buffer_load_b128(rs, avoff, 2u * fld16, kCohSc1);
+  const v4u r3 = __builtin_amdgcn_raw_buffer_load_b128(rs, avoff, 3u * fld16, kCohSc1);
+  const v4u r4 = __builtin_amdgcn_raw_buffer_load_b128(rs, avoff, 4u * fld16, kCohSc1);
+  const v4u r5 = __builtin_amdgcn_raw_buffer_load_b128(rs, avoff, 5u * fld16, kCohSc1);
+  const v4u r6 = __builtin_amdgcn_raw_buffer_load_b128(rs, avoff, 6u * fld16, kCohSc1);
+  // lanes beyond the batch have no row (their stores were dropped, their loads return zeros): they keep what they have --
+  // parked lanes whose filters run on zeros, wherever those stand
+  const bool mine = avoff < 0xFFFFFFF0u;
+  auto f = [mine](uint32_t x, float old) { return mine ? __builtin_bit_cast(float, x) : old; };
+  auto u = [mine](uint32_t x, uint32_t old) { return mine ? x : old; };
+  B.qai = f(r0.x, B.qai); B.qaq = f(r0.y, B.qaq); B.qbi = f(r0.z, B.qbi); B.qbq = f(r0.w, B.qbq);
+  B.px1 = f(r1.x, B.px1); B.px2 = f(r1.y, B.px2); B.py = f(r1.z, B.py); B.pv = f(r1.w, B.pv);
+  B.last_phase = f(r2.x, B.last_phase); B.thf = f(r2.y, B.thf); B.dph = u(r2.z, B.dph); B.matched = u(r2.w, B.matched);
+  B.dix1 = f(r3.x, B.dix1); B.dix2 = f(r3.y, B.dix2); B.diy = f(r3.z, B.diy); B.dvi = f(r3.w, B.dvi);
+  B.dqx1 = f(r4.x, B.dqx1); B.dqx2 = f(r4.y, B.dqx2); B.dqy = f(r4.z, B.dqy); B.dqv = f(r4.w, B.dqv);
+  B.q0i = f(r5.x, B.q0i); B.q0q = f(r5.y, B.q0q); B.thr_eff = u(r5.z, B.thr_eff); B.ls = u(r5.w, B.ls);
+  B.acc = u(r6.x, B.acc); B.T = u(r6.y, B.T); B.tlast = u(r6.z, B.tlast); B.sreg = u(r6.w, B.sreg);
+}
+
+// (works on Bn IN PLACE: the caller has parked the entry state with med_stash)
+__device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t matched_min, uint32_t kv0,
+                                      const v4f *slot, const v4f *slot2, const v4f *ys0, const v4f *ys1, uint32_t lane,
+                                      const v4f *ztile, const float (&thf8)[kBlk], const uint32_t *prow, uint32_t pidx, uint32_t pidx2,
+                                      float (&am)[kBlk], uint32_t &bq, uint32_t &nq, MedEv &E, uint32_t &w_out) {
+  uint32_t w = 0, hard = 0;
+  uint32_t matched = Bn.matched, thr_cur = Bn.thr_eff, ls = Bn.ls;
+  E.jr = 0; E.jc = 0; E.cai = E.caq = E.cbi = E.cbq = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < kBlk / 2; jj++) {
+    // two decimated samples' inputs: ring entries (pair sums where the lane's span is this wave's, else phase and magnitude),
+    // the four pre-filter outputs behind them, the two polyphase registers (not kept: the caller re-forms the new ones
+    // from the old ones and the block's slicer bits).  The fence keeps the compiler from reading all eight samples' inputs
+    // up front: 40 registers it does not have.
+    asm volatile("" ::: "memory");
+    const v4f pe = (jj < 2 ? slot : slot2)[(jj & 1) * 64 + (int)lane];
+    const v4f ye2 = (jj < 2 ? ys0 : ys1)[(jj & 1) * 64 + (int)lane];
+    const uint2 rp2 = *reinterpret_cast<const uint2 *>(prow + (jj < 2 ? pidx : pidx2) + 2 * (jj & 1));
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+    const int j = 2 * jj + h;
+    const float e0 = h ? pe.z : pe.x, e1 = h ? pe.w : pe.y;
+    const float y0 = h ? ye2.z : ye2.x, y1 = h ? ye2.w : ye2.y;
+    const uint32_t kvj = kv0 + (uint32_t)(j + 1);
+    const v4f z = ztile[j];                                                  // (c0, s0, c1, s1) of the pair's two input samples
+    // ---- zir_step<UNI, HAND = true>, flat
+    const uint32_t dph0 = Bn.dph;
+    float wi = e0 - Bn.qai, wq = e1 - Bn.qaq;
+    {
+      const float ni = __builtin_fmaf(K.c1, Bn.qbi, -(K.c2 * Bn.qai));
+      const float nq2 = __builtin_fmaf(K.c1, Bn.qbq, -(K.c2 * Bn.qaq));
+      Bn.qai = Bn.qbi; Bn.qaq = Bn.qbq; Bn.qbi = ni; Bn.qbq = nq2;
+    }
+    float di, dq;
+    {
+      const float mi = y0 * z.x, mq = y0 * z.y;
+      const float ti = __builtin_fmaf(2.0f, Bn.dix1, mi) + Bn.dix2, tq = __builtin_fmaf(2.0f, Bn.dqx1, mq) + Bn.dqx2;
+      Bn.dvi = __builtin_fmaf(K.lp_a2, Bn.dvi, __builtin_fmaf(K.lp_nd, Bn.diy, ti));
+      Bn.dqv = __builtin_fmaf(K.lp_a2, Bn.dqv, __builtin_fmaf(K.lp_nd, Bn.dqy, tq));
+      Bn.diy += Bn.dvi; Bn.dqy += Bn.dqv;
+      Bn.dix2 = Bn.dix1; Bn.dix1 = mi; Bn.dqx2 = Bn.dqx1; Bn.dqx1 = mq;
+      di = Bn.diy; dq = Bn.dqy;
+    }
+    {
+      const float mi = y1 * z.z, mq = y1 * z.w;
+      const float ti = __builtin_fmaf(2.0f, Bn.dix1, mi) + Bn.dix2, tq = __builtin_fmaf(2.0f, Bn.dqx1, mq) + Bn.dqx2;
+      Bn.dvi = __builtin_fmaf(K.lp_a2, Bn.dvi, __builtin_fmaf(K.lp_nd, Bn.diy, ti));
+      Bn.dqv = __builtin_fmaf(K.lp_a2, Bn.dqv, __builtin_fmaf(K.lp_nd, Bn.dqy, tq));
+      Bn.diy += Bn.dvi; Bn.dqy += Bn.dqv;
+      Bn.dix2 = Bn.dix1; Bn.dix1 = mi; Bn.dqx2 = Bn.dqx1; Bn.dqx1 = mq;
+      di += Bn.diy; dq += Bn.dqy;
+    }
+    // (lanes past the direct instance run it on as well: its state is not theirs any more -- pipe_store writes zeros for it
+    // once zr_dph has reached kDirectPairs, whichever path the samples took)
+    const uint32_t m_dir = neg_mask(dph0 - kDirectPairs);                    // zr_dph < kDirectPairs: the direct instance's output
+    wi = bself(m_dir, di, wi); wq = bself(m_dir, dq, wq);
+    {
+      const float qi = e0 - di, qq = e1 - dq;                                // U - d: the free-running filters' zero-input response
+      const uint32_t m24 = eq_mask(dph0, kZeroLagPairs), m25 = eq_mask(dph0, kZeroLagPairs + 1u);
+      const float nai = __builtin_fmaf(K.c1, qi, -(K.c2 * Bn.q0i)), naq = __builtin_fmaf(K.c1, qq, -(K.c2 * Bn.q0q));
+      const float nbi = __builtin_fmaf(K.c1, nai, -(K.c2 * qi)), nbq = __builtin_fmaf(K.c1, naq, -(K.c2 * qq));
+      Bn.q0i = bself(m24, qi, Bn.q0i); Bn.q0q = bself(m24, qq, Bn.q0q);
+      Bn.qai = bself(m25, nai, Bn.qai); Bn.qaq = bself(m25, naq, Bn.qaq);
+      Bn.qbi = bself(m25, nbi, Bn.qbi); Bn.qbq = bself(m25, nbq, Bn.qbq);
+      E.cai = bself(m25, nai, E.cai); E.caq = bself(m25, naq, E.caq);
+      E.cbi = bself(m25, nbi, E.cbi); E.cbq = bself(m25, nbq, E.cbq);
+      E.jc = bsel(m25, (uint32_t)(j + 1), E.jc);
+      // (materialised here: left to itself the compiler spills the eight samples' candidates and forms these in the rare
+      // branch that posts them, behind sixteen scratch round trips)
+      asm volatile("" : "+v"(E.cai), "+v"(E.caq), "+v"(E.cbi), "+v"(E.cbq), "+v"(E.jc));
+    }
+    const uint32_t m_own = neg_mask(dph0 - kHandPairs);                      // the span is this wave's
+    Bn.dph = dph0 - m_own;                                                   // + 1, saturating at kHandPairs
+    {
+      const uint32_t keep = ~eq_mask(dph0, kHandPairs - 1u);                 // handed over: the discriminator wave's from here on
+      Bn.qai = bzero(keep, Bn.qai); Bn.qaq = bzero(keep, Bn.qaq); Bn.qbi = bzero(keep, Bn.qbi); Bn.qbq = bzero(keep, Bn.qbq);
+    }
+    float a2;
+    const float p2 = atan2_amp_fma(wq, wi, a2, K.tiny, K.sgn);
+    const float ph = bself(m_own, p2, e0);
+    am[j] = bself(m_own, a2, e1);
+    // ---- discriminator tail, slicer, correlator, silence run (as blk_fast)
+    const float f = disc_post(Bn, K, ph, am[j]);
+    const uint32_t nf = __builtin_bit_cast(uint32_t, 0.0f - f);
+    const uint32_t rold = h ? rp2.y : rp2.x;
+    const uint32_t r = __builtin_amdgcn_alignbit(rold, nf, 31);
+    matched += (uint32_t)__builtin_popcount((r ^ K.qn) & K.mask);
+    matched -= (uint32_t)__builtin_popcount((rold ^ K.qn) & K.mask);
+    hard |= ~(matched - thr_cur);                                            // sync candidate
+    const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, am[j] - Bn.thr));
+    ls = (ls & silent) | (kvj & ~silent);
+    w = __builtin_amdgcn_alignbit(w, nf, 31);
+    // ---- 'eod' (fsk.ts:288) -> resetState() at the end of this sample (back_reset, masked)
+    const uint32_t me = neg_mask(K.eod_m1 - (kvj - ls));
+    hard |= me & (0u - E.jr);                                                // a second reset in the block
+    E.jr = bsel(me, (uint32_t)(j + 1), E.jr);
+    asm volatile("" : "+v"(E.jr), "+v"(hard));
+    Bn.last_phase = bself(me, thf8[j], Bn.last_phase);
+    Bn.thf = bself(me, thf8[j], Bn.thf);
+    const uint32_t keep = ~me;
+    Bn.dph &= keep;
+    Bn.dix1 = bzero(keep, Bn.dix1); Bn.dix2 = bzero(keep, Bn.dix2); Bn.diy = bzero(keep, Bn.diy); Bn.dvi = bzero(keep, Bn.dvi);
+    Bn.dqx1 = bzero(keep, Bn.dqx1); Bn.dqx2 = bzero(keep, Bn.dqx2); Bn.dqy = bzero(keep, Bn.dqy); Bn.dqv = bzero(keep, Bn.dqv);
+    Bn.px1 = bzero(keep, Bn.px1); Bn.px2 = bzero(keep, Bn.px2); Bn.py = bzero(keep, Bn.py); Bn.pv = bzero(keep, Bn.pv);
+    ls = bsel(me, kvj, ls);
+    thr_cur = bsel(me, matched_min, thr_cur);
+    }
+  }
+  Bn.matched = matched;
+  Bn.ls = ls;
+  // ---- bit clock, once per block, from the entry state; a lane that was reset in this block may not also decide a bit
+  uint32_t md;
+  hard |= blk_clock(Bn, K, Q, kv0, w, bq, nq, md);
+  const uint32_t mjr = neg_mask(0u - E.jr);
+  hard |= md & mjr;
+  {
+    // what resetState() leaves of the bit clock: the vote holds the bits sliced after the reset, no decision pending
+    const uint32_t after = w & ((1u << (((uint32_t)kBlk - E.jr) & 31u)) - 1u);
+    const uint32_t park = kv0 + E.jr + kBigWait;
+    Bn.acc = bsel(mjr, (uint32_t)__builtin_popcount(after), Bn.acc);
+    Bn.T = bsel(mjr, park, Bn.T);
+    Bn.tlast = bsel(mjr, park, Bn.tlast);
+    Bn.sreg = bsel(mjr, 1u, Bn.sreg);
+  }
+  Bn.thr_eff = thr_cur;
+  w_out = w;
+  return hard;
 }
 
 // completed bytes of the fast path -> out (oldest first); B.out_cnt counts them as the per-sample path does
@@ -167,7 +380,6 @@ __device__ inline void blk_flush(BackLane &B, uint32_t &bq, uint32_t &nq, const 
 // The discriminator wave's share of the ZIR correction (see back_pair for the arithmetic it restates op for op):
 // w = U - q, q advances by its recurrence and retires to exactly zero once below 2^-28 of the magnitude it corrects.
 struct QLane { float ai, aq, bi, bq; };
-typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
 // Time-sliced priority.  With equal priorities a SIMD issues from its OLDEST wave first: the four groups sharing a CU then
 // finish one after the other (185 .. 284 cycles per sample, profiles/r03_blk4_stamps.txt), the last one largely alone
@@ -247,6 +459,8 @@ struct BlkSched {
   uint32_t zt_tiles;             // tiles of NCO phasors in flight (wave 0 -> wave 1), a power of two > y_slots / 2
   uint32_t lanes;                // streams per workgroup: 64, or 32 / 16 / 8 for batches that would otherwise leave CUs idle
                                  // (round 4, "narrow groups": see launch_demod_blk)
+  uint32_t medium;               // 1: blocks with an 'eod' or a lane inside the back wave's own span take blk_medium; 0: the
+                                 // per-sample path, as in round 3; 2 (tests): blk_medium, then the entry state back and the per-sample path
 };
 
 template <bool WB, bool UNI, bool SL>
@@ -270,8 +484,9 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
   uint32_t *poly = reinterpret_cast<uint32_t *>(zt + Z.zt_tiles * 8);   // [lane][PS], index 0 = the phase of the launch's first push
   uint32_t *ctr = poly + 64u * PS;                        // produced by wave 0, 1, 2 | consumed by wave 3 | [4] CU arrival | [5] item
   uint32_t *zmail = ctr + 8;                              // back -> wave 1: where to zero a lane's I/Q low-pass
-  uint32_t *cmail = zmail + 64;                           // back -> wave 2: [0] from which decimated sample, [1..4] the correction there,
-                                                          // [5] since which sample the back wave wants a lane's pair sums kept
+  uint32_t *cmail = zmail + 64;                           // back -> wave 2: [0] from which decimated sample, [1..4] the correction [6] steps
+                                                          // of its recurrence before that, [5] since which sample the back wave wants a
+                                                          // lane's pair sums kept
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t lane = threadIdx.x & 63u;
 
@@ -369,17 +584,13 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     const uint32_t dph = PIPE_ILOAD(zr_dph);
     uint32_t kq = 0xFFFFFFFFu;
     float ai = 0.f, aq = 0.f, bi = 0.f, bq = 0.f;
-    if (dph >= kDirectPairs && dph < kHandPairs) {
+    if (dph >= kDirectPairs && dph < kHandPairs) {            // (the values as they stand and how many steps are left: see zir_step)
       ai = PIPE_RLOAD(zq_ai); aq = PIPE_RLOAD(zq_aq); bi = PIPE_RLOAD(zq_bi); bq = PIPE_RLOAD(zq_bq);
-      const float c1 = P.z_c1, c2 = P.z_c2;
-      for (uint32_t g = dph; g < kHandPairs; g++) {
-        const float ni = __builtin_fmaf(c1, bi, -(c2 * ai)), nq = __builtin_fmaf(c1, bq, -(c2 * aq));
-        ai = bi; aq = bq; bi = ni; bq = nq;
-      }
       kq = kHandPairs - dph;
     }
     cmail[64u + lane] = __builtin_bit_cast(uint32_t, ai); cmail[128u + lane] = __builtin_bit_cast(uint32_t, aq);
     cmail[192u + lane] = __builtin_bit_cast(uint32_t, bi); cmail[256u + lane] = __builtin_bit_cast(uint32_t, bq);
+    cmail[384u + lane] = kq == 0xFFFFFFFFu ? 0u : kq;
     cmail[lane] = kq;
     cmail[320u + lane] = 0u - dph;                          // (dph >= kHandPairs: the span is over)
   }
@@ -641,11 +852,22 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         // one test for everything that is not the plain discriminator: a hand-over due in this tile, a lane inside the
         // back wave's own span, a live correction
         if (__builtin_expect((__builtin_amdgcn_ballot_w64((kq - 4u * hidx < 8u) | (ow < kHandPairs)) | qlive) != 0ull, 0)) {
+          // a hand-over due in this tile: the posted start values, advanced by the posted number of steps of the
+          // recurrence (all of the tile's lanes at once)
+          QLane H = {0.f, 0.f, 0.f, 0.f};
+          if (kq - 4u * hidx < 8u) {
+            H.ai = __builtin_bit_cast(float, cmail[64u + lane]); H.aq = __builtin_bit_cast(float, cmail[128u + lane]);
+            H.bi = __builtin_bit_cast(float, cmail[192u + lane]); H.bq = __builtin_bit_cast(float, cmail[256u + lane]);
+            const uint32_t steps = cmail[384u + lane];
+            for (uint32_t g = 0; g < steps; g++) {
+              const float ni = __builtin_fmaf(c1, H.bi, -(c2 * H.ai)), nq = __builtin_fmaf(c1, H.bq, -(c2 * H.aq));
+              H.ai = H.bi; H.aq = H.bq; H.bi = ni; H.bq = nq;
+            }
+          }
 #pragma unroll
           for (int j = 0; j < 8; j++) {
             if (kq == 4u * hidx + (uint32_t)j) {              // the back wave's correction becomes this wave's here
-              Qz.ai = __builtin_bit_cast(float, cmail[64u + lane]); Qz.aq = __builtin_bit_cast(float, cmail[128u + lane]);
-              Qz.bi = __builtin_bit_cast(float, cmail[192u + lane]); Qz.bq = __builtin_bit_cast(float, cmail[256u + lane]);
+              Qz = H;
             }
             const float wi = ui[j] - Qz.ai, wq = uq[j] - Qz.aq;
             {
@@ -685,12 +907,13 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
   } else {
     // ---------------------------------------------------------------------------------------------- block back
     BackLane B;
-    BackK K;
-    back_load<UNI, COH>(B, K, P, S, C, stream, out_counts, eod_counts, append);
+    BackK Kp;
+    back_load<UNI, COH>(B, Kp, P, S, C, stream, out_counts, eod_counts, append);
+    BackK Ks;                                                 // the constants as scalars, for the paths that are not the fast block loop
+    back_consts(Ks, P);
     if (B.dph >= kHandPairs) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }   // the discriminator wave's
-    BlkK Q;
-    Q.stop_m1 = (1u << P.stop_pos) - 1u; Q.sh9 = P.stop_pos - 9u; Q.ff = 0xFFu;
-    asm volatile("" : "+v"(Q.stop_m1), "+v"(Q.sh9), "+v"(Q.ff));
+    BlkK Qs;
+    Qs.stop_m1 = (1u << P.stop_pos) - 1u; Qs.sh9 = P.stop_pos - 9u; Qs.ff = 0xFFu;
     const FastMem &M = C.M;
     const uint32_t fld = C.fld, row4 = C.row4;
     const uint32_t phase0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
@@ -717,10 +940,12 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     // block takes the per-sample path
     const bool amp_misaligned = (amp_pos0 & 3u) != 0u;
     const __amdgpu_buffer_rsrc_t amp_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.amp_ring, 0, (int)amp_wrap, 0x00020000);
+    const __amdgpu_buffer_rsrc_t stash_rsrc = __builtin_amdgcn_make_buffer_rsrc(S.blk_stash, 0, (int)(7u * amp_quad_bytes), 0x00020000);
     uint32_t produced = 0, slot_i = 0;                        // (x-ring slot of half tile t; even wherever a block starts)
     uint32_t pidx = 0;                                        // LDS index of the block's first polyphase register
     uint32_t bq = 0, nq = 0;                                  // completed bytes not yet stored (newest in the low byte)
     uint32_t *prow = poly + lane * PS;
+    uint32_t yb = 0, yb_t = 0;                                // y-ring slot of half tile yb_t (kept while consecutive tiles need it)
     FSK_STAMP_BEGIN
     uint32_t t = 0;                                           // half tiles consumed (a block = a tile = two of them)
     while (t < nh) {
@@ -744,6 +969,15 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
       // that end about together, 81 % of such tiles also hold another lane's 'eod' or false start and fail the block's
       // rare test after paying for it -- 8 192 streams 118.7 -> 111.3 Gsamples/s, profiles/r03_own_span_blocks.txt.)
       bool rare_exit = (X.zlive != 0u || amp_misaligned) && !FSK_ABL(3);
+      uint32_t hardw = 0;                                     // (looked at after the loop: its exit stays one branch)
+      // the fast loop's constants live in VGPRs for the loop only (re-made from the scalars at every entry: the registers are
+      // the data's in the other two paths)
+      BackK K = Ks;
+      BlkK Q = Qs;
+      if (!rare_exit) {
+        back_consts_pin(K);
+        asm volatile("" : "+v"(Q.stop_m1), "+v"(Q.sh9), "+v"(Q.ff));
+      }
       if (!rare_exit) for (;;) {
         v4u32 cv;
         lds_peek4_begin(ctr, cv);
@@ -756,7 +990,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         uint32_t rp[kBlk] = {rpa.x, rpa.y, rpa.z, rpa.w, rpb.x, rpb.y, rpb.z, rpb.w};
         float am[kBlk];
         uint32_t bqn = bq, nqn = nq;
-        const uint32_t rare = blk_fast(Bn, K, Q, X.kv, pa, rp, am, bqn, nqn);
+        const uint32_t rare = blk_fast(Bn, K, Q, X.kv, pa, rp, am, bqn, nqn, hardw);
         FSK_STAMP_COUNT(0)                                    // blocks
         if (__builtin_expect((__builtin_amdgcn_ballot_w64((int32_t)rare < 0) != 0ull) & !FSK_ABL(3), 0)) { rare_exit = true; break; }
         B = Bn; bq = bqn; nq = nqn;
@@ -780,6 +1014,92 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
         produced = lds_peek4_get(cv, 2);
         lim = lim0 < (produced & ~1u) ? lim0 : (produced & ~1u);
         if (!(t < lim)) break;
+      }
+      // a sync candidate, a bad start / stop bit, an amplitude ring off its quad grid: nothing but the per-sample path will do
+      const bool hard_exit = amp_misaligned || __builtin_amdgcn_ballot_w64((int32_t)hardw < 0) != 0ull;
+      if (rare_exit && !hard_exit && UNI && Z.medium != 0u) {
+        // an 'eod' in the tile at t, or a lane inside this wave's own span after one: the block path that takes resets
+        // (blk_medium), in place, the tile's entry state parked in the engine's stash
+        const uint32_t slot_j = slot_i + 1u;
+        const uint32_t pidx2 = pidx + 4u >= P.d ? 0u : pidx + 4u;
+        const v4f *slot = ring + slot_i * kBlkSlotV4, *slot2 = ring + slot_j * kBlkSlotV4;
+        if (yb_t != t) { yb = t % NY; yb_t = t; }
+        const uint32_t yb2 = yb + 1u == NY ? 0u : yb + 1u;
+        const v4f *ys0 = yring + yb * 2u * 64u, *ys1 = yring + yb2 * 2u * 64u;
+        const v4f *ztile = zt + ((t >> 1) & ZTM) * 8u;
+        // lastPhase after a resetState() at the end of sample j of this tile: the free-running frame's phase there
+        // (back_reset's expression; lane j evaluates it, the wave reads it back as a scalar)
+        float thf8[kBlk];
+        {
+          const uint64_t fr0 = X.free0 + inc * (uint64_t)(2u * (X.k + (lane & 7u) + 1u));
+          double r = (double)fr0 * 5.42101086242752217e-20 * 6.283185307179586476925;
+          r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
+          const float thfv = (float)r;
+#pragma unroll
+          for (int j = 0; j < kBlk; j++) thf8[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thfv), j));
+        }
+        med_stash(B, stash_rsrc, M.avoff, amp_quad_bytes);
+        float am[kBlk];
+        uint32_t bqn = bq, nqn = nq, wbits;
+        MedEv E;
+        const uint32_t hard = blk_medium(B, Ks, Qs, P.matched_min, X.kv, slot, slot2, ys0, ys1, lane, ztile, thf8, prow, pidx, pidx2,
+                                         am, bqn, nqn, E, wbits);
+        FSK_STAMP_COUNT(2)
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)hard < 0) != 0ull || Z.medium == 2u, 0)) {
+          med_unstash(B, stash_rsrc, M.avoff, amp_quad_bytes);   // a sync candidate or a bad bit after all: from the entry state, sample by sample
+        } else {
+          bq = bqn; nq = nqn;
+          {
+            // syncSamplesBuffer.put x 8: old register << 1 | the sample's slicer bit (sample 1 is bit 7 of wbits)
+            const uint4 oa = *reinterpret_cast<const uint4 *>(prow + pidx), ob = *reinterpret_cast<const uint4 *>(prow + pidx2);
+            *reinterpret_cast<uint4 *>(prow + pidx) = make_uint4((oa.x << 1) | ((wbits >> 7) & 1u), (oa.y << 1) | ((wbits >> 6) & 1u),
+                                                                 (oa.z << 1) | ((wbits >> 5) & 1u), (oa.w << 1) | ((wbits >> 4) & 1u));
+            *reinterpret_cast<uint4 *>(prow + pidx2) = make_uint4((ob.x << 1) | ((wbits >> 3) & 1u), (ob.y << 1) | ((wbits >> 2) & 1u),
+                                                                  (ob.z << 1) | ((wbits >> 1) & 1u), (ob.w << 1) | (wbits & 1u));
+          }
+          {
+            uint32_t q2 = X.amp_soff + amp_quad_bytes; q2 = q2 == amp_wrap ? 0u : q2;
+            __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, am[0]), __builtin_bit_cast(uint32_t, am[1]),
+                                                          __builtin_bit_cast(uint32_t, am[2]), __builtin_bit_cast(uint32_t, am[3])},
+                                                   amp_rsrc, M.avoff, X.amp_soff, COH);
+            __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, am[4]), __builtin_bit_cast(uint32_t, am[5]),
+                                                          __builtin_bit_cast(uint32_t, am[6]), __builtin_bit_cast(uint32_t, am[7])},
+                                                   amp_rsrc, M.avoff, q2, COH);
+            X.amp_soff = q2 + amp_quad_bytes; X.amp_soff = X.amp_soff == amp_wrap ? 0u : X.amp_soff;
+          }
+          const uint32_t k0 = X.k;
+          X.k += (uint32_t)kBlk; X.kv += (uint32_t)kBlk;
+          slot_i = slot_i + 2u == kBlkSlots ? 0u : slot_i + 2u;
+          pidx = pidx2 + 4u >= P.d ? 0u : pidx2 + 4u;
+          t += 2u;
+          yb = yb2 + 1u == NY ? 0u : yb2 + 1u; yb_t = t;
+          // what the tile's resets owe memory and the other waves' mailboxes, once, before the tile's slots are released
+          if (__builtin_amdgcn_ballot_w64((E.jr | E.jc) != 0u)) {
+            if (E.jc != 0u) {                                  // (zir_step: the correction's start values, for the discriminator wave)
+              cmail[64u + lane] = __builtin_bit_cast(uint32_t, E.cai); cmail[128u + lane] = __builtin_bit_cast(uint32_t, E.caq);
+              cmail[192u + lane] = __builtin_bit_cast(uint32_t, E.cbi); cmail[256u + lane] = __builtin_bit_cast(uint32_t, E.cbq);
+              cmail[384u + lane] = kHandLag;
+              cmail[lane] = k0 + E.jc + kHandLag;
+            }
+            if (E.jr != 0u) {                                  // (back_pair's 'eod' + back_reset)
+              const uint32_t kr = k0 + E.jr;
+              ist_add<COH>(M, IF_eod_total, 1u);
+              if (eod_counts && M.voff < 0xFFFFFFF0u) __hip_atomic_fetch_add(&eod_counts[M.voff >> 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const uint64_t off = 0ull - (X.free0 + inc * (uint64_t)(2u * kr));
+              ist_store<COH>(M, IF_fr_lo, (uint32_t)off);
+              ist_store<COH>(M, IF_fr_hi, (uint32_t)(off >> 32));
+              ist_store<COH>(M, IF_gsc, 0u - kr);
+              zmail[lane] = kr + kZeroLagPairs;
+              cmail[lane] = 0xFFFFFFFFu;
+              cmail[320u + lane] = kr;
+              B.rho = kr % P.cadence;
+            }
+          }
+          X.zlive = __builtin_amdgcn_ballot_w64(B.dph < kHandPairs) != 0ull ? 1u : 0u;
+          X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) != 0ull ? kDirectPairs : 0u;
+          lds_post(&ctr[3], t);
+          rare_exit = false;
+        }
       }
       if (rare_exit) {
         // something rare in the tile at t: sample by sample from its entry state (the round-2 path, unchanged)
@@ -811,7 +1131,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
             X.k++;
             X.kv += 1u;
             const float zph[4] = {zq[j].x, zq[j].y, zq[j].z, zq[j].w};
-            back_pair<UNI, true, false, true, COH>(B, K, P, S, M, &rn[j], lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
+            back_pair<UNI, true, false, true, COH>(B, Ks, P, S, M, &rn[j], lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
                                               uv[2 * j], uv[2 * j + 1], &yv[2 * j], ro[j], inc, uv[2 * j], uv[2 * j + 1], UNI ? zph : nullptr);
             amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
           }
@@ -848,6 +1168,11 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
       if (cmail[lane] == X.k) {
         B.qai = __builtin_bit_cast(float, cmail[64u + lane]); B.qaq = __builtin_bit_cast(float, cmail[128u + lane]);
         B.qbi = __builtin_bit_cast(float, cmail[192u + lane]); B.qbq = __builtin_bit_cast(float, cmail[256u + lane]);
+        const uint32_t steps = cmail[384u + lane];             // (what the discriminator wave would have run on taking them)
+        for (uint32_t g = 0; g < steps; g++) {
+          const float ni = __builtin_fmaf(Ks.c1, B.qbi, -(Ks.c2 * B.qai)), nq = __builtin_fmaf(Ks.c1, B.qbq, -(Ks.c2 * B.qaq));
+          B.qai = B.qbi; B.qaq = B.qbq; B.qbi = ni; B.qbq = nq;
+        }
       }
     }
     {
@@ -874,7 +1199,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
 // ---- host side ---------------------------------------------------------------------------------------------------
 size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots) {
   return sizeof(float4) * (4 * kSlotStride + y_slots * 2 * 64 + kBlkSlots * kBlkSlotV4 + blk_zt_tiles(y_slots) * 8) +
-         sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 8u + 64u + 6u * 64u);
+         sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 8u + 64u + 7u * 64u);
 }
 size_t demod_blk_lds_bytes(const DemodParams &P) { return demod_blk_lds_bytes(P, kBlkSlots); }
 // the block path needs whole blocks of polyphase registers (dsSPB a multiple of 4) and at most one bit decision per block
@@ -963,13 +1288,13 @@ uint32_t demod_blk_lanes(uint32_t n_streams, int device) {
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, uint32_t y_slots,
-                             uint32_t lanes, bool *sliced_out) {
+                             uint32_t lanes, uint32_t medium, bool *sliced_out) {
   lanes = (lanes == 8u || lanes == 16u || lanes == 32u) ? lanes : 64u;
   const uint32_t blocks = (P.n_streams + lanes - 1u) / lanes;
   y_slots = y_slots < kBlkSlots ? kBlkSlots : y_slots > kBlkYMax ? kBlkYMax : y_slots;
   const size_t lds = demod_blk_lds_bytes(P, y_slots);
   set_ablate_blk();
-  BlkSched Z = {nullptr, blocks, 1u, 0u, 0u, y_slots, blk_zt_tiles(y_slots), lanes};
+  BlkSched Z = {nullptr, blocks, 1u, 0u, 0u, y_slots, blk_zt_tiles(y_slots), lanes, medium};
   uint32_t st = 0;
   // (time slices are for batches beyond one round of whole-wave groups; narrow groups are never sliced -- the queue is
   // sized for 64-stream groups)

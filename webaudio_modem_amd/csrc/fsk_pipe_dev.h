@@ -217,8 +217,9 @@ struct BackU {                   // wave-uniform context of one decimated sample
   uint32_t direct;               // decimated samples for which some lane still runs the direct instance (after a reset)
   uint32_t zlive;                // some lane carries a non-zero correction (or runs the direct instance)
   uint32_t *zmail;               // LDS [64]: decimated-sample index of this launch before which the front zeroes the lane's filters
-  uint32_t *cmail;               // LDS [6][64] or null (fsk_blk.hip): hand-over of the ZIR correction to the discriminator wave
-                                 // ([0] from which sample, [1..4] its value there), [5] the sample this wave's own span began at
+  uint32_t *cmail;               // LDS [7][64] or null (fsk_blk.hip): hand-over of the ZIR correction to the discriminator wave
+                                 // ([0] from which sample, [1..4] its value [6] steps of the recurrence before that sample),
+                                 // [5] the sample this wave's own span began at
   uint64_t free0;                // free-running frame: NCO phase (turns * 2^64) at the first sample of the launch
 };
 
@@ -354,14 +355,13 @@ __device__ inline void zir_step(BackLane &B, const BackK &K, BackU &X, float Ui,
         B.qbq = __builtin_fmaf(K.c1, B.qaq, -(K.c2 * q1q));
         if (HAND) {
           // the correction stays here for the next kHandLag decimated samples (numbers X.k .. X.k + kHandLag - 1 of this
-          // launch) and then moves to the discriminator wave: post what the recurrence makes of it by then
-          float ai = B.qai, aq = B.qaq, bi = B.qbi, bq = B.qbq;
-          for (uint32_t g = 0; g < kHandLag; g++) {
-            const float ni = __builtin_fmaf(K.c1, bi, -(K.c2 * ai)), nq = __builtin_fmaf(K.c1, bq, -(K.c2 * aq));
-            ai = bi; aq = bq; bi = ni; bq = nq;
-          }
-          X.cmail[64u + lane] = __builtin_bit_cast(uint32_t, ai); X.cmail[128u + lane] = __builtin_bit_cast(uint32_t, aq);
-          X.cmail[192u + lane] = __builtin_bit_cast(uint32_t, bi); X.cmail[256u + lane] = __builtin_bit_cast(uint32_t, bq);
+          // launch) and then moves to the discriminator wave.  Its values at the hand-over sample follow from these by
+          // kHandLag steps of the recurrence alone: posted are the start values and the step count, and the discriminator
+          // wave -- the one with time to spare wherever resets are frequent -- runs the steps when it takes them (round 4;
+          // the back wave used to, ~100 instructions of the wave that paces an idle receiver bank, per reset)
+          X.cmail[64u + lane] = __builtin_bit_cast(uint32_t, B.qai); X.cmail[128u + lane] = __builtin_bit_cast(uint32_t, B.qaq);
+          X.cmail[192u + lane] = __builtin_bit_cast(uint32_t, B.qbi); X.cmail[256u + lane] = __builtin_bit_cast(uint32_t, B.qbq);
+          X.cmail[384u + lane] = kHandLag;
           X.cmail[lane] = X.k + kHandLag;
         }
       }
@@ -470,7 +470,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
                               pushes < P.amp_cap ? pushes : P.amp_cap);
       }
       if (eod) {
-        ist_store<COH>(M, IF_eod_total, ist_load<COH>(M, IF_eod_total) + 1u);
+        ist_add<COH>(M, IF_eod_total, 1u);
         if (eod_counts && M.voff < 0xFFFFFFF0u) __hip_atomic_fetch_add(&eod_counts[M.voff >> 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         back_reset<UNI, COH>(B, P, M, X, inc, lane);
       }
@@ -491,7 +491,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
         B.thr_eff = kStartedP;
         B.sreg = 1u;
         B.acc = 0; B.T = X.k; B.tlast = X.k;
-        ist_store<COH>(M, IF_sync_det, ist_load<COH>(M, IF_sync_det) + 1u);
+        ist_add<COH>(M, IF_sync_det, 1u);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's ring stores have reached L2
       while (m) {
@@ -624,6 +624,21 @@ __device__ inline void front_load(FrontLane &F, FrontK &K, const DemodParams &P,
   asm volatile("" : "+v"(K.bp_b0), "+v"(K.bp_na1), "+v"(K.bp_na2), "+v"(K.lp_a2), "+v"(K.lp_nd));
 }
 
+// the back's constants as the parameters give them (scalars), and pinned into VGPRs: an SGPR operand halves a vector
+// instruction's rate, which matters where four waves share a SIMD (the hot paths) and not where a wave runs alone or
+// rarely (fsk_blk.hip's block path with resets and per-sample path use them unpinned and leave the registers to the data)
+__device__ inline void back_consts(BackK &K, const DemodParams &P) {
+  K.c1 = P.z_c1; K.c2 = P.z_c2;
+  K.lp_b0 = P.f_lp_b0; K.lp_a2 = P.f_lp_a2; K.lp_nd = -P.f_lp_delta;
+  K.qn = ~(uint32_t)P.pat_q; K.mask = (uint32_t)P.pat_mask; K.d = P.d;
+  K.tiny = 0x1p-123f; K.sgn = 0x80000000u; K.edge_min = (1u << P.stop_pos) - 2u; K.eod_m1 = P.eod_min - 1u; K.zk = -0x1p123f; K.unscale = kIqUnscale;
+}
+__device__ inline void back_consts_pin(BackK &K) {
+  asm volatile("" : "+v"(K.edge_min), "+v"(K.eod_m1), "+v"(K.zk), "+v"(K.unscale));
+  asm volatile("" : "+v"(K.c1), "+v"(K.c2), "+v"(K.lp_b0), "+v"(K.lp_a2), "+v"(K.lp_nd), "+v"(K.qn), "+v"(K.mask), "+v"(K.d));
+  asm volatile("" : "+v"(K.tiny), "+v"(K.sgn));
+}
+
 template <bool UNI, int COH = 0>
 __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, const DemodState &S, const PipeCtx &C,
                                  uint32_t stream, uint32_t *out_counts, uint32_t *eod_counts, int append) {
@@ -669,13 +684,8 @@ __device__ inline void back_load(BackLane &B, BackK &K, const DemodParams &P, co
     // they never enter a rare path, where their out-of-range row index would be used as an address.
     B.thr_eff = 0x7FFFFFFEu; B.thr = -1.0f; B.T = kBigWait; B.tlast = B.T;
   }
-  K.c1 = P.z_c1; K.c2 = P.z_c2;
-  K.lp_b0 = P.f_lp_b0; K.lp_a2 = P.f_lp_a2; K.lp_nd = -P.f_lp_delta;
-  K.qn = ~(uint32_t)P.pat_q; K.mask = (uint32_t)P.pat_mask; K.d = P.d;
-  K.tiny = 0x1p-123f; K.sgn = 0x80000000u; K.edge_min = (1u << P.stop_pos) - 2u; K.eod_m1 = P.eod_min - 1u; K.zk = -0x1p123f; K.unscale = kIqUnscale;
-  asm volatile("" : "+v"(K.edge_min), "+v"(K.eod_m1), "+v"(K.zk), "+v"(K.unscale));
-  asm volatile("" : "+v"(K.c1), "+v"(K.c2), "+v"(K.lp_b0), "+v"(K.lp_a2), "+v"(K.lp_nd), "+v"(K.qn), "+v"(K.mask), "+v"(K.d));
-  asm volatile("" : "+v"(K.tiny), "+v"(K.sgn));
+  back_consts(K, P);
+  back_consts_pin(K);
 }
 
 // everything back to the state arrays.  F: the front's final state, n: samples of the launch, k: decimated samples,
@@ -697,8 +707,16 @@ __device__ inline void pipe_store(const FrontLane &F, bool store_front, const Ba
   PIPE_RSTORE(zq_ai, B.qai); PIPE_RSTORE(zq_aq, B.qaq); PIPE_RSTORE(zq_bi, B.qbi); PIPE_RSTORE(zq_bq, B.qbq);
   PIPE_RSTORE(zq_0i, B.q0i); PIPE_RSTORE(zq_0q, B.q0q);
   PIPE_ISTORE(zr_dph, B.dph);
-  PIPE_RSTORE(zd_ix1, B.dix1); PIPE_RSTORE(zd_ix2, B.dix2); PIPE_RSTORE(zd_iy, B.diy); PIPE_RSTORE(zd_iv, B.dvi);
-  PIPE_RSTORE(zd_qx1, B.dqx1); PIPE_RSTORE(zd_qx2, B.dqx2); PIPE_RSTORE(zd_qy, B.dqy); PIPE_RSTORE(zd_qv, B.dqv);
+  {
+    // the direct instance's registers mean something only while it runs (zr_dph < kDirectPairs); after that zeros are
+    // stored, so that the state arrays do not depend on which path took the samples in between (fsk_blk.hip's block path
+    // with resets lets the instance run on for lanes that are past it)
+    const bool live = B.dph < kDirectPairs;
+    PIPE_RSTORE(zd_ix1, live ? B.dix1 : 0.f); PIPE_RSTORE(zd_ix2, live ? B.dix2 : 0.f);
+    PIPE_RSTORE(zd_iy, live ? B.diy : 0.f); PIPE_RSTORE(zd_iv, live ? B.dvi : 0.f);
+    PIPE_RSTORE(zd_qx1, live ? B.dqx1 : 0.f); PIPE_RSTORE(zd_qx2, live ? B.dqx2 : 0.f);
+    PIPE_RSTORE(zd_qy, live ? B.dqy : 0.f); PIPE_RSTORE(zd_qv, live ? B.dqv : 0.f);
+  }
   PIPE_RSTORE(last_phase, B.last_phase);
   {
     const uint64_t off = ((uint64_t)PIPE_ILOAD(fr_hi) << 32) | PIPE_ILOAD(fr_lo);
