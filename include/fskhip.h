@@ -277,8 +277,9 @@ int fskhip_timing_end(fskhip_engine *e, uint32_t *n_launches, double *total_ms);
  *   "force_generic"  0 | 1          never a whole-tile kernel: the sample-serial kernel only
  *   "blk_y_slots"    6 .. 28        depth of the four-wave kernel's first ring (checked against the LDS it needs)
  *   "blk_min_tiles"  n              calls with fewer whole tiles stay off the four-wave kernel
- *   "blk_resets"     0 | 1          the four-wave kernel's block path takes 'eod' resets itself (1, default) or hands such blocks to its
- *                                   per-sample path (0, round 3's behaviour)
+ *   "blk_resets"     auto | 0 | 1   which four-wave kernel: the one whose block path takes 'eod' resets itself (1: pays on idle receiver
+ *                                   banks, costs ~4 % where resets are rare) or the one that hands such blocks to its per-sample path
+ *                                   (0); auto (default): by the previous call's share of tiles off the fast path
  *   "blk_lanes"      auto|64|32|16|8 streams per workgroup of the four-wave kernel (auto: the widest that gives every workgroup its own CU)
  *   "blk_resident"   n >= 1         treat the device as holding n workgroups at once (time-sliced launches on small batches)
  *   "slice_tiles"    n >= 1 | off   tiles per time slice of a persistent launch

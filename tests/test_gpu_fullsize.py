@@ -729,12 +729,16 @@ def test_idle_receiver_bank_one_frame_then_a_noise_floor():
         x[s] += rng.normal(0.0, np.sqrt(p_frame / 1000.0), N).astype(np.float32)   # the floor: 30 dB under the frame
     gen.h2d(d_x, x)
     digests = []
-    for schedule in ([N], [48000], [128]):
-        eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    # (round 4: this is the regime the block path that takes resets -- demod_blk_kernel_r -- was built for; "auto" starts on
+    # the other kernel and moves to it once a call's statistics are in)
+    for schedule, resets in (([N], 0), ([N], 1), ([48000], "auto"), ([128], "auto"), ([4800], 1), ([16000], 2)):
+        eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options={"blk_resets": resets})
         rows, eod = _demod_schedule(eng, d_x, N, N, schedule)
         if schedule == [N]:
-            assert "demod_blk_kernel" in eng.last_kernel()
+            assert eng.last_kernel().startswith("fsk::demod_blk_kernel_r<" if resets else "fsk::demod_blk_kernel<"), eng.last_kernel()
             rows1, eod1 = rows, eod
+        if schedule == [48000]:
+            assert eng.last_kernel().startswith("fsk::demod_blk_kernel_r<"), eng.last_kernel()      # three calls of floor behind it
         digests.append(_digest(rows, eod))
         eng.close()
     assert len(set(digests)) == 1, digests

@@ -40,7 +40,10 @@ def _check_status(st, ref, tol, agc_gain):
 # "kernel" by tests/conftest.py) pins one of them at engine creation.
 # (round 4: the four-wave kernel cuts batches that would leave CUs idle into groups of 32 / 16 / 8 streams -- a one-stream
 # golden runs on an 8-lane group by default; "f32-four-wave-64" pins whole-wave groups)
-GOLDEN_VARIANTS = PRECISIONS + [("f32-one-wave", 0, 1e-5), ("f32-four-wave", 0, 1e-5), ("f32-four-wave-64", 0, 1e-5)]
+# "-resets": demod_blk_kernel_r, whose block path takes 'eod' resets itself (the default picks it only after a call whose
+# tiles mostly left the fast path); "-redo": the same, every such block then put back and redone sample by sample
+GOLDEN_VARIANTS = PRECISIONS + [("f32-one-wave", 0, 1e-5), ("f32-four-wave", 0, 1e-5), ("f32-four-wave-64", 0, 1e-5),
+                                ("f32-four-wave-resets", 0, 1e-5), ("f32-four-wave-redo", 0, 1e-5)]
 
 
 @pytest.mark.parametrize("pname,prec,tol", GOLDEN_VARIANTS)
@@ -54,6 +57,9 @@ def test_demod_matches_reference_golden(name, pname, prec, tol, monkeypatch):
     elif pname == "f32-four-wave-64":
         monkeypatch.setenv("FSKHIP_SPLIT", "4")
         monkeypatch.setenv("FSKHIP_BLK_LANES", "64")
+    elif pname in ("f32-four-wave-resets", "f32-four-wave-redo"):
+        monkeypatch.setenv("FSKHIP_SPLIT", "4")
+        monkeypatch.setenv("FSKHIP_BLK_RESETS", "1" if pname.endswith("resets") else "2")
     elif pname == "f32":
         monkeypatch.setenv("FSKHIP_SPLIT", "1")
     g = golden()
@@ -501,7 +507,8 @@ def test_errors_are_loud():
 def test_narrow_groups_leave_every_stream_exactly_as_whole_waves_do():
     """Round 4: batches too small to give every CU a 64-stream group run the four-wave kernel in groups of 32 / 16 / 8
     streams (fskhip_blk_lanes; fsk_blk.hip, launch_demod_blk).  The state arrays are indexed by stream and the polyphase
-    registers blocked by 64, so group width must not show anywhere: 150 streams (a ragged last group at every width) with
+    registers blocked by 64, so group width must not show anywhere -- and neither must which of the two four-wave kernels ran
+    (blk_resets: the block path that takes 'eod' resets, fsk_blk.hip's blk_medium): 150 streams (a ragged last group at every width) with
     their own payloads, lead-ins, levels and noise, a ragged call schedule with AGC write-back, per width -- bytes and eod
     against the oracle, and the written-back samples, every status field and the internal state words identical to the
     whole-wave run's."""
@@ -530,8 +537,8 @@ def test_narrow_groups_leave_every_stream_exactly_as_whole_waves_do():
         want_eod.append(e)
     assert sum(len(w) for w in want) > 2 * S
     ref = None
-    for lanes in (64, 32, 16, 8, "auto"):
-        eng = wm.FSKEngine(S, cfg, precision=wm.PRECISION_F32, options={"kernel": "four-wave", "blk_lanes": lanes})
+    for lanes, resets in ((64, 0), (32, 0), (16, 1), (8, 0), ("auto", "auto"), (64, 1), (32, 2)):
+        eng = wm.FSKEngine(S, cfg, precision=wm.PRECISION_F32, options={"kernel": "four-wave", "blk_lanes": lanes, "blk_resets": resets})
         assert eng.blk_lanes() == (8 if lanes == "auto" else lanes)       # (150 streams: 19 groups of 8 on any device)
         got = [b""] * S
         eods = np.zeros(S, np.int64)
@@ -553,8 +560,8 @@ def test_narrow_groups_leave_every_stream_exactly_as_whole_waves_do():
         status = [eng.get_status(s) for s in range(S)]
         eng.close()
         for s in range(S):
-            assert got[s] == want[s], (lanes, s)
-            assert int(eods[s]) == want_eod[s], (lanes, s)
+            assert got[s] == want[s], (lanes, resets, s)
+            assert int(eods[s]) == want_eod[s], (lanes, resets, s)
         if ref is None:
             ref = (wb, state, status)
         else:
@@ -573,7 +580,7 @@ def test_options_are_validated_and_none_changes_a_result():
     from oracle import pyoracle as po
     bell = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
     for bad in ({"kernel": "fastest"}, {"blk_y_slots": "abc"}, {"blk_y_slots": 4}, {"blk_y_slots": 30}, {"blk_resident": 0},
-                {"blk_lanes": 12}, {"blk_lanes": 4}, {"blk_lanes": "wide"},
+                {"blk_lanes": 12}, {"blk_lanes": 4}, {"blk_lanes": "wide"}, {"blk_resets": 3}, {"blk_resets": "yes"},
                 {"slice_tiles": "-3"}, {"force_generic": 2}, {"no_such_option": 1}, {"host_slab": "1e9"}):
         with pytest.raises(wm.FskHipError) as ei:
             wm.FSKEngine(64, bell, options=bad)
@@ -585,7 +592,8 @@ def test_options_are_validated_and_none_changes_a_result():
     seen = set()
     for opts in ({}, {"kernel": "two-wave"}, {"kernel": "one-wave"}, {"kernel": "four-wave", "blk_y_slots": 7},
                  {"blk_resident": 2, "slice_tiles": 3}, {"force_generic": 1}, {"kernel": "auto-r02"}, {"slice_tiles": "off"},
-                 {"blk_lanes": 16}, {"blk_lanes": "auto"}, {"blk_lanes": 64, "blk_y_slots": 9}):
+                 {"blk_lanes": 16}, {"blk_lanes": "auto"}, {"blk_lanes": 64, "blk_y_slots": 9}, {"blk_resets": 1}, {"blk_resets": 0},
+                 {"blk_resets": "auto"}, {"blk_resets": 2, "blk_lanes": 32}):
         eng = wm.FSKEngine(130, bell, options=opts)
         out, eod = eng.demodulate_data(x.copy())
         assert all(b == want for b in out), opts

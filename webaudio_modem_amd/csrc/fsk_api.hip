@@ -191,7 +191,14 @@ struct fskhip_engine {
   uint32_t blk_resident = 0;     // workgroups of demod_blk_kernel the device holds at once; larger batches run it persistent, in time slices
   uint32_t blk_min_tiles = 0;    // calls with fewer whole tiles than this stay with round 2's kernels
   uint32_t blk_y_slots = 6;      // half tiles in the block kernel's y ring: as deep as the LDS allows at this batch size
-  uint32_t blk_medium = 1;       // blocks that hold an 'eod' take the block path with resets (fsk_blk.hip, blk_medium); false: the per-sample path
+  // "blk_resets": which of fsk_blk.hip's two kernels a call launches -- demod_blk_kernel_r, whose block path takes 'eod' resets
+  // itself, pays where resets are frequent (an idle receiver bank: +50 %) and costs ~4 % where they are rare.  auto: by the
+  // share of tiles the PREVIOUS call's back waves took off their fast loop (the kernels count; the totals come back with an
+  // asynchronous 8-byte copy behind every launch and are looked at, without waiting, before the next one).
+  uint32_t blk_medium = 3;       // 0 never, 1 always, 2 (tests) always + redo every such block sample by sample, 3 auto
+  bool blk_med_now = false;      // auto's current choice
+  volatile unsigned long long *h_stat = nullptr;   // pinned: {tiles, tiles off the fast loop} as the last completed copy left them
+  uint32_t stat_tiles = 0, stat_rare = 0;          // ... as of the last look
   uint32_t blk_lanes = 64;       // streams per workgroup of demod_blk_kernel: 64, or 32 / 16 / 8 for batches that leave CUs idle (fsk_blk.hip)
   uint32_t blk_slice_tiles = 0;  // tiles per time slice (0 = the kernel file's default, 0xFFFFFFFF = never slice)
   size_t host_slab = (size_t)-1; // samples per time slab of fskhip_demodulate_host's pipeline ((size_t)-1 = ~96 MB, 0 = no pipeline)
@@ -235,7 +242,19 @@ size_t engine_max_bytes(const fskhip_engine *e, size_t n_per_stream) {
 uint32_t engine_launch_key(const fskhip_engine *e) {
   return (e->ds_uniform ? 1u : 0u) | (e->ds_parity << 1) | (e->force_generic ? 4u : 0u) | (e->timing ? 8u : 0u) |
          (e->use_split ? 32u : 0u) | (e->gen_odd ? 64u : 0u) | (e->P.quality ? 256u : 0u) |
-         (e->S.trace_stream != 0xFFFFFFFFu ? 16u : 0u) | (e->use_blk ? 512u : 0u) | ((uint32_t)(e->pushes & 3u) << 10);
+         (e->S.trace_stream != 0xFFFFFFFFu ? 16u : 0u) | (e->use_blk ? 512u : 0u) | ((uint32_t)(e->pushes & 3u) << 10) |
+         ((e->blk_medium == 3u ? e->blk_med_now : e->blk_medium != 0u) ? 4096u : 0u);
+}
+// "blk_resets" = auto: tiles and tiles off the fast loop since the last look (whatever the last completed copy brought;
+// nothing new = the choice stands).  0.15: the block path with resets wins from about one tile in seven on.
+void engine_refresh_kernel_choice(fskhip_engine *e) {
+  if (e->blk_medium != 3u || !e->h_stat) return;
+  const unsigned long long hs = *e->h_stat;
+  const uint32_t tiles = (uint32_t)hs, rare = (uint32_t)(hs >> 32);
+  const uint32_t dt = tiles - e->stat_tiles, dr = rare - e->stat_rare;
+  if (dt == 0u) return;
+  e->blk_med_now = (double)dr >= 0.15 * (double)dt;
+  e->stat_tiles = tiles; e->stat_rare = rare;
 }
 void engine_note_replayed_call(fskhip_engine *e, size_t n) {
   e->calls += 1;
@@ -326,9 +345,10 @@ int fskhip_destroy(fskhip_engine *e) {
   (void)hipDeviceSynchronize();
   void *bufs[] = {e->S.rs, e->S.is, e->S.poly, e->S.amp_ring, (void *)e->S.coef, (void *)e->S.nco_inc, e->d_samples,
                   e->d_samples2, e->d_out, e->d_counts, e->d_eod, e->d_lens, e->d_payloads, e->d_status, e->d_sigma,
-                  e->S.trace_amp, e->S.trace_post, e->S.trace_bit, e->S.trace_n, e->S.poly_u, e->S.cu_ctr, e->S.blk_q, e->S.blk_stash, e->d_clock};
+                  e->S.trace_amp, e->S.trace_post, e->S.trace_bit, e->S.trace_n, e->S.poly_u, e->S.cu_ctr, e->S.blk_q, e->S.blk_stash, e->S.blk_stat, e->d_clock};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
+  if (e->h_stat) (void)hipHostFree((void *)e->h_stat);
   for (auto ev : e->ev) (void)hipEventDestroy(ev);
   for (int i = 0; i < 2; i++) {
     if (e->ev_copied[i]) (void)hipEventDestroy(e->ev_copied[i]);
@@ -611,6 +631,10 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   if (e->demod_ok && precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(P)) {
     CREATE_TRY(set_blk_lds_limit(P));
     CREATE_TRY(hipMalloc((void **)&e->S.blk_stash, sizeof(float) * 28u * (size_t)n_streams));
+    CREATE_TRY(hipMalloc((void **)&e->S.blk_stat, 2 * sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(e->S.blk_stat, 0, 2 * sizeof(uint32_t)));
+    CREATE_TRY(hipHostMalloc((void **)&e->h_stat, sizeof(unsigned long long), hipHostMallocDefault));
+    *e->h_stat = 0ull;
     e->blk_lanes = demod_blk_lanes(n_streams, device);
     demod_blk_plan(P, (n_streams + e->blk_lanes - 1u) / e->blk_lanes, device, &e->blk_y_slots, &e->blk_resident);
     if (e->blk_resident && e->n_blocks > e->blk_resident) {
@@ -675,6 +699,7 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
     return FSKHIP_OK;
   }
   if (k == "blk_resets") {      // 1: the four-wave kernel's block path takes resets (default), 0: such blocks go sample by sample
+    if (v == "auto") { e->blk_medium = 3u; return FSKHIP_OK; }
     if ((rc = number(0, 2, &x)) != FSKHIP_OK) return rc;   // (2, tests: run it, then restore the entry state and redo the block sample by sample)
     e->blk_medium = (uint32_t)x;
     return FSKHIP_OK;
@@ -803,14 +828,22 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
                               demod_blk_slices(e->P, e->S, n_fast, e->blk_resident, e->blk_slice_tiles, nullptr) >= 2u;
         if (e->use_blk && demod_blk_applicable(e->P) && blk_lds <= 160 * 1024 && (quad_aligned || e->split_forced) &&
             ((blk_fits && n_fast / 16 >= e->blk_min_tiles) || e->split_forced)) {
+          engine_refresh_kernel_choice(e);
+          uint32_t med = e->blk_medium == 3u ? (e->blk_med_now ? 1u : 0u) : e->blk_medium;
+          if (!e->P.uni_cfg) med = 0u;
           HIP_TRY(launch_demod_blk(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
-                                   e->blk_resident, e->blk_slice_tiles, e->blk_y_slots, e->blk_lanes, e->blk_medium, &e->last_sliced));
-          static const char *const names[8] = {
+                                   e->blk_resident, e->blk_slice_tiles, e->blk_y_slots, e->blk_lanes, med, &e->last_sliced));
+          if (e->blk_medium == 3u && e->h_stat && e->S.blk_stat)
+            HIP_TRY(hipMemcpyAsync((void *)e->h_stat, e->S.blk_stat, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+          static const char *const names[12] = {
               "fsk::demod_blk_kernel<false, false, false>", "fsk::demod_blk_kernel<false, false, true>",
               "fsk::demod_blk_kernel<false, true, false>", "fsk::demod_blk_kernel<false, true, true>",
               "fsk::demod_blk_kernel<true, false, false>", "fsk::demod_blk_kernel<true, false, true>",
-              "fsk::demod_blk_kernel<true, true, false>", "fsk::demod_blk_kernel<true, true, true>"};
-          e->last_kernel = names[(wb ? 4 : 0) + (e->P.uni_cfg ? 2 : 0) + (e->last_sliced ? 1 : 0)];   // <writeback, uniform, time-sliced>
+              "fsk::demod_blk_kernel<true, true, false>", "fsk::demod_blk_kernel<true, true, true>",
+              "fsk::demod_blk_kernel_r<false, false>", "fsk::demod_blk_kernel_r<false, true>",
+              "fsk::demod_blk_kernel_r<true, false>", "fsk::demod_blk_kernel_r<true, true>"};
+          e->last_kernel = med ? names[8 + (wb ? 2 : 0) + (e->last_sliced ? 1 : 0)]                  // <writeback, time-sliced>
+                               : names[(wb ? 4 : 0) + (e->P.uni_cfg ? 2 : 0) + (e->last_sliced ? 1 : 0)];   // <writeback, uniform, time-sliced>
         } else if (two_wave) {
           HIP_TRY(launch_demod_pipe(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
           e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_pipe_kernel<true, true>" : "fsk::demod_pipe_kernel<true, false>")

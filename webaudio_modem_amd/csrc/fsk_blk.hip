@@ -463,11 +463,15 @@ struct BlkSched {
                                  // per-sample path, as in round 3; 2 (tests): blk_medium, then the entry state back and the per-sample path
 };
 
-template <bool WB, bool UNI, bool SL>
-__global__ __launch_bounds__(256, 4) void demod_blk_kernel(
-    DemodParams P, DemodState S, float *__restrict__ samples, size_t n_call, size_t pitch, int append_call,
+// MED: the back wave's block path takes resets (blk_medium).  A second kernel rather than a switch inside one: the
+// straight-line path needs nearly the whole 128-register budget, and merely compiled in beside the other two it costs
+// them ~4 % where resets are rare (constants pushed out of registers, spills around it: profiles/r04_block_resets.txt).
+// The host launches demod_blk_kernel_r when the previous call's share of tiles off the fast path says it pays.
+template <bool WB, bool UNI, bool SL, bool MED>
+__device__ __forceinline__ void demod_blk_body(
+    const DemodParams &P, const DemodState &S, float *__restrict__ samples, size_t n_call, size_t pitch, int append_call,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
-    uint32_t *__restrict__ eod_counts, BlkSched Z) {
+    uint32_t *__restrict__ eod_counts, const BlkSched &Z) {
   FSK_ABL_INIT
   FSK_STAMP_DECL
   constexpr int COH = SL ? kCohSc1 : 0;           // cache policy of what a time slice hands to the next (fsk_dev.h)
@@ -914,6 +918,8 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     if (B.dph >= kHandPairs) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }   // the discriminator wave's
     BlkK Qs;
     Qs.stop_m1 = (1u << P.stop_pos) - 1u; Qs.sh9 = P.stop_pos - 9u; Qs.ff = 0xFFu;
+    BlkK Qp = Qs;
+    if (!MED) asm volatile("" : "+v"(Qp.stop_m1), "+v"(Qp.sh9), "+v"(Qp.ff));
     const FastMem &M = C.M;
     const uint32_t fld = C.fld, row4 = C.row4;
     const uint32_t phase0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(poly_phase));
@@ -946,6 +952,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     uint32_t bq = 0, nq = 0;                                  // completed bytes not yet stored (newest in the low byte)
     uint32_t *prow = poly + lane * PS;
     uint32_t yb = 0, yb_t = 0;                                // y-ring slot of half tile yb_t (kept while consecutive tiles need it)
+    uint32_t rare_tiles = 0;                                  // tiles of this item that left the fast block loop
     FSK_STAMP_BEGIN
     uint32_t t = 0;                                           // half tiles consumed (a block = a tile = two of them)
     while (t < nh) {
@@ -972,12 +979,14 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
       uint32_t hardw = 0;                                     // (looked at after the loop: its exit stays one branch)
       // the fast loop's constants live in VGPRs for the loop only (re-made from the scalars at every entry: the registers are
       // the data's in the other two paths)
-      BackK K = Ks;
-      BlkK Q = Qs;
-      if (!rare_exit) {
-        back_consts_pin(K);
-        asm volatile("" : "+v"(Q.stop_m1), "+v"(Q.sh9), "+v"(Q.ff));
+      BackK Kf = Ks;
+      BlkK Qf = Qs;
+      if (MED && !rare_exit) {
+        back_consts_pin(Kf);
+        asm volatile("" : "+v"(Qf.stop_m1), "+v"(Qf.sh9), "+v"(Qf.ff));
       }
+      const BackK &K = MED ? Kf : Kp;                         // (without blk_medium: pinned once, for the fast loop and the per-sample path)
+      const BlkK &Q = MED ? Qf : Qp;
       if (!rare_exit) for (;;) {
         v4u32 cv;
         lds_peek4_begin(ctr, cv);
@@ -1017,7 +1026,8 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
       }
       // a sync candidate, a bad start / stop bit, an amplitude ring off its quad grid: nothing but the per-sample path will do
       const bool hard_exit = amp_misaligned || __builtin_amdgcn_ballot_w64((int32_t)hardw < 0) != 0ull;
-      if (rare_exit && !hard_exit && UNI && Z.medium != 0u) {
+      if (rare_exit) rare_tiles++;
+      if (MED && rare_exit && !hard_exit && UNI && Z.medium != 0u) {
         // an 'eod' in the tile at t, or a lane inside this wave's own span after one: the block path that takes resets
         // (blk_medium), in place, the tile's entry state parked in the engine's stash
         const uint32_t slot_j = slot_i + 1u;
@@ -1131,7 +1141,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
             X.k++;
             X.kv += 1u;
             const float zph[4] = {zq[j].x, zq[j].y, zq[j].z, zq[j].w};
-            back_pair<UNI, true, false, true, COH>(B, Ks, P, S, M, &rn[j], lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
+            back_pair<UNI, true, false, true, COH>(B, MED ? Ks : Kp, P, S, M, &rn[j], lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
                                               uv[2 * j], uv[2 * j + 1], &yv[2 * j], ro[j], inc, uv[2 * j], uv[2 * j + 1], UNI ? zph : nullptr);
             amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
           }
@@ -1146,6 +1156,10 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     }
     blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
     FSK_STAMP_END(3)
+    if (lane == 0 && S.blk_stat) {                            // what the host picks the next call's kernel by
+      __hip_atomic_fetch_add(&S.blk_stat[0], (uint32_t)n_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&S.blk_stat[1], rare_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     while (produced <= nh) {
       produced = lds_peek(&ctr[2]);
       if (produced <= nh) __builtin_amdgcn_s_sleep(1);
@@ -1196,6 +1210,22 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
   }
 }
 
+template <bool WB, bool UNI, bool SL>
+__global__ __launch_bounds__(256, 4) void demod_blk_kernel(
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n_call, size_t pitch, int append_call,
+    uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
+    uint32_t *__restrict__ eod_counts, BlkSched Z) {
+  demod_blk_body<WB, UNI, SL, false>(P, S, samples, n_call, pitch, append_call, out, out_pitch, out_counts, eod_counts, Z);
+}
+// ... with the block path that takes resets (uniform configurations: its lastPhase table is the wave's)
+template <bool WB, bool SL>
+__global__ __launch_bounds__(256, 4) void demod_blk_kernel_r(
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n_call, size_t pitch, int append_call,
+    uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
+    uint32_t *__restrict__ eod_counts, BlkSched Z) {
+  demod_blk_body<WB, true, SL, true>(P, S, samples, n_call, pitch, append_call, out, out_pitch, out_counts, eod_counts, Z);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots) {
   return sizeof(float4) * (4 * kSlotStride + y_slots * 2 * 64 + kBlkSlots * kBlkSlotV4 + blk_zt_tiles(y_slots) * 8) +
@@ -1218,6 +1248,12 @@ hipError_t set_blk_lds_limit(const DemodParams &P) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   FSK_ATTR(false, false, false) FSK_ATTR(false, true, false) FSK_ATTR(true, false, false) FSK_ATTR(true, true, false)
   FSK_ATTR(false, false, true) FSK_ATTR(false, true, true) FSK_ATTR(true, false, true) FSK_ATTR(true, true, true)
+#undef FSK_ATTR
+#define FSK_ATTR(WBV, SLV)                                                                                       \
+  if (e == hipSuccess)                                                                                           \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk_kernel_r<WBV, SLV>),                      \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  FSK_ATTR(false, false) FSK_ATTR(false, true) FSK_ATTR(true, false) FSK_ATTR(true, true)
 #undef FSK_ATTR
   return e;
 }
@@ -1311,6 +1347,15 @@ hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, c
   hipLaunchKernelGGL((demod_blk_kernel<WBV, UNIV, SLV>), dim3(grid), dim3(256), lds, stream, P, S, samples, n, pitch, \
                      append ? 1 : 0, out, out_pitch, out_counts, eod_counts, Z)
   const bool uni = P.uni_cfg != 0;
+#define FSK_LAUNCH_BLKR(WBV, SLV)                                                                               \
+  hipLaunchKernelGGL((demod_blk_kernel_r<WBV, SLV>), dim3(grid), dim3(256), lds, stream, P, S, samples, n, pitch, \
+                     append ? 1 : 0, out, out_pitch, out_counts, eod_counts, Z)
+  if (uni && medium != 0u) {
+    if (sliced) { if (writeback) FSK_LAUNCH_BLKR(true, true); else FSK_LAUNCH_BLKR(false, true); }
+    else { if (writeback) FSK_LAUNCH_BLKR(true, false); else FSK_LAUNCH_BLKR(false, false); }
+    return hipGetLastError();
+  }
+#undef FSK_LAUNCH_BLKR
   if (sliced) {
     if (writeback) { if (uni) FSK_LAUNCH_BLK(true, true, true); else FSK_LAUNCH_BLK(true, false, true); }
     else { if (uni) FSK_LAUNCH_BLK(false, true, true); else FSK_LAUNCH_BLK(false, false, true); }

@@ -153,6 +153,8 @@ struct DemodState {
   uint32_t *cu_ctr;       // u32 [2048]: workgroups started per compute unit (fsk_blk.hip spreads its waves' roles with it)
   float *blk_stash;       // f32 [7][n_streams][4] or null: fsk_blk.hip's block path with resets parks a lane's entry state here
                           // (written per such block, read back only when the block has to be redone sample by sample)
+  uint32_t *blk_stat;     // u32 [2] or null: tiles fsk_blk.hip's back waves have processed, and how many of them left the fast block loop
+                          // (running totals; the host picks the next call's kernel by their increments)
   uint32_t *blk_q;        // u32 [16 + groups * 127] or null: fsk_blk.hip's (group, time slice) queue for batches beyond one round
 };
 

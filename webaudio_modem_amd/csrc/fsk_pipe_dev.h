@@ -54,6 +54,12 @@ static __device__ unsigned long long g_stamp[4 * 2048 * 8];   // [wave][group][w
 #define FSK_STAMP_END(w)
 #endif
 
+#ifndef FSK_AB_OLDHAND
+#define FSK_AB_OLDHAND 0
+#endif
+#ifndef FSK_AB_OLDCNT
+#define FSK_AB_OLDCNT 0
+#endif
 #ifndef FSK_PIPE_SLOTS
 #define FSK_PIPE_SLOTS 4
 #endif
@@ -359,10 +365,22 @@ __device__ inline void zir_step(BackLane &B, const BackK &K, BackU &X, float Ui,
           // kHandLag steps of the recurrence alone: posted are the start values and the step count, and the discriminator
           // wave -- the one with time to spare wherever resets are frequent -- runs the steps when it takes them (round 4;
           // the back wave used to, ~100 instructions of the wave that paces an idle receiver bank, per reset)
+#if FSK_AB_OLDHAND
+          float ai = B.qai, aq = B.qaq, bi = B.qbi, bq = B.qbq;
+          for (uint32_t g = 0; g < kHandLag; g++) {
+            const float ni = __builtin_fmaf(K.c1, bi, -(K.c2 * ai)), nq = __builtin_fmaf(K.c1, bq, -(K.c2 * aq));
+            ai = bi; aq = bq; bi = ni; bq = nq;
+          }
+          X.cmail[64u + lane] = __builtin_bit_cast(uint32_t, ai); X.cmail[128u + lane] = __builtin_bit_cast(uint32_t, aq);
+          X.cmail[192u + lane] = __builtin_bit_cast(uint32_t, bi); X.cmail[256u + lane] = __builtin_bit_cast(uint32_t, bq);
+          X.cmail[384u + lane] = 0u;
+          X.cmail[lane] = X.k + kHandLag;
+#else
           X.cmail[64u + lane] = __builtin_bit_cast(uint32_t, B.qai); X.cmail[128u + lane] = __builtin_bit_cast(uint32_t, B.qaq);
           X.cmail[192u + lane] = __builtin_bit_cast(uint32_t, B.qbi); X.cmail[256u + lane] = __builtin_bit_cast(uint32_t, B.qbq);
           X.cmail[384u + lane] = kHandLag;
           X.cmail[lane] = X.k + kHandLag;
+#endif
         }
       }
       B.dph += 1u;
@@ -470,7 +488,11 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
                               pushes < P.amp_cap ? pushes : P.amp_cap);
       }
       if (eod) {
+#if FSK_AB_OLDCNT
+        ist_store<COH>(M, IF_eod_total, ist_load<COH>(M, IF_eod_total) + 1u);
+#else
         ist_add<COH>(M, IF_eod_total, 1u);
+#endif
         if (eod_counts && M.voff < 0xFFFFFFF0u) __hip_atomic_fetch_add(&eod_counts[M.voff >> 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         back_reset<UNI, COH>(B, P, M, X, inc, lane);
       }

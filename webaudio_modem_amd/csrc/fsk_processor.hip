@@ -26,6 +26,7 @@ const ModParams &engine_mod_params(const fskhip_engine *e);
 const double *engine_coef(const fskhip_engine *e);
 size_t engine_max_bytes(const fskhip_engine *e, size_t n_per_stream);
 uint32_t engine_launch_key(const fskhip_engine *e);       // changes whenever the demodulator would launch differently
+void engine_refresh_kernel_choice(fskhip_engine *e);     // "blk_resets" = auto: look at the tile statistics the last completed call left
 void engine_note_replayed_call(fskhip_engine *e, size_t n);  // host-side counters of a call replayed from a graph
 }  // namespace fsk
 
@@ -178,6 +179,7 @@ int fskhip_processor_process_device(fskhip_processor *p, float *d_in, size_t n_i
     }
   }
   // timing events / the trace capture are per-launch host decisions: no replay while either is armed
+  engine_refresh_kernel_choice(p->e);
   if (engine_launch_key(p->e) & (8u | 16u)) flags &= ~FSKHIP_PROC_GRAPH;
   if (!(flags & FSKHIP_PROC_GRAPH)) return launch_quantum(p, d_in, n_in, in_pitch, d_out, n_out, out_pitch, flags, st);
 
