@@ -93,6 +93,7 @@ def main(budget=None, seed=None, max_rounds=None):
     if seed is None:
         seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0x50A4
     rng = np.random.default_rng(seed)
+    rng2 = np.random.default_rng(seed ^ 0x5EED4)
     t_end = time.time() + budget
     rounds = streams = 0
     while time.time() < t_end and (max_rounds is None or rounds < max_rounds):
@@ -106,6 +107,10 @@ def main(budget=None, seed=None, max_rounds=None):
             prec = int(os.environ["SOAK_FORCE_PREC"])
         S = int(rng.choice([1, 2, 63, 64, 65, 100, 130, 192, 257]))
         os.environ["FSKHIP_SPLIT"] = "014"[int(rng.integers(3))]   # one / two / four waves per 64-stream group
+        # round 4: which four-wave kernel (block path with resets: never / always / always + redo / by the statistics) and its
+        # group width -- drawn from a generator of their own, so that earlier rounds' seeds still replay the same signals
+        os.environ["FSKHIP_BLK_RESETS"] = ["auto", "0", "1", "2", "1"][int(rng2.integers(5))]
+        os.environ["FSKHIP_BLK_LANES"] = ["auto", "64", "16"][int(rng2.integers(3))]
         if target and os.environ.get("SOAK_FORCE_SPLIT"):
             os.environ["FSKHIP_SPLIT"] = os.environ["SOAK_FORCE_SPLIT"]
         os.environ["FSKHIP_SPLIT_LAST"] = os.environ["FSKHIP_SPLIT"]
