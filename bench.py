@@ -453,6 +453,11 @@ def worker(args):
         torch.cuda.synchronize()
 
     elapsed, n_launch, kernel_ms = measure(sync, dist, eng, step, args.steps, args.warmup, dev)
+    if not dry:
+        # the kernel the TIMED launches ran (the engine picks between its two four-wave kernels by the previous call's tile
+        # statistics: the first pass above always runs the plain one)
+        kernel_name = eng.last_kernel()
+        lanes_main = eng.blk_lanes() if "demod_blk_kernel" in kernel_name else None
 
     # ---- the shader clock the device holds under this load: a one-wave probe (fskhip_clock_probe_*) started
     # first, a few more steps of the same work behind it.  Outside the timed region on purpose: the probe's wave takes a slot

@@ -244,23 +244,33 @@ __device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &
   uint32_t w = 0, hard = 0;
   uint32_t matched = Bn.matched, thr_cur = Bn.thr_eff, ls = Bn.ls;
   E.jr = 0; E.jc = 0; E.cai = E.caq = E.cbi = E.cbq = 0.f;
+  // two decimated samples' inputs at a time: ring entries (pair sums where the lane's span is this wave's, else phase and
+  // magnitude), the four pre-filter outputs behind them, the two polyphase registers (not kept: the caller re-forms the new
+  // ones from the old ones and the block's slicer bits), the phasors.  Read one pair AHEAD of the arithmetic (the wave runs
+  // alone: an LDS round trip it waits for is ~120 cycles of nothing); the fences keep the compiler from reading all eight
+  // samples' inputs up front -- 40 registers it does not have.
+  v4f pe_n = slot[lane], ye_n = ys0[lane], zz0_n = ztile[0], zz1_n = ztile[1];
+  uint2 rp_n = *reinterpret_cast<const uint2 *>(prow + pidx);
 #pragma unroll
   for (int jj = 0; jj < kBlk / 2; jj++) {
-    // two decimated samples' inputs: ring entries (pair sums where the lane's span is this wave's, else phase and magnitude),
-    // the four pre-filter outputs behind them, the two polyphase registers (not kept: the caller re-forms the new ones
-    // from the old ones and the block's slicer bits).  The fence keeps the compiler from reading all eight samples' inputs
-    // up front: 40 registers it does not have.
+    const v4f pe = pe_n, ye2 = ye_n, zz0 = zz0_n, zz1 = zz1_n;
+    const uint2 rp2 = rp_n;
     asm volatile("" ::: "memory");
-    const v4f pe = (jj < 2 ? slot : slot2)[(jj & 1) * 64 + (int)lane];
-    const v4f ye2 = (jj < 2 ? ys0 : ys1)[(jj & 1) * 64 + (int)lane];
-    const uint2 rp2 = *reinterpret_cast<const uint2 *>(prow + (jj < 2 ? pidx : pidx2) + 2 * (jj & 1));
+    if (jj + 1 < kBlk / 2) {
+      const int jn = jj + 1;
+      pe_n = (jn < 2 ? slot : slot2)[(jn & 1) * 64 + (int)lane];
+      ye_n = (jn < 2 ? ys0 : ys1)[(jn & 1) * 64 + (int)lane];
+      rp_n = *reinterpret_cast<const uint2 *>(prow + (jn < 2 ? pidx : pidx2) + 2 * (jn & 1));
+      zz0_n = ztile[2 * jn]; zz1_n = ztile[2 * jn + 1];
+    }
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int h = 0; h < 2; h++) {
     const int j = 2 * jj + h;
     const float e0 = h ? pe.z : pe.x, e1 = h ? pe.w : pe.y;
     const float y0 = h ? ye2.z : ye2.x, y1 = h ? ye2.w : ye2.y;
     const uint32_t kvj = kv0 + (uint32_t)(j + 1);
-    const v4f z = ztile[j];                                                  // (c0, s0, c1, s1) of the pair's two input samples
+    const v4f z = h ? zz1 : zz0;                                             // (c0, s0, c1, s1) of the pair's two input samples
     // ---- zir_step<UNI, HAND = true>, flat
     const uint32_t dph0 = Bn.dph;
     float wi = e0 - Bn.qai, wq = e1 - Bn.qaq;
