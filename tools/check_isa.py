@@ -164,7 +164,7 @@ def pipe_prefetch_hazards(symbol=r"_ZN3fsk17demod_pipe_kernel"):
 
 
 def blk_checks():
-    """fsk_blk.hip (four waves per group): eight kernel bodies (<write-back, uniform, time-sliced>), each within 128
+    """fsk_blk.hip (four waves per group): eight + four kernel bodies (<write-back, uniform, time-sliced>), each within 128
     VGPRs (four workgroups per CU).  The kernel is built with __launch_bounds__(256, 4) and spills in its set-up and in the
     per-sample slow path; the loops that run per tile must not: every block of the innermost loop around each of the four
     parts' asynchronous counter read (lds_peek4_begin: an asm ds_read_b128) has to be free of scratch instructions.  And
@@ -185,10 +185,11 @@ def blk_checks():
         return out
 
     problems = []
-    found = list(re.finditer(r"^(_ZN3fsk16demod_blk_kernel\w+):[^\n]*\n", text, re.M))
-    if len(found) != 8:
-        problems.append(("demod_blk_kernel", "expected 8 kernel bodies in the ISA, found %d" % len(found)))
-    for name, n in re.findall(r"\.name:\s+(_ZN3fsk16demod_blk_kernel\w+)\s*\n(?:[^\n]*\n)*?\s+\.vgpr_count:\s+(\d+)", text):
+    # (round 4: plus the four bodies of demod_blk_kernel_r<write-back, time-sliced>, the kernel whose block path takes resets)
+    found = list(re.finditer(r"^(_ZN3fsk1[68]demod_blk_kernel(?:_r)?I\w+):[^\n]*\n", text, re.M))
+    if len(found) != 12:
+        problems.append(("demod_blk_kernel", "expected 8 + 4 kernel bodies in the ISA, found %d" % len(found)))
+    for name, n in re.findall(r"\.name:\s+(_ZN3fsk1[68]demod_blk_kernel(?:_r)?I\w+)\s*\n(?:[^\n]*\n)*?\s+\.vgpr_count:\s+(\d+)", text):
         if int(n) > 128:
             problems.append((name, "%s VGPRs: more than four workgroups per CU allow" % n))
     for m in found:
@@ -222,6 +223,10 @@ def blk_checks():
                     problems.append((m.group(1), "counter read outside any loop: " + st))
                     continue
                 for o in blocks:
+                    # (demod_blk_kernel_r is for calls whose tiles mostly leave the fast loop: its guard is blk_medium's
+                    # block below; its time-sliced instantiation reloads one register per fast tile)
+                    if "demod_blk_kernel_r" in m.group(1):
+                        break
                     if o["loop"] == b["loop"] and any(x.startswith("scratch_") for _, x in o["lines"]):
                         problems.append((m.group(1), "scratch access in a per-tile loop, block %s" % o["name"]))
                 dst = regs_of(st.split(",")[0])
@@ -234,6 +239,19 @@ def blk_checks():
                     if regs_of(line) & dst:
                         problems.append((m.group(1), "counter read's registers touched before a wait: " + line))
                         break
+        if "demod_blk_kernel_r" in m.group(1):
+            # blk_medium: one straight-line basic block of ~1 400 instructions, hand-kept free of scratch traffic (its
+            # inputs are read a sample pair ahead, its event captures pinned, the entry state parked in the engine's stash)
+            big = [b for b in blocks if len(b["lines"]) > 1000]
+            if len(big) != 1:
+                problems.append((m.group(1), "expected blk_medium as ONE basic block of > 1000 instructions, found %d" % len(big)))
+            # (the time-sliced instantiations carry the queue's bookkeeping too and reload a piece of the lane state at the
+            # block's top: three loads and a store, one round trip per block, tolerated; the plain ones must have none)
+            allowed = 4 if re.search(r"kernel_rILb[01]ELb1E", m.group(1)) else 0
+            for b in big:
+                n_scr = sum(1 for _, x in b["lines"] if x.startswith("scratch_"))
+                if n_scr > allowed:
+                    problems.append((m.group(1), "%d scratch accesses inside blk_medium's block %s (allowed: %d)" % (n_scr, b["name"], allowed)))
         if peeks < 4:   # (the compiler duplicates the back wave's block loop: six sites in the current build)
             problems.append((m.group(1), "expected at least 4 asynchronous counter reads (one per part), found %d" % peeks))
     return problems

@@ -990,13 +990,10 @@ __device__ __forceinline__ void demod_blk_body(
       // the fast loop's constants live in VGPRs for the loop only (re-made from the scalars at every entry: the registers are
       // the data's in the other two paths)
       BackK Kf = Ks;
-      BlkK Qf = Qs;
-      if (MED && !rare_exit) {
-        back_consts_pin(Kf);
-        asm volatile("" : "+v"(Qf.stop_m1), "+v"(Qf.sh9), "+v"(Qf.ff));
-      }
+      if (MED && !rare_exit) back_consts_pin(Kf);             // (the bit clock's three constants stay scalars in this kernel: the
+                                                              // time-sliced instantiation's fast loop was one register short)
       const BackK &K = MED ? Kf : Kp;                         // (without blk_medium: pinned once, for the fast loop and the per-sample path)
-      const BlkK &Q = MED ? Qf : Qp;
+      const BlkK &Q = MED ? Qs : Qp;
       if (!rare_exit) for (;;) {
         v4u32 cv;
         lds_peek4_begin(ctr, cv);
