@@ -414,7 +414,22 @@ struct QLane { float ai, aq, bi, bq; };
 #ifndef FSK_BLK_PRIO_PERIOD
 #define FSK_BLK_PRIO_PERIOD 64
 #endif
+// BYROLE (demod_blk_kernel_r): fixed levels by part instead, the back wave highest -- in the calls that kernel is picked for
+// the back wave IS the group's time and the other three mostly wait; measured on the idle bank 291 -> 312 Gsamples/s
+// (and the rotation, which evens out four equally loaded groups of a CU, has nothing to even out there).
+template <bool BYROLE = false>
 __device__ inline void blk_prio(uint32_t hidx, uint32_t wgj, uint32_t role = 0) {
+  if (BYROLE) {
+    if (hidx == 0u) {
+      switch (role) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+      }
+    }
+    return;
+  }
 #if FSK_BLK_PRIO == 1
   if ((hidx & (FSK_BLK_PRIO_PERIOD - 1u)) == 0u) {
     switch (((hidx / FSK_BLK_PRIO_PERIOD) + wgj) & 3u) {
@@ -696,7 +711,7 @@ __device__ __forceinline__ void demod_blk_body(
     const uint32_t nt = (uint32_t)n_tiles;
     FSK_STAMP_BEGIN
     for (uint32_t t0 = 0; t0 < nt; t0 += 96u) {             // (a multiple of three tiles and of 64 half tiles)
-      blk_prio(2u * t0, wgj, 0u);
+      blk_prio<MED>(2u * t0, wgj, 0u);
       const uint32_t te = t0 + 96u < nt ? t0 + 96u : nt;
       for (uint32_t t = t0; t < te; t += 3) {
         do_tile(t, a0, a1, a2, a3);
@@ -733,7 +748,7 @@ __device__ __forceinline__ void demod_blk_body(
     FSK_STAMP_BEGIN
     uint32_t hidx = 0;                                        // half tiles done; this wave works a tile (two of them) at a time
     while (hidx < nh) {
-      if ((hidx & 63u) == 0u) blk_prio(hidx, wgj, 1u);
+      if ((hidx & 63u) == 0u) blk_prio<MED>(hidx, wgj, 1u);
       if (produced < hidx + 2u || hidx + 2u - consumed > kBlkSlots) {
         FSK_STAMP_W0
         while (produced < hidx + 2u) {                        // wave 0's tile
@@ -839,7 +854,7 @@ __device__ __forceinline__ void demod_blk_body(
     FSK_STAMP_BEGIN
     uint32_t hidx = 0;                                        // half tiles done; a tile (two of them, eight decimated samples) at a time
     while (hidx < nh) {
-      if ((hidx & 63u) == 0u) blk_prio(hidx, wgj, 2u);
+      if ((hidx & 63u) == 0u) blk_prio<MED>(hidx, wgj, 2u);
       if (produced < hidx + 2u) {
         FSK_STAMP_W0
         while (produced < hidx + 2u) {
@@ -966,7 +981,7 @@ __device__ __forceinline__ void demod_blk_body(
     FSK_STAMP_BEGIN
     uint32_t t = 0;                                           // half tiles consumed (a block = a tile = two of them)
     while (t < nh) {
-      blk_prio(t & ~15u, wgj, 3u);                            // (t advances in steps of two; the outer loop sees every multiple of 16)
+      blk_prio<MED>(t & ~15u, wgj, 3u);                            // (t advances in steps of two; the outer loop sees every multiple of 16)
       if (produced < t + 2u) {
         FSK_STAMP_W0
         while (produced < t + 2u) {
