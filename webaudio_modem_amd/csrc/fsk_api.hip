@@ -199,6 +199,7 @@ struct fskhip_engine {
   bool blk_med_now = false;      // auto's current choice
   volatile unsigned long long *h_stat = nullptr;   // pinned: {tiles, tiles off the fast loop} as the last completed copy left them
   uint32_t stat_tiles = 0, stat_rare = 0;          // ... as of the last look
+  uint32_t stat_skip = 0;                          // short calls since the last fetch
   uint32_t blk_lanes = 64;       // streams per workgroup of demod_blk_kernel: 64, or 32 / 16 / 8 for batches that leave CUs idle (fsk_blk.hip)
   uint32_t blk_slice_tiles = 0;  // tiles per time slice (0 = the kernel file's default, 0xFFFFFFFF = never slice)
   size_t host_slab = (size_t)-1; // samples per time slab of fskhip_demodulate_host's pipeline ((size_t)-1 = ~96 MB, 0 = no pipeline)
@@ -245,15 +246,17 @@ uint32_t engine_launch_key(const fskhip_engine *e) {
          (e->S.trace_stream != 0xFFFFFFFFu ? 16u : 0u) | (e->use_blk ? 512u : 0u) | ((uint32_t)(e->pushes & 3u) << 10) |
          ((e->blk_medium == 3u ? e->blk_med_now : e->blk_medium != 0u) ? 4096u : 0u);
 }
-// "blk_resets" = auto: tiles and tiles off the fast loop since the last look (whatever the last completed copy brought;
-// nothing new = the choice stands).  0.15: the block path with resets wins from about one tile in seven on.
+// "blk_resets" = auto: tiles, and tiles the block path with resets took or would be given, of a sample of the groups since the
+// last look (whatever the last completed copy brought; nothing new = the choice stands).  It wins from about one tile in six on.
 void engine_refresh_kernel_choice(fskhip_engine *e) {
   if (e->blk_medium != 3u || !e->h_stat) return;
   const unsigned long long hs = *e->h_stat;
   const uint32_t tiles = (uint32_t)hs, rare = (uint32_t)(hs >> 32);
   const uint32_t dt = tiles - e->stat_tiles, dr = rare - e->stat_rare;
   if (dt == 0u) return;
-  e->blk_med_now = (double)dr >= 0.15 * (double)dt;
+  // (with hysteresis: the two kernels count slightly different things -- the plain one cannot tell whether a tile it sends
+  // down its per-sample path because of a lane's own span also holds a sync candidate)
+  e->blk_med_now = (double)dr >= (e->blk_med_now ? 0.10 : 0.20) * (double)dt;
   e->stat_tiles = tiles; e->stat_rare = rare;
 }
 void engine_note_replayed_call(fskhip_engine *e, size_t n) {
@@ -833,7 +836,9 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
           if (!e->P.uni_cfg) med = 0u;
           HIP_TRY(launch_demod_blk(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
                                    e->blk_resident, e->blk_slice_tiles, e->blk_y_slots, e->blk_lanes, med, &e->last_sliced));
-          if (e->blk_medium == 3u && e->h_stat && e->S.blk_stat)
+          // (the totals are fetched behind every long call, behind every eighth of a run of short ones: the copy is ~3 us of
+          // the stream's time, 7 % of a 128-sample call of 65 536 streams)
+          if (e->blk_medium == 3u && e->h_stat && e->S.blk_stat && (n_fast >= 4096 || (++e->stat_skip & 7u) == 0u))
             HIP_TRY(hipMemcpyAsync((void *)e->h_stat, e->S.blk_stat, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
           static const char *const names[12] = {
               "fsk::demod_blk_kernel<false, false, false>", "fsk::demod_blk_kernel<false, false, true>",

@@ -977,7 +977,7 @@ __device__ __forceinline__ void demod_blk_body(
     uint32_t bq = 0, nq = 0;                                  // completed bytes not yet stored (newest in the low byte)
     uint32_t *prow = poly + lane * PS;
     uint32_t yb = 0, yb_t = 0;                                // y-ring slot of half tile yb_t (kept while consecutive tiles need it)
-    uint32_t rare_tiles = 0;                                  // tiles of this item that left the fast block loop
+    uint32_t rare_tiles = 0;                                  // tiles of this item that blk_medium took, or would be given
     FSK_STAMP_BEGIN
     uint32_t t = 0;                                           // half tiles consumed (a block = a tile = two of them)
     while (t < nh) {
@@ -1048,7 +1048,7 @@ __device__ __forceinline__ void demod_blk_body(
       }
       // a sync candidate, a bad start / stop bit, an amplitude ring off its quad grid: nothing but the per-sample path will do
       const bool hard_exit = amp_misaligned || __builtin_amdgcn_ballot_w64((int32_t)hardw < 0) != 0ull;
-      if (rare_exit) rare_tiles++;
+      if (!MED && rare_exit && !hard_exit) rare_tiles++;       // (a tile blk_medium would be given)
       if (MED && rare_exit && !hard_exit && UNI && Z.medium != 0u) {
         // an 'eod' in the tile at t, or a lane inside this wave's own span after one: the block path that takes resets
         // (blk_medium), in place, the tile's entry state parked in the engine's stash
@@ -1131,6 +1131,7 @@ __device__ __forceinline__ void demod_blk_body(
           X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) != 0ull ? kDirectPairs : 0u;
           lds_post(&ctr[3], t);
           rare_exit = false;
+          rare_tiles++;                                         // (a tile blk_medium took)
         }
       }
       if (rare_exit) {
@@ -1178,7 +1179,9 @@ __device__ __forceinline__ void demod_blk_body(
     }
     blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
     FSK_STAMP_END(3)
-    if (lane == 0 && S.blk_stat) {                            // what the host picks the next call's kernel by
+    // what the host picks the next call's kernel by: a sample -- every 64th group reports (two atomics on two words from every
+    // workgroup of a launch serialise at one L2 channel: +16 us on a 40-us call of 65 536 streams x 128 samples)
+    if (lane == 0 && S.blk_stat && (grp & 63u) == 0u) {
       __hip_atomic_fetch_add(&S.blk_stat[0], (uint32_t)n_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(&S.blk_stat[1], rare_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
