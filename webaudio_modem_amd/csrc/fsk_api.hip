@@ -838,8 +838,14 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
                                    e->blk_resident, e->blk_slice_tiles, e->blk_y_slots, e->blk_lanes, med, &e->last_sliced));
           // (the totals are fetched behind every long call, behind every eighth of a run of short ones: the copy is ~3 us of
           // the stream's time, 7 % of a 128-sample call of 65 536 streams)
-          if (e->blk_medium == 3u && e->h_stat && e->S.blk_stat && (n_fast >= 4096 || (++e->stat_skip & 7u) == 0u))
-            HIP_TRY(hipMemcpyAsync((void *)e->h_stat, e->S.blk_stat, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+          if (e->blk_medium == 3u && e->h_stat && e->S.blk_stat) {
+            bool fetch = n_fast >= 4096 || (++e->stat_skip & 7u) == 0u;
+            if (!fetch) {                                      // (a call being captured into a graph is replayed many times: it fetches)
+              hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+              fetch = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+            }
+            if (fetch) HIP_TRY(hipMemcpyAsync((void *)e->h_stat, e->S.blk_stat, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+          }
           static const char *const names[12] = {
               "fsk::demod_blk_kernel<false, false, false>", "fsk::demod_blk_kernel<false, false, true>",
               "fsk::demod_blk_kernel<false, true, false>", "fsk::demod_blk_kernel<false, true, true>",
