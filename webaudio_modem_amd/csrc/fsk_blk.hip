@@ -873,9 +873,12 @@ __device__ __forceinline__ void demod_blk_body(
         slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
         v4f *slot2 = ring + slot_i * kBlkSlotV4;
         slot_i = slot_i + 1u == kBlkSlots ? 0u : slot_i + 1u;
-        const v4f ua = slot[lane], ub = slot[64u + lane], uc = slot2[lane], ud = slot2[64u + lane];
+        // (the two mailbox words first, fenced: LDS answers in order, and the one test below that needs them then waits for
+        // them alone while the tile's ring entries are still on their way -- the compiler, left alone, put them last)
         const uint32_t kq = cmail[lane];
         const uint32_t ow = 4u * hidx - cmail[320u + lane];     // decimated samples since the back wave's own span began
+        asm volatile("" ::: "memory");
+        const v4f ua = slot[lane], ub = slot[64u + lane], uc = slot2[lane], ud = slot2[64u + lane];
         const float ui[8] = {ua.x, ua.z, ub.x, ub.z, uc.x, uc.z, ud.x, ud.z}, uq[8] = {ua.y, ua.w, ub.y, ub.w, uc.y, uc.w, ud.y, ud.w};
         float ph[8], am[8];
         // one test for everything that is not the plain discriminator: a hand-over due in this tile, a lane inside the
@@ -1047,8 +1050,11 @@ __device__ __forceinline__ void demod_blk_body(
         if (!(t < lim)) break;
       }
       // a sync candidate, a bad start / stop bit, an amplitude ring off its quad grid: nothing but the per-sample path will do
-      const bool hard_exit = amp_misaligned || __builtin_amdgcn_ballot_w64((int32_t)hardw < 0) != 0ull;
-      if (!MED && rare_exit && !hard_exit) rare_tiles++;       // (a tile blk_medium would be given)
+      const bool hard_exit = MED && (amp_misaligned || __builtin_amdgcn_ballot_w64((int32_t)hardw < 0) != 0ull);
+      // (a tile blk_medium would be given: counted are those inside a lane's own span -- six for every reset -- because telling an
+      // 'eod' from a sync candidate at the fast loop's exit would keep blk_fast's second flag word alive in this kernel: 3.6 % at
+      // 8 192 streams)
+      if (!MED && rare_exit && X.zlive != 0u) rare_tiles++;
       if (MED && rare_exit && !hard_exit && UNI && Z.medium != 0u) {
         // an 'eod' in the tile at t, or a lane inside this wave's own span after one: the block path that takes resets
         // (blk_medium), in place, the tile's entry state parked in the engine's stash
