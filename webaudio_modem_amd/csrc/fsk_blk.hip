@@ -46,7 +46,8 @@
 // Batches beyond one round of resident workgroups run persistently over (group, time slice) items: BlkSched below.
 // LDS: stage [4][65] v4f (the final-state hand-over fin [3][64] over it) | yring [y_slots][2][64] v4f, y_slots = 6 .. 28 by
 //      what the batch leaves (demod_blk_plan) | xring [6][2][64] v4f | zt [8 or 16][8] v4f | poly [64][PS] u32 |
-//      counters [8] | zmail [64] u32 | cmail [7][64] u32
+//      counters [8] | zmail [64] u32 | cmail [6][64] u32   (not a byte more: 256 B more per workgroup cost config #3 2 %,
+//      profiles/r04_block_resets.txt section 11)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -513,9 +514,9 @@ __device__ __forceinline__ void demod_blk_body(
   uint32_t *poly = reinterpret_cast<uint32_t *>(zt + Z.zt_tiles * 8);   // [lane][PS], index 0 = the phase of the launch's first push
   uint32_t *ctr = poly + 64u * PS;                        // produced by wave 0, 1, 2 | consumed by wave 3 | [4] CU arrival | [5] item
   uint32_t *zmail = ctr + 8;                              // back -> wave 1: where to zero a lane's I/Q low-pass
-  uint32_t *cmail = zmail + 64;                           // back -> wave 2: [0] from which decimated sample, [1..4] the correction [6] steps
-                                                          // of its recurrence before that, [5] since which sample the back wave wants a
-                                                          // lane's pair sums kept
+  uint32_t *cmail = zmail + 64;                           // back -> wave 2: [0] from which decimated sample, [1..4] the correction kHandLag
+                                                          // steps of its recurrence before that (or there, if [0] <= kHandLag), [5] since
+                                                          // which sample the back wave wants a lane's pair sums kept
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t lane = threadIdx.x & 63u;
 
@@ -613,13 +614,18 @@ __device__ __forceinline__ void demod_blk_body(
     const uint32_t dph = PIPE_ILOAD(zr_dph);
     uint32_t kq = 0xFFFFFFFFu;
     float ai = 0.f, aq = 0.f, bi = 0.f, bq = 0.f;
-    if (dph >= kDirectPairs && dph < kHandPairs) {            // (the values as they stand and how many steps are left: see zir_step)
+    if (dph >= kDirectPairs && dph < kHandPairs) {            // (the steps that are left run here, once per launch: kq <= kHandLag
+                                                              // tells the taker that the values are final -- see zir_step)
       ai = PIPE_RLOAD(zq_ai); aq = PIPE_RLOAD(zq_aq); bi = PIPE_RLOAD(zq_bi); bq = PIPE_RLOAD(zq_bq);
+      const float c1 = P.z_c1, c2 = P.z_c2;
+      for (uint32_t g = dph; g < kHandPairs; g++) {
+        const float ni = __builtin_fmaf(c1, bi, -(c2 * ai)), nq = __builtin_fmaf(c1, bq, -(c2 * aq));
+        ai = bi; aq = bq; bi = ni; bq = nq;
+      }
       kq = kHandPairs - dph;
     }
     cmail[64u + lane] = __builtin_bit_cast(uint32_t, ai); cmail[128u + lane] = __builtin_bit_cast(uint32_t, aq);
     cmail[192u + lane] = __builtin_bit_cast(uint32_t, bi); cmail[256u + lane] = __builtin_bit_cast(uint32_t, bq);
-    cmail[384u + lane] = kq == 0xFFFFFFFFu ? 0u : kq;
     cmail[lane] = kq;
     cmail[320u + lane] = 0u - dph;                          // (dph >= kHandPairs: the span is over)
   }
@@ -890,7 +896,7 @@ __device__ __forceinline__ void demod_blk_body(
           if (kq - 4u * hidx < 8u) {
             H.ai = __builtin_bit_cast(float, cmail[64u + lane]); H.aq = __builtin_bit_cast(float, cmail[128u + lane]);
             H.bi = __builtin_bit_cast(float, cmail[192u + lane]); H.bq = __builtin_bit_cast(float, cmail[256u + lane]);
-            const uint32_t steps = cmail[384u + lane];
+            const uint32_t steps = kq > kHandLag ? kHandLag : 0u;   // (posted inside this launch: kHandLag steps before its sample)
             for (uint32_t g = 0; g < steps; g++) {
               const float ni = __builtin_fmaf(c1, H.bi, -(c2 * H.ai)), nq = __builtin_fmaf(c1, H.bq, -(c2 * H.aq));
               H.ai = H.bi; H.aq = H.bq; H.bi = ni; H.bq = nq;
@@ -1116,7 +1122,6 @@ __device__ __forceinline__ void demod_blk_body(
             if (E.jc != 0u) {                                  // (zir_step: the correction's start values, for the discriminator wave)
               cmail[64u + lane] = __builtin_bit_cast(uint32_t, E.cai); cmail[128u + lane] = __builtin_bit_cast(uint32_t, E.caq);
               cmail[192u + lane] = __builtin_bit_cast(uint32_t, E.cbi); cmail[256u + lane] = __builtin_bit_cast(uint32_t, E.cbq);
-              cmail[384u + lane] = kHandLag;
               cmail[lane] = k0 + E.jc + kHandLag;
             }
             if (E.jr != 0u) {                                  // (back_pair's 'eod' + back_reset)
@@ -1213,7 +1218,7 @@ __device__ __forceinline__ void demod_blk_body(
       if (cmail[lane] == X.k) {
         B.qai = __builtin_bit_cast(float, cmail[64u + lane]); B.qaq = __builtin_bit_cast(float, cmail[128u + lane]);
         B.qbi = __builtin_bit_cast(float, cmail[192u + lane]); B.qbq = __builtin_bit_cast(float, cmail[256u + lane]);
-        const uint32_t steps = cmail[384u + lane];             // (what the discriminator wave would have run on taking them)
+        const uint32_t steps = X.k > kHandLag ? kHandLag : 0u;   // (what the discriminator wave would have run on taking them)
         for (uint32_t g = 0; g < steps; g++) {
           const float ni = __builtin_fmaf(Ks.c1, B.qbi, -(Ks.c2 * B.qai)), nq = __builtin_fmaf(Ks.c1, B.qbq, -(Ks.c2 * B.qaq));
           B.qai = B.qbi; B.qaq = B.qbq; B.qbi = ni; B.qbq = nq;
@@ -1260,7 +1265,7 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel_r(
 // ---- host side ---------------------------------------------------------------------------------------------------
 size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots) {
   return sizeof(float4) * (4 * kSlotStride + y_slots * 2 * 64 + kBlkSlots * kBlkSlotV4 + blk_zt_tiles(y_slots) * 8) +
-         sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 8u + 64u + 7u * 64u);
+         sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 8u + 64u + 6u * 64u);
 }
 size_t demod_blk_lds_bytes(const DemodParams &P) { return demod_blk_lds_bytes(P, kBlkSlots); }
 // the block path needs whole blocks of polyphase registers (dsSPB a multiple of 4) and at most one bit decision per block

@@ -54,12 +54,6 @@ static __device__ unsigned long long g_stamp[4 * 2048 * 8];   // [wave][group][w
 #define FSK_STAMP_END(w)
 #endif
 
-#ifndef FSK_AB_OLDHAND
-#define FSK_AB_OLDHAND 0
-#endif
-#ifndef FSK_AB_OLDCNT
-#define FSK_AB_OLDCNT 0
-#endif
 #ifndef FSK_PIPE_SLOTS
 #define FSK_PIPE_SLOTS 4
 #endif
@@ -223,9 +217,9 @@ struct BackU {                   // wave-uniform context of one decimated sample
   uint32_t direct;               // decimated samples for which some lane still runs the direct instance (after a reset)
   uint32_t zlive;                // some lane carries a non-zero correction (or runs the direct instance)
   uint32_t *zmail;               // LDS [64]: decimated-sample index of this launch before which the front zeroes the lane's filters
-  uint32_t *cmail;               // LDS [7][64] or null (fsk_blk.hip): hand-over of the ZIR correction to the discriminator wave
-                                 // ([0] from which sample, [1..4] its value [6] steps of the recurrence before that sample),
-                                 // [5] the sample this wave's own span began at
+  uint32_t *cmail;               // LDS [6][64] or null (fsk_blk.hip): hand-over of the ZIR correction to the discriminator wave
+                                 // ([0] from which sample, [1..4] its value kHandLag steps of the recurrence before that sample,
+                                 // or there if [0] <= kHandLag), [5] the sample this wave's own span began at
   uint64_t free0;                // free-running frame: NCO phase (turns * 2^64) at the first sample of the launch
 };
 
@@ -362,25 +356,14 @@ __device__ inline void zir_step(BackLane &B, const BackK &K, BackU &X, float Ui,
         if (HAND) {
           // the correction stays here for the next kHandLag decimated samples (numbers X.k .. X.k + kHandLag - 1 of this
           // launch) and then moves to the discriminator wave.  Its values at the hand-over sample follow from these by
-          // kHandLag steps of the recurrence alone: posted are the start values and the step count, and the discriminator
-          // wave -- the one with time to spare wherever resets are frequent -- runs the steps when it takes them (round 4;
-          // the back wave used to, ~100 instructions of the wave that paces an idle receiver bank, per reset)
-#if FSK_AB_OLDHAND
-          float ai = B.qai, aq = B.qaq, bi = B.qbi, bq = B.qbq;
-          for (uint32_t g = 0; g < kHandLag; g++) {
-            const float ni = __builtin_fmaf(K.c1, bi, -(K.c2 * ai)), nq = __builtin_fmaf(K.c1, bq, -(K.c2 * aq));
-            ai = bi; aq = bq; bi = ni; bq = nq;
-          }
-          X.cmail[64u + lane] = __builtin_bit_cast(uint32_t, ai); X.cmail[128u + lane] = __builtin_bit_cast(uint32_t, aq);
-          X.cmail[192u + lane] = __builtin_bit_cast(uint32_t, bi); X.cmail[256u + lane] = __builtin_bit_cast(uint32_t, bq);
-          X.cmail[384u + lane] = 0u;
-          X.cmail[lane] = X.k + kHandLag;
-#else
+          // kHandLag steps of the recurrence alone: posted are the start values, and the discriminator wave -- the one with
+          // time to spare wherever resets are frequent -- runs the steps when it takes them (round 4; the back wave used to,
+          // ~100 instructions of the wave that paces an idle receiver bank, per reset).  A hand-over posted inside a launch
+          // is due at sample kHandLag + 1 of it at the earliest; one posted at a launch's start (fsk_blk.hip: the remaining
+          // steps run there, once) at sample kHandLag at the latest -- which is how the taker tells them apart.
           X.cmail[64u + lane] = __builtin_bit_cast(uint32_t, B.qai); X.cmail[128u + lane] = __builtin_bit_cast(uint32_t, B.qaq);
           X.cmail[192u + lane] = __builtin_bit_cast(uint32_t, B.qbi); X.cmail[256u + lane] = __builtin_bit_cast(uint32_t, B.qbq);
-          X.cmail[384u + lane] = kHandLag;
           X.cmail[lane] = X.k + kHandLag;
-#endif
         }
       }
       B.dph += 1u;
@@ -488,11 +471,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
                               pushes < P.amp_cap ? pushes : P.amp_cap);
       }
       if (eod) {
-#if FSK_AB_OLDCNT
-        ist_store<COH>(M, IF_eod_total, ist_load<COH>(M, IF_eod_total) + 1u);
-#else
         ist_add<COH>(M, IF_eod_total, 1u);
-#endif
         if (eod_counts && M.voff < 0xFFFFFFF0u) __hip_atomic_fetch_add(&eod_counts[M.voff >> 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         back_reset<UNI, COH>(B, P, M, X, inc, lane);
       }
