@@ -45,7 +45,7 @@
 // SIMD hosts one wave of each part (see the kernel).
 // Batches beyond one round of resident workgroups run persistently over (group, time slice) items: BlkSched below.
 // LDS: stage [4][65] v4f (the final-state hand-over fin [3][64] over it) | yring [y_slots][2][64] v4f, y_slots = 6 .. 28 by
-//      what the batch leaves (demod_blk_plan) | xring [6][2][64] v4f | zt [8 or 16][8] v4f | poly [64][PS] u32 |
+//      what the batch leaves (demod_blk_plan) | xring [6][2][64] v4f | zt [4, 8 or 16][8] v4f | poly [64][PS] u32 |
 //      counters [8] | zmail [64] u32 | cmail [6][64] u32   (not a byte more: 256 B more per workgroup cost config #3 2 %,
 //      profiles/r04_block_resets.txt section 11)
 #include <hip/hip_runtime.h>
@@ -74,7 +74,10 @@ static constexpr uint32_t kFlushBlocks = 16;       // byte queues are flushed ev
 // streams 116 + 132 + 121 + 148 = 517 -> 172; the loop ran at 182).  Only wave 1 .. 3's distance is tied to the lag
 // constants (static_asserts above); wave 0 has no such tie, so its ring takes whatever LDS the launch has to spare.
 static constexpr uint32_t kBlkYMax = 28;
-__host__ __device__ inline uint32_t blk_zt_tiles(uint32_t y_slots) { return y_slots <= 12u ? 8u : 16u; }
+// (tiles of phasors in flight: wave 0 runs at most y_slots - 2 half tiles ahead of the tile the back wave reads, so a power of two
+// above y_slots / 2 holds them; 4 at the six slots a full device gets -- which also keeps the workgroup's LDS 670 bytes under the
+// 29-granule mark above which config #3 loses 2 %, profiles/r04_block_resets.txt section 11-12)
+__host__ __device__ inline uint32_t blk_zt_tiles(uint32_t y_slots) { return y_slots <= 6u ? 4u : y_slots <= 12u ? 8u : 16u; }
 
 // lane stride of the polyphase registers in LDS: >= d, = 4 mod 8, so that the ds_read_b128 of 16 lanes at consecutive
 // strides touches 64 different banks (20 for 1200 baud, 84 for 300 baud)
