@@ -47,6 +47,16 @@ void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t 
 uint32_t demod_blk_slices(const DemodParams &P, const DemodState &S, size_t n, uint32_t resident_wgs, uint32_t slice_tiles,
                           uint32_t *slice_tiles_out);
 size_t demod_blk_queue_words(uint32_t groups);
+// fsk_blk6.hip: six waves per group, for batches that leave every workgroup a compute unit of its own
+size_t demod_blk6_lds_bytes(const DemodParams &P, uint32_t y_slots);
+uint32_t demod_blk6_y_slots(const DemodParams &P);
+bool demod_blk6_applicable(const DemodParams &P);
+size_t demod_blk6_max_samples();
+hipError_t set_blk6_lds_limit(const DemodParams &P);
+uint32_t demod_blk6_default_rolemap();
+hipError_t launch_demod_blk6(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
+                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts, uint32_t *eod_counts,
+                              hipStream_t stream, uint32_t lanes, uint32_t y_slots, uint32_t rolemap);
 hipError_t set_pipe_lds_limit(size_t pipe_bytes);
 hipError_t set_demod_lds_limit(size_t lds_bytes);
 size_t demod_lds_bytes(const DemodParams &P);
@@ -200,6 +210,15 @@ struct fskhip_engine {
   volatile unsigned long long *h_stat = nullptr;   // pinned: {tiles, tiles off the fast loop} as the last completed copy left them
   uint32_t stat_tiles = 0, stat_rare = 0;          // ... as of the last look
   uint32_t stat_skip = 0;                          // short calls since the last fetch
+  // six waves per group (demod_blk6_kernel, fsk_blk6.hip): the whole-tile kernel of batches small enough to give every workgroup a
+  // compute unit of its own (uniform configurations, calls of at least six_min_tiles tiles, resets rare): 0 never, 1 wherever it
+  // applies ("kernel" = six-wave), 2 auto
+  uint32_t use_six = 2;
+  uint32_t six_min_tiles = 64;   // shorter calls stay on the four-wave kernel: six stages take longer to fill and drain
+  uint32_t six_y_slots = 0;      // 0 = as deep as the LDS allows
+  uint32_t six_rolemap = 0;      // 0 = the default placement of the six parts on a workgroup's waves
+  int cus = 0;
+  bool demodulated = false;      // a demodulate call has been issued or replayed (fskhip_set_option refuses from then on)
   uint32_t blk_lanes = 64;       // streams per workgroup of demod_blk_kernel: 64, or 32 / 16 / 8 for batches that leave CUs idle (fsk_blk.hip)
   uint32_t blk_slice_tiles = 0;  // tiles per time slice (0 = the kernel file's default, 0xFFFFFFFF = never slice)
   size_t host_slab = (size_t)-1; // samples per time slab of fskhip_demodulate_host's pipeline ((size_t)-1 = ~96 MB, 0 = no pipeline)
@@ -244,7 +263,7 @@ uint32_t engine_launch_key(const fskhip_engine *e) {
   return (e->ds_uniform ? 1u : 0u) | (e->ds_parity << 1) | (e->force_generic ? 4u : 0u) | (e->timing ? 8u : 0u) |
          (e->use_split ? 32u : 0u) | (e->gen_odd ? 64u : 0u) | (e->P.quality ? 256u : 0u) |
          (e->S.trace_stream != 0xFFFFFFFFu ? 16u : 0u) | (e->use_blk ? 512u : 0u) | ((uint32_t)(e->pushes & 3u) << 10) |
-         ((e->blk_medium == 3u ? e->blk_med_now : e->blk_medium != 0u) ? 4096u : 0u);
+         ((e->blk_medium == 3u ? e->blk_med_now : e->blk_medium != 0u) ? 4096u : 0u) | (e->use_six << 13);
 }
 // "blk_resets" = auto: tiles, and tiles the block path with resets took or would be given, of a sample of the groups since the
 // last look (whatever the last completed copy brought; nothing new = the choice stands).  It wins from about one tile in six on.
@@ -260,6 +279,7 @@ void engine_refresh_kernel_choice(fskhip_engine *e) {
   e->stat_tiles = tiles; e->stat_rare = rare;
 }
 void engine_note_replayed_call(fskhip_engine *e, size_t n) {
+  e->demodulated = true;
   e->calls += 1;
   e->total_samples += n;
   e->pushes += (e->ds_parity + n) >> 1;     // (the amplitude ring's position moves with a replayed call too)
@@ -640,6 +660,8 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     *e->h_stat = 0ull;
     e->blk_lanes = demod_blk_lanes(n_streams, device);
     demod_blk_plan(P, (n_streams + e->blk_lanes - 1u) / e->blk_lanes, device, &e->blk_y_slots, &e->blk_resident);
+    if (hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) e->cus = 0;
+    if (demod_blk6_applicable(P)) CREATE_TRY(set_blk6_lds_limit(P));
     if (e->blk_resident && e->n_blocks > e->blk_resident) {
       CREATE_TRY(hipMalloc((void **)&e->S.blk_q, sizeof(uint32_t) * demod_blk_queue_words(e->n_blocks)));
     }
@@ -679,7 +701,8 @@ int fskhip_carry_over(fskhip_engine *dst, const fskhip_engine *src) {
 // unvalidated getenv() calls inside fskhip_create).
 int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
   if (!e || !name || !value) return fail(FSKHIP_E_INVALID, "fskhip_set_option: null argument");
-  if (e->calls != 0 || e->total_samples != 0) return fail(FSKHIP_E_INVALID, "fskhip_set_option(%s): the engine has demodulated already (set options right after fskhip_create)", name);
+  // (a flag of this engine's own calls -- not the call counters, which fskhip_carry_over copies from the old engine: ADVICE r04)
+  if (e->demodulated) return fail(FSKHIP_E_INVALID, "fskhip_set_option(%s): the engine has demodulated already (set options after fskhip_create / fskhip_carry_over, before the first demodulate call)", name);
   const std::string k(name), v(value);
   auto number = [&](uint64_t lo, uint64_t hi, uint64_t *out) -> int {
     if (v.empty() || v.find_first_not_of("0123456789") != std::string::npos || v.size() > 12)
@@ -693,18 +716,44 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
   int rc = FSKHIP_OK;
   if (k == "kernel") {          // which whole-tile kernel fp32 lock-step calls use
     const uint32_t n_blocks = e->n_blocks;
-    if (v == "auto") { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; }
+    e->use_six = 0u;
+    if (v == "auto") { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; e->use_six = 2u; }
+    else if (v == "auto-r04") { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; }   // (round 4's choice: never six waves)
     else if (v == "auto-r02") { e->use_blk = false; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; }
+    else if (v == "six-wave") { e->use_blk = true; e->use_split = true; e->split_forced = true; e->use_six = 1u; }   // (four waves where six do not apply)
     else if (v == "four-wave") { e->use_blk = true; e->use_split = true; e->split_forced = true; }
     else if (v == "two-wave") { e->use_blk = false; e->use_split = true; e->split_forced = true; }
     else if (v == "one-wave") { e->use_blk = false; e->use_split = false; e->split_forced = true; }
-    else return fail(FSKHIP_E_INVALID, "fskhip_set_option(kernel): '%s' is none of auto, auto-r02, four-wave, two-wave, one-wave", value);
+    else return fail(FSKHIP_E_INVALID, "fskhip_set_option(kernel): '%s' is none of auto, auto-r04, auto-r02, six-wave, four-wave, two-wave, one-wave", value);
     return FSKHIP_OK;
   }
   if (k == "blk_resets") {      // 1: the four-wave kernel's block path takes resets (default), 0: such blocks go sample by sample
     if (v == "auto") { e->blk_medium = 3u; return FSKHIP_OK; }
     if ((rc = number(0, 2, &x)) != FSKHIP_OK) return rc;   // (2, tests: run it, then restore the entry state and redo the block sample by sample)
     e->blk_medium = (uint32_t)x;
+    return FSKHIP_OK;
+  }
+  if (k == "six_min_tiles") {
+    if ((rc = number(0, 1u << 30, &x)) != FSKHIP_OK) return rc;
+    e->six_min_tiles = (uint32_t)x;
+    return FSKHIP_OK;
+  }
+  if (k == "six_y_slots") {
+    if ((rc = number(6, 24, &x)) != FSKHIP_OK) return rc;
+    e->six_y_slots = (uint32_t)x & ~1u;
+    return FSKHIP_OK;
+  }
+  if (k == "six_roles") {       // measurements: the part each of the six waves plays, e.g. 025143 (every part exactly once)
+    if (v == "auto") { e->six_rolemap = 0u; return FSKHIP_OK; }
+    uint32_t m = 0, seen = 0;
+    if (v.size() != 6) return fail(FSKHIP_E_INVALID, "fskhip_set_option(six_roles): '%s' is not six digits 0..5", value);
+    for (uint32_t w = 0; w < 6; w++) {
+      const uint32_t r = (uint32_t)(v[w] - '0');
+      if (r > 5u || (seen & (1u << r))) return fail(FSKHIP_E_INVALID, "fskhip_set_option(six_roles): '%s' is not a permutation of 0..5", value);
+      seen |= 1u << r; m |= r << (3u * w);
+    }
+    e->six_rolemap = m ? m : 0u;
+    if (!m) return fail(FSKHIP_E_INVALID, "fskhip_set_option(six_roles): '%s'", value);
     return FSKHIP_OK;
   }
   if (k == "force_generic") {
@@ -727,10 +776,21 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
                     demod_blk_lds_bytes(e->P, (uint32_t)x), e->P.d);
       e->blk_y_slots = (uint32_t)x;
     } else if (k == "blk_lanes") {                    // streams per workgroup: auto (what the device's CU count suggests) | 64 | 32 | 16 | 8
-      if (v == "auto") { e->blk_lanes = demod_blk_lanes(e->n_streams, e->device); return FSKHIP_OK; }
+      if (v == "auto") {
+        e->blk_lanes = demod_blk_lanes(e->n_streams, e->device);
+        uint32_t y = 0, res = 0;
+        demod_blk_plan(e->P, (e->n_streams + e->blk_lanes - 1u) / e->blk_lanes, e->device, &y, &res);
+        if (y) e->blk_y_slots = y;
+        return FSKHIP_OK;
+      }
       if ((rc = number(8, 64, &x)) != FSKHIP_OK) return rc;
       if (x & (x - 1u)) return fail(FSKHIP_E_INVALID, "fskhip_set_option(blk_lanes): %s is none of auto, 64, 32, 16, 8", value);
       e->blk_lanes = (uint32_t)x;
+      {   // the ring depth follows the workgroup count the new width gives; a "blk_resident" pinned by a test stays
+        uint32_t y = 0, res = 0;
+        demod_blk_plan(e->P, (e->n_streams + e->blk_lanes - 1u) / e->blk_lanes, e->device, &y, &res);
+        if (y) e->blk_y_slots = y;
+      }
     } else if (k == "blk_min_tiles") {
       if ((rc = number(0, 1u << 30, &x)) != FSKHIP_OK) return rc;
       e->blk_min_tiles = (uint32_t)x;
@@ -834,6 +894,28 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
           engine_refresh_kernel_choice(e);
           uint32_t med = e->blk_medium == 3u ? (e->blk_med_now ? 1u : 0u) : e->blk_medium;
           if (!e->P.uni_cfg) med = 0u;
+          // six waves per group: every workgroup has a compute unit to itself (the batch's groups <= CUs), a uniform configuration,
+          // resets rare (the idle-bank kernel keeps its calls), a call long enough to fill six stages
+          const uint32_t six_blocks = (e->n_streams + e->blk_lanes - 1u) / e->blk_lanes;
+          const bool six = e->use_six != 0u && quad_aligned && demod_blk6_applicable(e->P) && n_fast <= demod_blk6_max_samples() &&
+                           (e->use_six == 1u || (med == 0u && e->cus > 0 && six_blocks <= (uint32_t)e->cus && n_fast / 16 >= e->six_min_tiles));
+          if (six) {
+            HIP_TRY(launch_demod_blk6(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
+                                      e->blk_lanes, e->six_y_slots ? e->six_y_slots : demod_blk6_y_slots(e->P), e->six_rolemap));
+            e->last_sliced = false;
+            if (e->blk_medium == 3u && e->h_stat && e->S.blk_stat) {
+              bool fetch = n_fast >= 4096 || (++e->stat_skip & 7u) == 0u;
+              if (!fetch) {
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                fetch = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+              }
+              if (fetch) HIP_TRY(hipMemcpyAsync((void *)e->h_stat, e->S.blk_stat, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            }
+            static const char *const names6[8] = {
+                "fsk::demod_blk6_kernel<false, 64>", "fsk::demod_blk6_kernel<false, 32>", "fsk::demod_blk6_kernel<false, 16>", "fsk::demod_blk6_kernel<false, 8>",
+                "fsk::demod_blk6_kernel<true, 64>", "fsk::demod_blk6_kernel<true, 32>", "fsk::demod_blk6_kernel<true, 16>", "fsk::demod_blk6_kernel<true, 8>"};
+            e->last_kernel = names6[(wb ? 4 : 0) + (e->blk_lanes == 64u ? 0 : e->blk_lanes == 32u ? 1 : e->blk_lanes == 16u ? 2 : 3)];
+          } else {
           HIP_TRY(launch_demod_blk(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
                                    e->blk_resident, e->blk_slice_tiles, e->blk_y_slots, e->blk_lanes, med, &e->last_sliced));
           // (the totals are fetched behind every long call, behind every eighth of a run of short ones: the copy is ~3 us of
@@ -855,6 +937,7 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
               "fsk::demod_blk_kernel_r<true, false>", "fsk::demod_blk_kernel_r<true, true>"};
           e->last_kernel = med ? names[8 + (wb ? 2 : 0) + (e->last_sliced ? 1 : 0)]                  // <writeback, time-sliced>
                                : names[(wb ? 4 : 0) + (e->P.uni_cfg ? 2 : 0) + (e->last_sliced ? 1 : 0)];   // <writeback, uniform, time-sliced>
+          }
         } else if (two_wave) {
           HIP_TRY(launch_demod_pipe(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
           e->last_kernel = wb ? (e->P.uni_cfg ? "fsk::demod_pipe_kernel<true, true>" : "fsk::demod_pipe_kernel<true, false>")
@@ -882,6 +965,7 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
     HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], st));
     e->ev_used += 2;
   }
+  e->demodulated = true;
   e->calls += count_call ? 1 : 0;
   e->total_samples += n;
   e->pushes += (e->ds_parity + n) >> 1;

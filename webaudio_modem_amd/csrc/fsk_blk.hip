@@ -55,121 +55,10 @@
 #include "fsk_params.h"
 #include "fsk_dev.h"
 #include "fsk_pipe_dev.h"
+#include "fsk_blk_dev.h"
 #include "fsk_blk_sched.h"
 
 namespace fsk {
-
-#ifndef FSK_BLK_SLOTS
-#define FSK_BLK_SLOTS 6
-#endif
-static constexpr uint32_t kBlkSlots = FSK_BLK_SLOTS;   // half tiles in the rings
-static_assert((kBlkSlots & 1u) == 0u, "blocks are two half tiles on an even slot");
-static_assert(4u * kBlkSlots <= kZeroLagPairs, "the wave that owns the I/Q low-pass must learn of a reset before it has passed the zeroing point");
-static_assert(4u * kBlkSlots <= kHandLag, "the discriminator wave (up to 4 * kBlkSlots - 1 samples beyond the start of the back wave's tile) must not have reached the hand-over sample when it is posted");
-static constexpr uint32_t kBlkSlotV4 = 2 * 64;     // v4f per x-ring slot: four pair sums (I, Q) -- in place -> four (phase, magnitude)
-static constexpr uint32_t kFlushBlocks = 16;       // byte queues are flushed every this many blocks
-// The y ring (wave 0 -> wave 1) may be deeper than the x ring.  With six slots everywhere the four waves hold exactly
-// three tiles between them and each tile goes round the closed chain "back wave frees a slot -> wave 0 -> 1 -> 2 -> back
-// wave": the group advances a tile per (t0 + t1 + t2 + t3) / 3, not per max(t) (measured busy cycles per sample at 8 192
-// streams 116 + 132 + 121 + 148 = 517 -> 172; the loop ran at 182).  Only wave 1 .. 3's distance is tied to the lag
-// constants (static_asserts above); wave 0 has no such tie, so its ring takes whatever LDS the launch has to spare.
-static constexpr uint32_t kBlkYMax = 28;
-// (tiles of phasors in flight: wave 0 runs at most y_slots - 2 half tiles ahead of the tile the back wave reads, so a power of two
-// above y_slots / 2 holds them; 4 at the six slots a full device gets -- which also keeps the workgroup's LDS 670 bytes under the
-// 29-granule mark above which config #3 loses 2 %, profiles/r04_block_resets.txt section 11-12)
-__host__ __device__ inline uint32_t blk_zt_tiles(uint32_t y_slots) { return y_slots <= 6u ? 4u : y_slots <= 12u ? 8u : 16u; }
-
-// lane stride of the polyphase registers in LDS: >= d, = 4 mod 8, so that the ds_read_b128 of 16 lanes at consecutive
-// strides touches 64 different banks (20 for 1200 baud, 84 for 300 baud)
-__host__ __device__ inline uint32_t blk_poly_stride(uint32_t d) {
-  uint32_t s = (d + 3u) & ~3u;
-  return (s & 4u) ? s : s + 4u;
-}
-
-typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-
-struct BlkK {                    // block-level constants, VGPRs
-  uint32_t stop_m1;              // 2^stop_pos - 1: sreg > stop_m1 <=> all data bits in
-  uint32_t sh9;                  // stop_pos - 9: byte = (sreg >> sh9) & 0xFF
-  uint32_t ff;                   // 0xFF
-};
-
-// Bit clock of one block (fsk.ts:335-341) and processByte (346-375), evaluated once from the block's eight slicer bits w
-// (sample 1 in bit kBlk - 1): a lane decides at most one bit per block, at sample jd = nextBitSampleIndex - k0.  Shared by
-// the fast block path and the one that takes resets.  Returns the bad start / stop bit flags (sign bit = rare), md = all
-// ones in the lanes that decide a bit in this block.
-static constexpr int kBlk = 8;                     // decimated samples per block
-__device__ inline uint32_t blk_clock(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t kv0, uint32_t w, uint32_t &bq,
-                                     uint32_t &nq, uint32_t &md_out) {
-  uint32_t jd = Bn.T - kv0;                        // 1..kBlk in this block; 0 right after a sync (nextBitSampleIndex = k)
-  jd -= neg_mask(jd - 1u);                         // 0 -> 1
-  const uint32_t md = neg_mask(jd - (uint32_t)(kBlk + 1));   // all ones <=> a decision falls into this block
-  const uint32_t hi = w >> (((uint32_t)kBlk - jd) & 31u);    // the slicer bits of samples 1..jd (garbage without a decision: masked)
-  const uint32_t nhi = (uint32_t)__builtin_popcount(hi);
-  const uint32_t ones = nhi + Bn.acc;
-  const uint32_t tot = (uint32_t)__builtin_popcount(w);
-  const uint32_t kvd = kv0 + jd;
-  const uint32_t b = sign_bit((kvd - Bn.tlast) - ones - ones);               // 2 * bitAccumulator > bitAccumCount
-  const uint32_t s0 = Bn.sreg;
-  const uint32_t s1 = s0 + s0 + b;
-  // processByte (fsk.ts:346-375) at the decision
-  const uint32_t m_start = neg_mask(s0 - 2u);                                // waiting for the start bit
-  const uint32_t m_stop = neg_mask(Q.stop_m1 - s0);                          // all data bits in: stop (or parity) position
-  const uint32_t bm = 0u - b;
-  const uint32_t good = md & m_stop & bm;                                    // a byte completes
-  Bn.acc = tot + (Bn.acc & ~md) - (nhi & md);
-  Bn.T += K.d & md;
-  Bn.tlast = (Bn.tlast & ~md) | (kvd & md);
-  Bn.sreg = (s0 & ~md) | (s1 & md & ~good) | (1u & good);
-  const uint32_t byte = (s0 >> Q.sh9) & Q.ff;
-  bq = (bq & ~good) | (((bq << 8) | byte) & good);
-  nq -= good;
-  md_out = md;
-  return md & ((m_stop & ~bm) | (m_start & bm));                             // bad stop bit / bad start bit
-}
-
-// The fast path of one block (a tile: eight decimated samples).  Works on copies (Bn, rp, bq, nq): the caller commits
-// them only if the returned flag word has its sign bit clear in every lane.  kv0 = pushes before the block.  hard_out:
-// the same without the 'eod' bound -- a sync candidate or a bad start / stop bit, which only the per-sample path takes.
-__device__ inline uint32_t blk_fast(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t kv0, const v4f (&pa)[4],
-                                    uint32_t (&rp)[kBlk], float (&am)[kBlk], uint32_t &bq, uint32_t &nq, uint32_t &hard_out) {
-  const float phs[kBlk] = {pa[0].x, pa[0].z, pa[1].x, pa[1].z, pa[2].x, pa[2].z, pa[3].x, pa[3].z};
-  am[0] = pa[0].y; am[1] = pa[0].w; am[2] = pa[1].y; am[3] = pa[1].w;
-  am[4] = pa[2].y; am[5] = pa[2].w; am[6] = pa[3].y; am[7] = pa[3].w;
-  uint32_t w = 0, hard = 0;
-  // inside the block the correlator's count is carried as its distance to the threshold and the last loud sample as its
-  // index relative to the block (1 .. kBlk, or <= 0 for "before it"): the per-sample test is then one operation and the
-  // sample index an inline constant
-  uint32_t dm = Bn.matched - Bn.thr_eff;
-  const uint32_t lsr0 = Bn.ls - kv0;
-  uint32_t lsr = lsr0;
-#pragma unroll
-  for (int j = 0; j < kBlk; j++) {
-    const float f = disc_post(Bn, K, phs[j], am[j]);                        // fsk.ts:251-261
-    // slicer (fsk.ts:264): the bit is the sign of 0 - f (f = +-0 gives +0, bit 0); it is shifted into the registers
-    // straight from there (v_alignbit: {hi, lo} >> 31 = hi << 1 | sign of lo) without being extracted first
-    const uint32_t nf = __builtin_bit_cast(uint32_t, 0.0f - f);
-    const uint32_t rold = rp[j];
-    const uint32_t r = __builtin_amdgcn_alignbit(rold, nf, 31);              // syncSamplesBuffer.put(bit)
-    rp[j] = r;
-    dm += (uint32_t)__builtin_popcount((r ^ K.qn) & K.mask);
-    dm -= (uint32_t)__builtin_popcount((rold ^ K.qn) & K.mask);
-    hard |= ~dm;                                                             // sign set <=> matched >= thr_eff (sync candidate)
-    const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, am[j] - Bn.thr));   // fsk.ts:285
-    lsr = (lsr & silent) | ((uint32_t)(j + 1) & ~silent);
-    w = __builtin_amdgcn_alignbit(w, nf, 31);                                // sample 1 ends up in bit kBlk - 1
-  }
-  Bn.matched = dm + Bn.thr_eff;
-  Bn.ls = lsr + kv0;
-  // 'eod' (fsk.ts:288): no silence run inside the block is longer than the one a wholly silent block would end with
-  // (eod_m1 - ((kv0 + kBlk) - ls at entry))
-  const uint32_t soft = K.eod_m1 - (uint32_t)kBlk + lsr0;
-  // ---- bit clock, once per block (fsk.ts:335-341)
-  uint32_t md;
-  hard |= blk_clock(Bn, K, Q, kv0, w, bq, nq, md);
-  hard_out = hard;
-  return hard | soft;
-}
 
 // ---- The block path that takes resets (round 4) --------------------------------------------------------------------
 // A block that holds an 'eod' (resetState(), fsk.ts:175-188, 288-291) or a lane inside this wave's own span after one
@@ -378,22 +267,6 @@ __device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &
   w_out = w;
   return hard;
 }
-
-// completed bytes of the fast path -> out (oldest first); B.out_cnt counts them as the per-sample path does
-__device__ inline void blk_flush(BackLane &B, uint32_t &bq, uint32_t &nq, const FastMem &M, uint8_t *out, uint32_t out_pitch) {
-  while (__builtin_amdgcn_ballot_w64(nq != 0u)) {
-    if (nq != 0u) {
-      nq -= 1u;
-      const uint32_t byte = (bq >> (8u * nq)) & 0xFFu;
-      if (M.voff < 0xFFFFFFF0u && B.out_cnt < out_pitch) out[(size_t)(M.voff >> 2) * out_pitch + B.out_cnt] = (uint8_t)byte;
-      B.out_cnt++;
-    }
-  }
-}
-
-// The discriminator wave's share of the ZIR correction (see back_pair for the arithmetic it restates op for op):
-// w = U - q, q advances by its recurrence and retires to exactly zero once below 2^-28 of the magnitude it corrects.
-struct QLane { float ai, aq, bi, bq; };
 
 // Time-sliced priority.  With equal priorities a SIMD issues from its OLDEST wave first: the four groups sharing a CU then
 // finish one after the other (185 .. 284 cycles per sample, profiles/r03_blk4_stamps.txt), the last one largely alone
