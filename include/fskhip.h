@@ -24,8 +24,9 @@ extern "C" {
 /* 2: fskhip_max_bytes, fskhip_last_kernel.  3: fskhip_carry_over, fskhip_host_alloc / _free, the pipelined
  * fskhip_demodulate_host, fskhip_enable_signal_quality / fskhip_get_signal_quality.  4: fskhip_set_option (the library reads no
  * environment variable any more), fskhip_clock_probe_begin / _end, fskhip_debug_state.  5: fskhip_blk_lanes, option
- * "blk_lanes" (additions only). */
-#define FSKHIP_ABI_VERSION 5
+ * "blk_lanes" (additions only).  6: kernel = six-wave / auto-r04, options "six_min_tiles" / "six_y_slots" / "six_roles"; the batched
+ * IIRFilter of fskhip_next.h (additions only). */
+#define FSKHIP_ABI_VERSION 6
 #define FSKHIP_MAX_PATTERN_BYTES 16
 
 enum {
@@ -269,11 +270,18 @@ int fskhip_synchronize(fskhip_engine *e);
 int fskhip_timing_begin(fskhip_engine *e);
 int fskhip_timing_end(fskhip_engine *e, uint32_t *n_launches, double *total_ms);
 
-/* Tuning and test switches, by name; call right after fskhip_create (FSKHIP_E_INVALID once the engine has demodulated,
- * for unknown names and for values that are not numbers or out of range).  None changes a result: every choice computes
- * the same bytes (tests/test_gpu_parity.py runs the goldens through each kernel).  The library reads no environment
- * variable.
- *   "kernel"         auto | auto-r02 | four-wave | two-wave | one-wave   which whole-tile fp32 kernel (default auto)
+/* Tuning and test switches, by name; call after fskhip_create (and after fskhip_carry_over, if any) and before the engine's
+ * first demodulate call: FSKHIP_E_INVALID once THIS engine has demodulated (a flag of its own calls: the call counters that
+ * fskhip_carry_over copies do not count), for unknown names and for values that are not numbers or out of range.  None
+ * changes a result: every choice computes the same bytes (tests/test_gpu_parity.py runs the goldens through each kernel).
+ * The library reads no environment variable.
+ *   "kernel"         auto | auto-r04 | auto-r02 | six-wave | four-wave | two-wave | one-wave   which whole-tile fp32 kernel.
+ *                    auto (default): six waves per group (demod_blk6_kernel) for uniform configurations in narrow groups
+ *                    (<= 32 streams per workgroup, i.e. batches of up to 32 x compute units streams) on calls of at least
+ *                    "six_min_tiles" tiles, four waves (demod_blk_kernel / _r) otherwise wherever they apply; auto-r04: never six
+ *   "six_min_tiles"  n              calls with fewer whole tiles stay off the six-wave kernel (default 64)
+ *   "six_y_slots"    6 .. 24        depth of the six-wave kernel's y ring (default: what the LDS of a compute unit allows)
+ *   "six_roles"      auto | six digits, a permutation of 0..5: the part each of a workgroup's six waves plays (measurements)
  *   "force_generic"  0 | 1          never a whole-tile kernel: the sample-serial kernel only
  *   "blk_y_slots"    6 .. 28        depth of the four-wave kernel's first ring (checked against the LDS it needs)
  *   "blk_min_tiles"  n              calls with fewer whole tiles stay off the four-wave kernel
@@ -299,6 +307,15 @@ int fskhip_debug_state(fskhip_engine *e, uint32_t stream, double *real_out, uint
 int fskhip_clock_probe_begin(fskhip_engine *e, double spin_ms);
 int fskhip_clock_probe_end(fskhip_engine *e, double *shader_ghz, double *covered_ms);
 
+/*
+ * Hand-off waits (a property of the multi-wave kernels, not an entry point).  The four- and six-wave demodulator kernels pass
+ * tiles from wave to wave through LDS rings guarded by counters; a wave that finds its input not there yet polls the counter
+ * with s_sleep in between, WITHOUT a bound: the producer is a wave of the same workgroup and is always running (every part is
+ * played exactly once: the waves settle their parts among themselves at the start), so the wait ends -- but a lost counter
+ * update would be a hung kernel, not an error code.  Hosts that need a bound put one on the stream (hipStreamQuery / an
+ * event with a timeout) as they would for any kernel; tools/six_check.py and the soak run every case in a child process under
+ * a timeout for that reason.
+ */
 const char *fskhip_last_error(void);
 int fskhip_abi_version(void);
 int fskhip_device_count(void);

@@ -163,6 +163,41 @@ int fskhip_fir_process_host(fskhip_fir *f, const float *in, size_t n_per_stream,
 /* reset() (filters.ts:153-156) for one stream, or all when stream < 0. */
 int fskhip_fir_reset(fskhip_fir *f, int64_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * IIR half of src/dsp/filters.ts: IIRFilter (8-106) batched over streams, + FilterFactory.createIIR* (325-344; the
+ * designs themselves are fskhip_butterworth_* in fskhip.h).  Inside the demodulator the same filter lives as three
+ * hard-wired biquads; this is the generic class: Direct Form I of any order <= 8.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct fskhip_iir fskhip_iir;
+
+/* new IIRFilter(b, a) (filters.ts:17-42) for n_streams independent streams sharing one coefficient set; histories start
+ * at zero.  The constructor's three errors come back as FSKHIP_E_INVALID with the reference's messages ('Feedforward
+ * coefficients (b) cannot be empty', 'Feedback coefficients (a) cannot be empty', 'First feedback coefficient (a[0])
+ * cannot be zero'); coefficients are normalised by a[0] exactly as filters.ts:30-39 does (b[i] /= a0, a[i] /= a0 for
+ * i >= 1).  More than 9 coefficients on either side: FSKHIP_E_UNSUPPORTED (the kernel keeps eight past inputs and outputs
+ * in registers).  precision: FSKHIP_PRECISION_F64 evaluates output += b[i] * x[n-i], output -= a[i] * y[n-i] in doubles
+ * in the reference's order, every product and sum rounded on its own (bit-identical results), FSKHIP_PRECISION_F32 in
+ * floats with FMAs. */
+int fskhip_iir_create(int device, const double *b, uint32_t nb, const double *a, uint32_t na, uint32_t n_streams,
+                      int precision, fskhip_iir **out);
+int fskhip_iir_destroy(fskhip_iir *f);
+/* getCoefficients() (filters.ts:103-105): the normalised sets; b and a must hold 9 doubles each. */
+int fskhip_iir_get_coefficients(const fskhip_iir *f, double *b, uint32_t *nb, double *a, uint32_t *na);
+/* processBuffer(input) (filters.ts:81-87) for every stream: out[s][t] = f32(process(in[s][t])), the histories carried
+ * across calls.  in/out are [n_streams][pitch] float32; in == out (in place) is allowed. */
+int fskhip_iir_process_device(fskhip_iir *f, const float *d_in, size_t n_per_stream, size_t in_pitch, float *d_out,
+                              size_t out_pitch, void *hip_stream);
+int fskhip_iir_process_host(fskhip_iir *f, const float *in, size_t n_per_stream, size_t in_pitch, float *out,
+                            size_t out_pitch);
+/* process(input) (filters.ts:47-76) sample by sample, numbers in and out (doubles, nothing rounded to float);
+ * shares the histories with the Float32Array calls above. */
+int fskhip_iir_process_f64_device(fskhip_iir *f, const double *d_in, size_t n_per_stream, size_t in_pitch, double *d_out,
+                                  size_t out_pitch, void *hip_stream);
+int fskhip_iir_process_f64_host(fskhip_iir *f, const double *in, size_t n_per_stream, size_t in_pitch, double *out,
+                                size_t out_pitch);
+/* reset() (filters.ts:92-98) for one stream, or all when stream < 0. */
+int fskhip_iir_reset(fskhip_iir *f, int64_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,7 +202,7 @@ def test_whole_tile_kernels_agree_on_ragged_batches(S, monkeypatch):
     gen.synchronize()
     digests = {}
     for name, env in (("split", {"FSKHIP_SPLIT": "1"}), ("one_wave", {"FSKHIP_SPLIT": "0"}),
-                      ("four_wave", {"FSKHIP_SPLIT": "4"}), ("generic", {"FSKHIP_FORCE_GENERIC": "1"})):
+                      ("four_wave", {"FSKHIP_SPLIT": "4"}), ("six_wave", {"FSKHIP_SPLIT": "6"}), ("generic", {"FSKHIP_FORCE_GENERIC": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
@@ -211,7 +211,7 @@ def test_whole_tile_kernels_agree_on_ragged_batches(S, monkeypatch):
         rows, eod = _demod_schedule(eng, d_x, N, N, [4096, 16, 1000, 48, 20000])
         digests[name] = (_digest(rows, eod), sum(len(r) for r in rows))
         eng.close()
-    assert digests["split"] == digests["one_wave"] == digests["four_wave"] == digests["generic"], digests
+    assert digests["split"] == digests["one_wave"] == digests["four_wave"] == digests["six_wave"] == digests["generic"], digests
     assert digests["split"][1] >= 12 * S * 0.5
     gen.device_free(d_x)
     gen.close()
@@ -228,6 +228,7 @@ def test_y_ring_depth_does_not_change_results(S, monkeypatch):
     gen.synth_device(d_x, N, N, 12, SEED + 11, 300, 0.1, 1.0)
     gen.synchronize()
     digests = {}
+    monkeypatch.setenv("FSKHIP_SPLIT", "c")      # (auto-r04: the four-wave kernel is what this test is about; small batches default to six waves since round 5)
     for y in ("auto", "6", "7", "12", "28"):
         if y != "auto":
             monkeypatch.setenv("FSKHIP_BLK_YSLOTS", y)
@@ -257,8 +258,8 @@ def test_time_sliced_persistent_launch_matches_one_workgroup_per_group(S, reside
     gen.synth_device(d_x, N, N, 12, SEED + 7, 300, 0.1, 1.0)
     gen.synchronize()
     digests = {}
-    for name, env in (("plain", {"FSKHIP_SLICE_TILES": "off"}),
-                      ("sliced", {"FSKHIP_BLK_RESIDENT": str(resident), "FSKHIP_SLICE_TILES": str(slice_tiles)})):
+    for name, env in (("plain", {"FSKHIP_SLICE_TILES": "off", "FSKHIP_SPLIT": "c"}),      # ("c" = auto-r04: never the six-wave kernel, which is never sliced)
+                      ("sliced", {"FSKHIP_BLK_RESIDENT": str(resident), "FSKHIP_SLICE_TILES": str(slice_tiles), "FSKHIP_SPLIT": "c"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
@@ -294,7 +295,7 @@ def test_time_sliced_launch_with_agc_write_back(monkeypatch):
     src = np.empty((S, N), np.float32)
     gen.d2h(src, d_src)
     results = {}
-    for name, env in (("plain", {"FSKHIP_SLICE_TILES": "off"}), ("sliced", {"FSKHIP_BLK_RESIDENT": "4", "FSKHIP_SLICE_TILES": "9"})):
+    for name, env in (("plain", {"FSKHIP_SLICE_TILES": "off", "FSKHIP_SPLIT": "c"}), ("sliced", {"FSKHIP_BLK_RESIDENT": "4", "FSKHIP_SLICE_TILES": "9", "FSKHIP_SPLIT": "c"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
@@ -372,6 +373,7 @@ def test_config2_v21_300_baud_batch(monkeypatch):
                                 ("fused_ragged", {"FSKHIP_SPLIT": "0"}, [30000, 17, 4096, 3, 128, 2049]),
                                 ("blk_one_call", {"FSKHIP_SPLIT": "4"}, [N]), ("blk_quanta", {"FSKHIP_SPLIT": "4"}, [128]),
                                 ("blk_ragged", {"FSKHIP_SPLIT": "4"}, [4096, 19, 128, 48000, 7, 30000, 17, 3, 2049]),
+                                ("six_one_call", {"FSKHIP_SPLIT": "6"}, [N]), ("six_ragged", {"FSKHIP_SPLIT": "6"}, [4096, 19, 128, 48000, 7, 30000, 17, 3, 2049]),
                                 ("auto_ragged", {}, [16, 4096, 21, 128, 48000, 5, 1024])):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -383,6 +385,8 @@ def test_config2_v21_300_baud_batch(monkeypatch):
             assert "demod_pipe_kernel" in eng.last_kernel()
         if name == "blk_one_call":
             assert "demod_blk_kernel" in eng.last_kernel()
+        if name == "six_one_call":
+            assert "demod_blk6_kernel" in eng.last_kernel()
         eng.close()
     base = _digest(*results["pipe_one_call"])
     for name, r in results.items():
@@ -660,7 +664,7 @@ def test_config2_full_length_480000_samples():
     """BASELINE config #2 as written: 4 096 V.21-tone 300-baud streams x 480 000 samples (10 s) in ONE call, against the oracle
     on a strided sample, and against the same buffer in 1 s calls (VERDICT r02 #7)."""
     kernel, nbytes = _full_length_check(4096, V21, 480000, 32, 1600, 12, 48000)
-    assert "demod_blk_kernel" in kernel
+    assert "demod_blk6_kernel" in kernel      # (round 5: 4 096 streams = 256 groups of 16: the six-wave small-batch kernel)
     assert nbytes >= 4096 * 32 * 4          # eight 32-byte frames fit into 10 s; most of them decode
 
 
@@ -732,7 +736,7 @@ def test_idle_receiver_bank_one_frame_then_a_noise_floor():
     # (round 4: this is the regime the block path that takes resets -- demod_blk_kernel_r -- was built for; "auto" starts on
     # the other kernel and moves to it once a call's statistics are in)
     for schedule, resets in (([N], 0), ([N], 1), ([48000], "auto"), ([128], "auto"), ([4800], 1), ([16000], 2)):
-        eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options={"blk_resets": resets})
+        eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options={"blk_resets": resets, "kernel": "auto-r04"})
         rows, eod = _demod_schedule(eng, d_x, N, N, schedule)
         if schedule == [N]:
             assert eng.last_kernel().startswith("fsk::demod_blk_kernel_r<" if resets else "fsk::demod_blk_kernel<"), eng.last_kernel()
@@ -741,6 +745,18 @@ def test_idle_receiver_bank_one_frame_then_a_noise_floor():
             assert eng.last_kernel().startswith("fsk::demod_blk_kernel_r<"), eng.last_kernel()      # three calls of floor behind it
         digests.append(_digest(rows, eod))
         eng.close()
+    # round 5's own choice for a batch this small: six waves first (resets rare as far as the engine knows), then, the first
+    # call's statistics in, the idle-bank kernel; and the six-wave kernel pinned for the whole run (every tile on its rare paths)
+    eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    rows, eod = _demod_schedule(eng, d_x, N, N, [48000])
+    assert eng.last_kernel().startswith("fsk::demod_blk_kernel_r<"), eng.last_kernel()
+    digests.append(_digest(rows, eod))
+    eng.close()
+    eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options={"kernel": "six-wave"})
+    rows, eod = _demod_schedule(eng, d_x, N, N, [30000, 128, 17, 48000])
+    assert "demod_blk6_kernel" in eng.last_kernel(), eng.last_kernel()
+    digests.append(_digest(rows, eod))
+    eng.close()
     assert len(set(digests)) == 1, digests
     hit = 0
     sample = list(range(0, S, S // 12)) + [S - 1]
@@ -783,7 +799,7 @@ def test_config1_polarity_bank_never_syncs():
     gen.close()
 
 
-@pytest.mark.parametrize("kernel", ["four-wave", "two-wave", "one-wave"])
+@pytest.mark.parametrize("kernel", ["six-wave", "four-wave", "two-wave", "one-wave"])
 def test_agc_write_back_on_dword_aligned_tiles(kernel):
     """Round 4: after an odd-length call the whole tiles of the next start 4, 8 or 12 bytes off a 16-byte boundary (the head only
     realigns the decimator and the amplitude ring).  With FSKHIP_DEMOD_WRITEBACK_AGC the kernels also STORE 16 bytes per lane
@@ -825,7 +841,63 @@ def test_agc_write_back_on_dword_aligned_tiles(kernel):
     assert results[0][0] == results[1][0]
     assert np.array_equal(results[0][1], results[1][1])
     assert not np.array_equal(results[0][1], x[:, :N])                    # (something was written back)
-    want = {"four-wave": "demod_blk_kernel", "two-wave": "demod_pipe_kernel", "one-wave": "demod_fused_kernel"}[kernel]
+    want = {"six-wave": "demod_blk6_kernel", "four-wave": "demod_blk_kernel", "two-wave": "demod_pipe_kernel", "one-wave": "demod_fused_kernel"}[kernel]
     assert any(want in k for k in results[1][2]), results[1][2]
     gen.device_free(d_src)
     gen.close()
+
+
+@pytest.mark.parametrize("S,lanes", [(2048, None), (4096, None), (700, "32"), (150, "64"), (96, "16")])
+def test_six_wave_kernel_is_the_four_wave_kernel_bit_for_bit(S, lanes, monkeypatch):
+    """Round 5: demod_blk6_kernel (fsk_blk6.hip) -- the small-batch kernel whose stages that are not recurrences run on the idle
+    lanes of a narrow group and whose post filter runs ahead of the frame logic and is rewound after a reset -- against
+    demod_blk_kernel on the same buffers: config #3's signal at 10 dB SNR on top of random lead-ins and levels, a ragged call
+    schedule (whole tiles, odd lengths, 128-sample quanta: launches that begin and end inside a reset's own span, a hand-over
+    or a frame).  Decoded bytes, per-call byte and 'eod' counts, and EVERY carried state word of every sampled stream must be
+    identical: the float sequence per decimated sample is the same whoever evaluates it."""
+    import webaudio_modem_amd as wm
+    N = 96000
+    gen = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    d_x = gen.device_malloc(S * N * 4)
+    gen.synth_device(d_x, N, N, 40, SEED + 77, 400, 0.1, 1.0)
+    gen.add_awgn_device(d_x, N, N, 10.0, SEED + 78)
+    gen.synchronize()
+    sched = [4096, 19, 128, 128, 30000, 7, 2049, 16, 48000, 3]
+    res = {}
+    for name, opts in (("four", {"kernel": "four-wave"}), ("six", {"kernel": "six-wave"})):
+        if lanes:
+            opts = dict(opts, blk_lanes=lanes)
+        eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options=opts)
+        rows, eod = _demod_schedule(eng, d_x, N, N, sched)
+        want = "demod_blk6_kernel" if name == "six" else "demod_blk_kernel"
+        state = [eng.debug_state(s) for s in sorted(set(list(range(min(S, 80))) + list(range(0, S, 61)) + [S - 1]))]
+        res[name] = (rows, eod, state)
+        eng2 = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options=opts)      # one long call: the kernel meant is the one that runs
+        _demod_schedule(eng2, d_x, N, N, [N])
+        assert want in eng2.last_kernel(), eng2.last_kernel()
+        assert _digest(*_demod_schedule(wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options=opts), d_x, N, N, [N])) == _digest(rows, eod)
+        eng.close(); eng2.close()
+    assert _digest(res["four"][0], res["four"][1]) == _digest(res["six"][0], res["six"][1])
+    assert sum(len(r) for r in res["six"][0]) > 20 * S
+    for (ra, ia), (rb, ib) in zip(res["four"][2], res["six"][2]):
+        assert np.array_equal(np.asarray(ra).view(np.uint64), np.asarray(rb).view(np.uint64))
+        assert ia == ib
+    gen.device_free(d_x)
+    gen.close()
+
+
+def test_six_wave_is_the_default_for_small_uniform_batches():
+    """The engine's own choice: narrow groups of a uniform configuration on a long enough call -> six waves; per-stream tone
+    pairs, whole-wave groups and short calls stay on four."""
+    import webaudio_modem_amd as wm
+    N = 48000
+    for S, cfg, n, want in ((2048, BELL, N, "demod_blk6_kernel"), (8192, BELL, N, "demod_blk6_kernel"), (16384, BELL, N, "demod_blk_kernel<"),
+                            (2048, BELL, 512, "demod_blk_kernel<"),
+                            (2048, [dict(BELL, markFrequency=1200 + s % 7) for s in range(2048)], N, "demod_blk_kernel<")):
+        eng = wm.FSKEngine(S, cfg, precision=wm.PRECISION_F32)
+        d_x = eng.device_malloc(S * N * 4)
+        eng.synth_device(d_x, N, N, 12, SEED + 5, 300, 0.1, 1.0)
+        _demod_schedule(eng, d_x, N, N, [n])
+        assert want in eng.last_kernel(), (S, n, eng.last_kernel())
+        eng.device_free(d_x)
+        eng.close()

@@ -374,3 +374,93 @@ def test_xmodem_scan_kernels_agree_across_layouts():
         for p in (d_b, d_c, d_e, d_d, d_r):
             eng.device_free(p)
     eng.close()
+
+
+# ---- batched generic IIRFilter (src/dsp/filters.ts:8-106, 325-344) ------------------------------------------------------------
+IIR_RUNS = [r for r in golden().manifest["filter_runs"] if isinstance(r["coeffs"], dict)]
+
+
+@pytest.mark.parametrize("run", IIR_RUNS, ids=lambda r: r["name"])
+def test_iir_matches_reference_golden(run):
+    """The six IIR runs captured from the real IIRFilter: process() per sample (doubles) and processBuffer() (Float32Array),
+    bit for bit on the fp64 path, any chunking; the fp32 path within 1e-4 of the peak."""
+    import webaudio_modem_amd as wm
+    g = golden()
+    x = g.array(run["x"])
+    y64 = g.array(run["y_process"])
+    y32 = g.array(run["y_buffer"])
+    co = run["coeffs"]
+    f = wm.IIRFilter(co["b"], co["a"], precision=wm.PRECISION_F64)
+    assert f.getCoefficients() == {"b": co["b"], "a": co["a"]}
+    got = f.processSamples(x.astype(np.float64))
+    assert np.array_equal(got.view(np.uint64), y64.view(np.uint64))          # process(): the reference's doubles
+    f.reset()
+    assert np.array_equal(f.processBuffer(x).view(np.uint32), y32.view(np.uint32))   # processBuffer(): its Float32Array
+    f.reset()
+    parts = [f.processBuffer(x[a:b]) for a, b in ((0, 1), (1, 8), (8, 9), (9, 200), (200, 203), (203, x.size))]
+    assert np.array_equal(np.concatenate(parts).view(np.uint32), y32.view(np.uint32))   # the histories carry across calls
+    f.reset()
+    assert [f.process(float(v)) for v in x[:40]] == [float(v) for v in y64[:40]]      # the per-sample surface
+    f32 = wm.IIRFilter(co["b"], co["a"], precision=wm.PRECISION_F32)
+    y = f32.processBuffer(x)
+    assert np.max(np.abs(y.astype(np.float64) - y32)) <= 1e-4 * max(1.0, float(np.max(np.abs(y32))))
+
+
+def test_iir_constructor_errors_and_normalisation():
+    """filters.ts:19-21 (tests/dsp/filters-advanced.node.test.ts:115-143): the three constructor errors with the reference's
+    messages -- from the host class and from the C ABI itself -- and the a[0] normalisation."""
+    import ctypes as C
+    import webaudio_modem_amd as wm
+    from webaudio_modem_amd import _lib
+    for b, a, msg in (([], [1.0], "Feedforward coefficients (b) cannot be empty"), ([1.0], [], "Feedback coefficients (a) cannot be empty"),
+                      ([1.0], [0.0, 1.0], "First feedback coefficient (a[0]) cannot be zero")):
+        with pytest.raises(ValueError, match=msg.replace("(", r"\(").replace(")", r"\)").replace("[", r"\[").replace("]", r"\]")):
+            wm.IIRFilter(b, a)
+        L = _lib.lib()
+        h = C.c_void_p()
+        bb, aa = (C.c_double * max(1, len(b)))(*b), (C.c_double * max(1, len(a)))(*a)
+        rc = L.fskhip_iir_create(0, bb, len(b), aa, len(a), 1, wm.PRECISION_F64, C.byref(h))
+        assert rc == -1 and L.fskhip_last_error().decode() == msg
+    f = wm.IIRFilter([2.0, 1.0, 0.5], [2.0, -0.5, 0.25])
+    assert f.getCoefficients() == {"b": [1.0, 0.5, 0.25], "a": [1.0, -0.25, 0.125]}
+    with pytest.raises(wm.FskHipError) as ei:
+        wm.IIRFilter([1.0] * 10, [1.0])
+    assert ei.value.code == -3
+
+
+def test_iir_factories_match_the_designs():
+    import webaudio_modem_amd as wm
+    g = golden()
+    runs = {r["name"]: r for r in g.manifest["filter_runs"]}
+    x = g.array("filt.x")
+    for name, f in (("iir_lp_1200", wm.FilterFactory.createIIRLowpass(1200, 48000)), ("iir_hp_300", wm.FilterFactory.createIIRHighpass(300, 48000)),
+                    ("iir_bp_1750_2600", wm.FilterFactory.createIIRBandpass(1750, 2600, 48000))):
+        assert f.getCoefficients() == runs[name]["coeffs"], name
+        assert np.array_equal(f.processBuffer(x).view(np.uint32), g.array(runs[name]["y_buffer"]).view(np.uint32)), name
+
+
+def test_iir_batch_matches_oracle():
+    """A ragged batch (70 streams: a full wave and a part of one), orders 0 .. 8 with unequal numerator / denominator lengths,
+    odd chunk lengths, per-stream reset: every stream bit-identical to the oracle's IIR (fp64 path)."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    r = _rng(0x11F)
+    S, N = 70, 2500
+    x = (r.random((S, N)) * 2 - 1).astype(np.float32)
+    for nb, na in ((1, 1), (2, 1), (1, 2), (3, 3), (2, 4), (5, 3), (9, 9), (9, 2)):
+        b = list(r.random(nb) - 0.5)
+        # a stable denominator: small feedback
+        a = [1.0 + 0.5 * float(r.random())] + list((r.random(na - 1) - 0.5) * (0.8 / max(1, na - 1)))
+        f = wm.IIRFilterBatch(b, a, S, precision=wm.PRECISION_F64)
+        y = np.concatenate([f.processBuffer(x[:, :1000]), f.processBuffer(x[:, 1000:1003]), f.processBuffer(x[:, 1003:])], axis=1)
+        for s in (0, 1, 31, 63, 64, 69):
+            o = po.IIR(b, a)
+            assert np.array_equal(y[s].view(np.uint32), o.process_buffer(x[s]).view(np.uint32)), (nb, na, s)
+        f.reset(5)
+        y2 = f.processBuffer(x[:, :300])
+        o = po.IIR(b, a)
+        assert np.array_equal(y2[5].view(np.uint32), o.process_buffer(x[5, :300]).view(np.uint32))     # stream 5 started over
+        o = po.IIR(b, a)
+        o.process_buffer(x[6])
+        assert np.array_equal(y2[6].view(np.uint32), o.process_buffer(x[6, :300]).view(np.uint32))     # stream 6 carried on
+        f.close()

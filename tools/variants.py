@@ -53,11 +53,13 @@ n, ms = eng.timing_end()
 print("RESULT", ms / n, eng.last_kernel().replace(" ", "") + ("/%%d" %% eng.blk_lanes() if "blk" in eng.last_kernel() else ""), nb, "%%08x" %% crc)
 if os.environ.get("VAR_STAMPS"):
     import ctypes, numpy as np
-    f = L.lib().fskdbg_read_stamps_blk if "blk" in eng.last_kernel() else L.lib().fskdbg_read_stamps
+    six = "blk6" in eng.last_kernel()
+    f = L.lib().fskdbg_read_stamps_blk6 if six else L.lib().fskdbg_read_stamps_blk if "blk" in eng.last_kernel() else L.lib().fskdbg_read_stamps
     f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-    a = np.zeros((4, 2048, 8), np.uint64)
+    a = np.zeros((7 if six else 4, 2048, 8), np.uint64)
+    NW = a.shape[0]
     assert f(a.ctypes.data, a.size) == 0
-    g = min(2048, (S + 63) // 64)
+    g = min(2048, (S + eng.blk_lanes() - 1) // eng.blk_lanes() if eng.blk_lanes() else (S + 63) // 64)
     hw = a[:, :g, 2].astype(np.int64)
     simd = (hw >> 4) & 3
     if os.environ.get("VAR_STAMPS") == "3":   # which groups are slow: per compute unit (XCC, SE, SH, CU) and per SIMD
@@ -74,16 +76,16 @@ if os.environ.get("VAR_STAMPS"):
         print("STAMP per XCC mean loop: " + " ".join("%%d:%%.0f" %% (x, tot3[xcc == x].mean()) for x in range(8) if (xcc == x).any()))
         # roles per (unit, simd)
         roles = collections.defaultdict(list)
-        for w in range(4):
+        for w in range(NW):
             for b in range(g):
                 if a[w, b, 1]: roles[(int(((hw[w, b] >> 8) & 0xFF) | (((hw[w, b] >> 32) & 7) << 8)), int((hw[w, b] >> 4) & 3))].append(w)
         pat = collections.Counter("".join(str(r) for r in sorted(v)) for v in roles.values())
         print("STAMP roles sharing a SIMD (sorted), how often: %%s" %% dict(pat.most_common(8)))
     if os.environ.get("VAR_STAMPS") == "2":   # where the waves of a group sit: SIMD id of wave 0..3 (HW_REG_HW_ID bits 5:4), first 16 groups
-        print("STAMP simd of waves (first 16 groups): " + " ".join("".join(str(int(simd[w, b])) for w in range(4) if a[w, b, 1]) for b in range(min(16, g))))
+        print("STAMP simd of waves (first 16 groups): " + " ".join("".join(str(int(simd[w, b])) for w in range(NW) if a[w, b, 1]) for b in range(min(16, g))))
         cu = ((hw >> 8) & 15) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5)
         import collections
-        for w in range(4):
+        for w in range(NW):
             if a[w, :g, 1].max() == 0: continue
             cnt = collections.Counter(int(x) for x in simd[w, :g])
             print("STAMP wave %%d on SIMD 0..3: %%s" %% (w, [cnt.get(i, 0) for i in range(4)]))
@@ -92,11 +94,12 @@ if os.environ.get("VAR_STAMPS"):
         late = (r0 - r0.min()) / 100.0   # s_memrealtime ticks at 100 MHz -> microseconds
         print("STAMP loop start of wave 0 after the first group's: median %%.0f us, 90 %%%% %%.0f us, max %%.0f us; groups starting more than 1 ms late: %%d of %%d"
               %% (np.median(late), np.percentile(late, 90), late.max(), int((late > 1000).sum()), g))
-    if a[3, :g, 3].sum():
-        c = a[3, :g, 3:7].astype(np.float64).sum(axis=0)
+    BW = 5 if six else NW - 1
+    if a[BW, :g, 3].sum():
+        c = a[BW, :g, 3:7].astype(np.float64).sum(axis=0)
         print("STAMP back wave blocks: %%.0f per group; per sample because a lane is inside this wave's own span after a reset %%.1f %%%%, (unused) %%.1f %%%%, per sample for a rare event %%.1f %%%%"
               %% (c[0] / g, 100 * c[1] / c[0], 100 * c[2] / c[0], 100 * c[3] / c[0]))
-    for w in range(4):
+    for w in range(NW):
         tot = a[w, :g, 1].astype(np.float64)
         if tot.max() == 0: continue
         wait = a[w, :g, 0].astype(np.float64)

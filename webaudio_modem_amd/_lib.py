@@ -133,6 +133,14 @@ _SYMBOLS = [
     ("fskhip_fir_process_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P]),
     ("fskhip_fir_process_host", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t]),
     ("fskhip_fir_reset", C.c_int, [_P, C.c_int64]),
+    ("fskhip_iir_create", C.c_int, [C.c_int, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    ("fskhip_iir_destroy", C.c_int, [_P]),
+    ("fskhip_iir_get_coefficients", C.c_int, [_P, _P, C.POINTER(C.c_uint32), _P, C.POINTER(C.c_uint32)]),
+    ("fskhip_iir_process_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P]),
+    ("fskhip_iir_process_host", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t]),
+    ("fskhip_iir_process_f64_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P]),
+    ("fskhip_iir_process_f64_host", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t]),
+    ("fskhip_iir_reset", C.c_int, [_P, C.c_int64]),
 ]
 SYMBOL_NAMES = [s[0] for s in _SYMBOLS]
 

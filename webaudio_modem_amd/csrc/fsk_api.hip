@@ -53,7 +53,7 @@ uint32_t demod_blk6_y_slots(const DemodParams &P);
 bool demod_blk6_applicable(const DemodParams &P);
 size_t demod_blk6_max_samples();
 hipError_t set_blk6_lds_limit(const DemodParams &P);
-uint32_t demod_blk6_default_rolemap();
+uint32_t demod_blk6_default_rolemap(uint32_t lanes);
 hipError_t launch_demod_blk6(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                               size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts, uint32_t *eod_counts,
                               hipStream_t stream, uint32_t lanes, uint32_t y_slots, uint32_t rolemap);
@@ -894,11 +894,13 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
           engine_refresh_kernel_choice(e);
           uint32_t med = e->blk_medium == 3u ? (e->blk_med_now ? 1u : 0u) : e->blk_medium;
           if (!e->P.uni_cfg) med = 0u;
-          // six waves per group: every workgroup has a compute unit to itself (the batch's groups <= CUs), a uniform configuration,
-          // resets rare (the idle-bank kernel keeps its calls), a call long enough to fill six stages
+          // six waves per group: narrow groups (<= 32 streams: the stages that are not recurrences spread over the idle lanes;
+          // measured x1.20 at <= 2 048 streams, x1.14 at 4 096, x1.06 at 8 192 and x0.93 with whole-wave groups at 16 384,
+          // profiles/r05_six_wave.txt), every workgroup a compute unit to itself, a uniform configuration, resets rare (the
+          // idle-bank kernel keeps its calls), a call long enough to fill six stages
           const uint32_t six_blocks = (e->n_streams + e->blk_lanes - 1u) / e->blk_lanes;
           const bool six = e->use_six != 0u && quad_aligned && demod_blk6_applicable(e->P) && n_fast <= demod_blk6_max_samples() &&
-                           (e->use_six == 1u || (med == 0u && e->cus > 0 && six_blocks <= (uint32_t)e->cus && n_fast / 16 >= e->six_min_tiles));
+                           (e->use_six == 1u || (med == 0u && e->blk_lanes <= 32u && e->cus > 0 && six_blocks <= (uint32_t)e->cus && n_fast / 16 >= e->six_min_tiles));
           if (six) {
             HIP_TRY(launch_demod_blk6(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
                                       e->blk_lanes, e->six_y_slots ? e->six_y_slots : demod_blk6_y_slots(e->P), e->six_rolemap));

@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "fsk_params.h"
 #include "fsk_dev.h"
@@ -50,10 +51,11 @@ static constexpr uint32_t kB6Stage = 4;                    // staging tiles betw
 static constexpr uint32_t kB6XT = kBlkSlots / 2;           // tiles in the x ring, the f ring and the entry-state history
 static constexpr uint32_t kB6TileV4 = 4 * 64;              // v4f per x / f ring tile
 static constexpr uint32_t kB6YMax = 24;
-// counters (LDS words): quad 0 = [0] loader, [1] agc-bp, [2] iq produced (half tiles), [3] frame consumed;
-//                       quad 1 = [4] disc produced, [5] post produced | generation << 24, [6] rewind: tile | generation << 24,
-//                                [7] frame done
-enum { C6_P0 = 0, C6_P1 = 1, C6_P2 = 2, C6_CONS = 3, C6_P3 = 4, C6_P4 = 5, C6_RW = 6, C6_DONE = 7 };
+// counters (LDS words, half tiles): quad 0 = [0] loader, [1] AGC done in place (narrow groups) or pair sums in the x ring (64-stream
+//                       groups), [2] y ring produced, [3] frame consumed;
+//                       quad 1 = [4] x ring holds (phase, magnitude), [5] post produced | generation << 24, [6] rewind: tile |
+//                                generation << 24, [7] frame done
+enum { C6_LD = 0, C6_AGC = 1, C6_IQ = 1, C6_Y = 2, C6_CONS = 3, C6_X = 4, C6_P4 = 5, C6_RW = 6, C6_DONE = 7 };
 
 struct Blk6Z {
   uint32_t y_slots;              // half tiles in the y ring
@@ -68,6 +70,11 @@ __host__ __device__ inline uint32_t blk6_zt_tiles(uint32_t y_slots) {
 
 // blk_fast (fsk_blk_dev.h) without its disc_post: P4 has evaluated the discriminator tail, the post filter and the slicer's
 // operand; fa[0..1] = 0 - f of the tile's eight decimated samples, fa[2..3] = their magnitudes (the reference's scale).
+// LEAN: every stream of the wave is inside a frame (thr_eff = kStartedP: no sync search, fsk.ts:297), so the correlator's running
+// count cannot matter before a rare path is taken -- it is not carried (seven of the twelve vector instructions per decimated
+// sample) and the caller re-forms it from the polyphase registers when it next needs it (matched = the sum over the registers
+// of their masked match counts, by construction of the incremental update).
+template <bool LEAN>
 __device__ inline uint32_t blk6_fast(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t kv0, const v4f (&fa)[4],
                                      uint32_t (&rp)[kBlk], float (&am)[kBlk], uint32_t &bq, uint32_t &nq) {
   // (floats first: __builtin_bit_cast applied to a vector ELEMENT expression read element 0 for every component -- hipcc 7.2)
@@ -87,14 +94,16 @@ __device__ inline uint32_t blk6_fast(BackLane &Bn, const BackK &K, const BlkK &Q
     const uint32_t rold = rp[j];
     const uint32_t r = __builtin_amdgcn_alignbit(rold, nf, 31);              // syncSamplesBuffer.put(bit)
     rp[j] = r;
-    dm += (uint32_t)__builtin_popcount((r ^ K.qn) & K.mask);
-    dm -= (uint32_t)__builtin_popcount((rold ^ K.qn) & K.mask);
-    hard |= ~dm;                                                             // sign set <=> matched >= thr_eff (sync candidate)
+    if (!LEAN) {
+      dm += (uint32_t)__builtin_popcount((r ^ K.qn) & K.mask);
+      dm -= (uint32_t)__builtin_popcount((rold ^ K.qn) & K.mask);
+      hard |= ~dm;                                                           // sign set <=> matched >= thr_eff (sync candidate)
+    }
     const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, am[j] - Bn.thr));   // fsk.ts:285
     lsr = (lsr & silent) | ((uint32_t)(j + 1) & ~silent);
     w = __builtin_amdgcn_alignbit(w, nf, 31);
   }
-  Bn.matched = dm + Bn.thr_eff;
+  if (!LEAN) Bn.matched = dm + Bn.thr_eff;
   Bn.ls = lsr + kv0;
   const uint32_t soft = K.eod_m1 - (uint32_t)kBlk + lsr0;                    // 'eod' bound, as blk_fast
   uint32_t md;
@@ -113,8 +122,50 @@ __device__ __forceinline__ float lp_step(LpLane &L, float a2, float nd, float v,
   return L.y;
 }
 
+// front_agc_bp (fsk_pipe_dev.h) as its two halves, instruction for instruction: the AGC (fsk.ts:52-76) ...
+__device__ __forceinline__ float front_agc(FrontLane &F, const FrontK &K, float xin) {
+  const float xv = xin * F.g;
+  const float level = __builtin_fabsf(xv);
+  const float t = __builtin_fmaf(0.5f, __builtin_amdgcn_rcpf(level), -F.g);
+  float st;
+  asm("v_fma_f32 %0, |%1|, %2, %3 clamp" : "=v"(st) : "v"(xv), "v"(K.step_k), "v"(K.step_b));
+  const float rate = __builtin_fmaf(st, K.att_m_rel, K.rel);
+  float gn = __builtin_fmaf(t, rate, F.g);
+  gn = level > 0.0f ? gn : F.g;
+  F.g = __builtin_amdgcn_fmed3f(gn, K.g_lo, K.g_hi);
+  return xv;
+}
+// ... and the pre-filter (filters.ts:47-87), b1 = 0, b2 = -b0
+__device__ __forceinline__ float front_bp(FrontLane &F, const FrontK &K, float xv) {
+  float v = K.bp_b0 * (xv - F.bx2);
+  v = __builtin_fmaf(K.bp_na2, F.by2, v);
+  v = __builtin_fmaf(K.bp_na1, F.by1, v);
+  F.bx2 = F.bx1; F.bx1 = xv;
+  F.by2 = F.by1; F.by1 = v;
+  return v;
+}
+
 #ifndef FSK_B6_SLEEP
 #define FSK_B6_SLEEP 1
+#endif
+// Hand-off counters.  FSK_B6_POSTWAIT = 1: a wave waits for its own LDS writes (lgkmcnt(0)) before it writes the counter that
+// publishes them, as fsk_blk.hip does; 0: it does not -- the LDS executes a wave's instructions in order, so the counter's write
+// is performed after the data's, and a reader that has seen the counter reads after both.  The wait costs the producer ~100
+// cycles per hand-off; with only three tiles of lead allowed between the iq wave and the frame wave (kZeroLagPairs) every hand-off's
+// latency is on the ring's critical path.
+#ifndef FSK_B6_POSTWAIT
+#define FSK_B6_POSTWAIT 1
+#endif
+__device__ inline void b6_post(uint32_t *p, uint32_t v) {
+#if FSK_B6_POSTWAIT
+  asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" : : "v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
+#else
+  asm volatile("ds_write_b32 %0, %1" : : "v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
+#endif
+}
+// poll period of the three waves on the x ring (x 64 cycles; the waves before it keep FSK_B6_SLEEP)
+#ifndef FSK_B6_SLEEP_RING
+#define FSK_B6_SLEEP_RING 1
 #endif
 
 template <bool WB, int LW>
@@ -155,7 +206,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
   constexpr uint32_t W = (uint32_t)LW;
   const uint32_t grp = blockIdx.x, s0 = grp * W;
   // which stream a lane works for: P2 (split) lanes 32.. mirror lanes 0.., P3 lanes l + W * part
-  const uint32_t l = role == 2u ? (SPLIT ? (lane & 31u) : lane) : role == 3u ? (lane % W) : lane;
+  const uint32_t l = (SPLIT && role == 3u) ? (lane & 31u) : lane;   // (the merged iq + disc wave: its iq half; its disc half maps lanes anew)
   const bool mine = l < W;
   const uint32_t stream = mine ? s0 + l : 0xFFFFFFFFu;
   const PipeCtx C = pipe_ctx(P, S, stream);
@@ -226,7 +277,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
     load_tile(2, c0, c1, c2, c3);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
                  "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
-    uint32_t used = 0;                                      // half tiles the AGC wave has taken out of the staging ring
+    uint32_t used = 0;                                      // half tiles the pre-filter wave has taken out of the staging ring
     uint32_t sidx = 0;
     uint64_t zacc = free0 + inc * (uint64_t)(lane & 15u);
     const uint64_t inc16 = inc * 16u;
@@ -235,7 +286,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
       if (2u * t + 2u - used > 2u * kB6Stage) {
         FSK_STAMP_W0
         while (2u * t + 2u - used > 2u * kB6Stage) {
-          used = lds_peek(&ctr[C6_P1]);
+          used = lds_peek(&ctr[C6_Y]);
           if (2u * t + 2u - used > 2u * kB6Stage) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
         }
         FSK_STAMP_W1
@@ -253,8 +304,8 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
         ztf[lane & 15u] = pc; ztf[16u + (lane & 15u)] = ps;
         zacc += inc16;
       }
-      lds_post(&ctr[C6_P0], 2u * t + 2u);
-      used = lds_peek4_get(cv, C6_P1);
+      b6_post(&ctr[C6_LD], 2u * t + 2u);
+      used = lds_peek4_get(cv, C6_Y);
     };
     FSK_STAMP_BEGIN
     for (uint32_t t = 0; t < nt; t += 3) {
@@ -266,22 +317,29 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
                  "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
 #undef B6_BLOAD4
-  } else if (role == 1u) {
+  } else if (role == 1u || (SPLIT && role == 2u)) {
     // ---------------------------------------------------------------------------------------------- AGC, pre-filter
+    // 64-stream groups: one wave does both.  Narrow groups: the AGC wave (a recurrence of ten dependent instructions per sample,
+    // the longest chain left) writes the scaled samples back IN PLACE into the staging tile, the pre-filter wave takes them
+    // from there.  The two halves are front_agc_bp's instruction sequences (fsk_pipe_dev.h).
     FrontLane F;
     FrontK K;
     front_load<UNI, 0>(F, K, P, S, C);
+    // (compile-time variants: a run-time choice inside the sample loop compiled to a branch per sample)
+    auto front_stage = [&](auto agc_tag, auto bp_tag) {
+    constexpr bool do_agc = decltype(agc_tag)::value, do_bp = decltype(bp_tag)::value;
+    constexpr uint32_t c_in = do_agc ? C6_LD : C6_AGC;
     uint32_t produced = 0, consumed = 0, slot_i = 0, sidx = 0;
     FSK_STAMP_BEGIN
     for (uint32_t t = 0; t < nt; t++) {
       const uint32_t hidx = 2u * t;
-      if (produced < hidx + 2u || hidx + 1u - consumed >= NY) {
+      if (produced < hidx + 2u || (do_bp && hidx + 1u - consumed >= NY)) {
         FSK_STAMP_W0
         while (produced < hidx + 2u) {
-          produced = lds_peek(&ctr[C6_P0]);
+          produced = lds_peek(&ctr[c_in]);
           if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
         }
-        while (hidx + 1u - consumed >= NY) {                  // y ring full: the frame wave (which may still need the slots'
+        while (do_bp && hidx + 1u - consumed >= NY) {         // y ring full: the frame wave (which may still need the slots'
           consumed = lds_peek(&ctr[C6_CONS]);                 // pre-filter outputs after a reset) has not released them
           if (hidx + 1u - consumed >= NY) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
         }
@@ -289,7 +347,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
       }
       v4u32 cv;
       lds_peek4_begin(ctr, cv);
-      const v4f *st = stage + sidx * 4u * kSlotStride;
+      v4f *st = stage + sidx * 4u * kSlotStride;
       sidx = sidx + 1u == kB6Stage ? 0u : sidx + 1u;
       v4f x4[4];
 #pragma unroll
@@ -297,34 +355,42 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
 #pragma unroll
       for (uint32_t hf = 0; hf < 2; hf++) {
         v4f *slot = yring + slot_i * 2u * 64u;
-        slot_i = slot_i + 1u == NY ? 0u : slot_i + 1u;
+        if (do_bp) slot_i = slot_i + 1u == NY ? 0u : slot_i + 1u;
 #pragma unroll
         for (uint32_t cc = 0; cc < 2; cc++) {
           const uint32_t c = 2u * hf + cc;
           const float xin[4] = {x4[c].x, x4[c].y, x4[c].z, x4[c].w};
           float xs[4], y[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) front_agc_bp(F, K, xin[j], xs[j], y[j]);
-          slot[cc * 64u + lane] = (v4f){y[0], y[1], y[2], y[3]};
-          if (WB) {
+          for (int j = 0; j < 4; j++) {
+            xs[j] = do_agc ? front_agc(F, K, xin[j]) : xin[j];
+            if (do_bp) y[j] = front_bp(F, K, xs[j]);
+          }
+          if (do_bp) slot[cc * 64u + lane] = (v4f){y[0], y[1], y[2], y[3]};
+          else st[c * kSlotStride + lane] = (v4f){xs[0], xs[1], xs[2], xs[3]};
+          if (WB && do_agc) {
             if (C.valid)
               *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + (size_t)t * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
           }
         }
       }
-      lds_post(&ctr[C6_P1], hidx + 2u);                      // (also: this tile of the staging ring is free)
-      produced = lds_peek4_get(cv, C6_P0); consumed = lds_peek4_get(cv, C6_CONS);
+      b6_post(&ctr[do_bp ? C6_Y : C6_AGC], hidx + 2u);       // (the pre-filter's post also frees this tile of the staging ring)
+      produced = lds_peek4_get(cv, do_agc ? C6_LD : C6_AGC); consumed = lds_peek4_get(cv, C6_CONS);
     }
-    FSK_STAMP_END(1)
+    FSK_STAMP_END(do_agc ? 1 : 6)
     {
       const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
       const FastMem &M = C.M;
       const uint32_t fld = C.fld;
-      PIPE_RSTORE(agc_gain, F.g);
-      PIPE_RSTORE(bp_x1, F.bx1); PIPE_RSTORE(bp_x2, F.bx2); PIPE_RSTORE(bp_y1, F.by1); PIPE_RSTORE(bp_y2, F.by2);
+      if (do_agc) PIPE_RSTORE(agc_gain, F.g);
+      if (do_bp) { PIPE_RSTORE(bp_x1, F.bx1); PIPE_RSTORE(bp_x2, F.bx2); PIPE_RSTORE(bp_y1, F.by1); PIPE_RSTORE(bp_y2, F.by2); }
     }
-  } else if (role == 2u) {
-    // ---------------------------------------------------------------------------------------------- mixer, I/Q low-pass, pair sums
+    };
+    if (!SPLIT) front_stage(std::true_type(), std::true_type());
+    else if (role == 1u) front_stage(std::true_type(), std::false_type());
+    else front_stage(std::false_type(), std::true_type());
+  } else if (!SPLIT && role == 2u) {
+    // ---------------------------------------------------------------------------------------------- mixer, I/Q low-pass, pair sums (64-stream groups)
     const bool upper = SPLIT && lane >= 32u;
     LpLane LI, LQ;                                           // SPLIT: LI is this lane's only chain (I in lanes 0..31, Q in 32..63)
     {
@@ -346,7 +412,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
       if (produced < hidx + 2u || hidx + 2u - consumed > kBlkSlots) {
         FSK_STAMP_W0
         while (produced < hidx + 2u) {
-          produced = lds_peek(&ctr[C6_P1]);
+          produced = lds_peek(&ctr[C6_Y]);
           if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
         }
         while (hidx + 2u - consumed > kBlkSlots) {           // x ring full: wait for the frame wave
@@ -410,14 +476,14 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
         xw[128u + l] = (v4f){sq[0], sq[1], sq[2], sq[3]};
         xw[192u + l] = (v4f){sq[4], sq[5], sq[6], sq[7]};
       }
-      lds_post(&ctr[C6_P2], hidx + 2u);
-      produced = lds_peek4_get(cv, C6_P1); consumed = lds_peek4_get(cv, C6_CONS);
+      b6_post(&ctr[C6_IQ], hidx + 2u);
+      produced = lds_peek4_get(cv, C6_Y); consumed = lds_peek4_get(cv, C6_CONS);
     }
     FSK_STAMP_END(2)
     if (SPLIT) fin[(upper ? 64u : 0u) + l] = (v4f){LI.x1, LI.x2, LI.y, LI.v};
     else { fin[l] = (v4f){LI.x1, LI.x2, LI.y, LI.v}; fin[64u + l] = (v4f){LQ.x1, LQ.x2, LQ.y, LQ.v}; }
-    lds_post(&ctr[C6_P2], nh + 1u);
-  } else if (role == 3u) {
+    b6_post(&ctr[C6_IQ], nh + 1u);
+  } else if (!SPLIT && role == 3u) {
     // ---------------------------------------------------------------------------------------------- ZIR correction + discriminator
     const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
     const FastMem &M = C.M;
@@ -439,8 +505,8 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
       if (produced < hidx + 2u) {
         FSK_STAMP_W0
         while (produced < hidx + 2u) {
-          produced = lds_peek(&ctr[C6_P2]);
-          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
+          produced = lds_peek(&ctr[C6_IQ]);
+          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
         }
         FSK_STAMP_W1
       }
@@ -526,12 +592,186 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
           xfw[fi] = ph[0]; xfw[fi + 512u] = am[0];
         }
       }
-      lds_post(&ctr[C6_P3], hidx + 2u);
-      produced = lds_peek4_get(cv, C6_P2);
+      b6_post(&ctr[C6_X], hidx + 2u);
+      produced = lds_peek4_get(cv, C6_IQ);
     }
     FSK_STAMP_END(3)
     if (first) fin[128u + l] = (v4f){Qz.ai, Qz.aq, Qz.bi, Qz.bq};
-    lds_post(&ctr[C6_P3], nh + 1u);
+    b6_post(&ctr[C6_X], nh + 1u);
+  } else if (SPLIT && role == 3u) {
+    // ---------------------------------------------------------------------------------------------- narrow groups: mixer + I/Q low-pass + pair sums, THEN correction + discriminator, one wave
+    // (Four stages on the x ring -- iq, disc, post, frame -- cannot all hold a tile: the frame wave's reset feedback allows the
+    // wave that owns the low-pass only 24 decimated samples = three tiles of lead (kZeroLagPairs), so the ring turned once per
+    // SUM of the four stage times / 3.  In a narrow group both of these stages run on half the lanes or less, and one wave does
+    // them back to back: I chain in lanes 0..31, Q chain in lanes 32..63, pair sums through the x ring tile -- LDS answers a wave
+    // in order, no counter -- then 64 / W lanes per stream for the stateless discriminator.)
+    const bool upper = lane >= 32u;
+    LpLane LI;
+    {
+      const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
+      const uint32_t fld = C.fld, row4 = C.row4;
+      const float ix1 = PIPE_RLOAD(li_x1), ix2 = PIPE_RLOAD(li_x2), iy = PIPE_RLOAD(li_y1), iv = PIPE_RLOAD(li_y2);
+      const float qx1 = PIPE_RLOAD(lq_x1), qx2 = PIPE_RLOAD(lq_x2), qy = PIPE_RLOAD(lq_y1), qv = PIPE_RLOAD(lq_y2);
+      LI.x1 = upper ? qx1 : ix1; LI.x2 = upper ? qx2 : ix2; LI.y = upper ? qy : iy; LI.v = upper ? qv : iv;
+    }
+    float lp_a2 = P.f_lp_a2, lp_nd = -P.f_lp_delta;
+    asm volatile("" : "+v"(lp_a2), "+v"(lp_nd));
+    const uint32_t zoff = upper ? 4u : 0u;                   // v4f offset of this lane's phasor row in a zt tile (cos | sin)
+    const uint32_t xoff = upper ? 2u * 64u : 0u;             // ... and of its rows in an x ring tile
+    // the disc half: lane -> (stream l3, part)
+    const uint32_t l3 = lane % W, part = lane / W;
+    const bool first = part == 0u;                           // the lane that carries the stream's correction
+    const PipeCtx C3 = pipe_ctx(P, S, s0 + l3);
+    const int tdel_x3 = C3.valid ? 0 : (int)(trash - xring);
+    QLane Qz = {0.f, 0.f, 0.f, 0.f};
+    {
+      const __amdgpu_buffer_rsrc_t rs_rsrc = C3.rs_rsrc;
+      const FastMem &M = C3.M;
+      const uint32_t fld = C3.fld, row4 = C3.row4;
+      if (first && PIPE_ILOAD(zr_dph) >= kHandPairs) {      // this wave's from the first sample on
+        Qz.ai = PIPE_RLOAD(zq_ai); Qz.aq = PIPE_RLOAD(zq_aq); Qz.bi = PIPE_RLOAD(zq_bi); Qz.bq = PIPE_RLOAD(zq_bq);
+      }
+    }
+    float c1 = P.z_c1, c2 = P.z_c2, tiny = 0x1p-123f, rel = 3.7252902984619141e-09f;
+    uint32_t sgn = 0x80000000u;
+    asm volatile("" : "+v"(c1), "+v"(c2), "+v"(tiny), "+v"(rel), "+v"(sgn));
+    uint64_t qlive = __builtin_amdgcn_ballot_w64(first & ((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f)));
+    uint32_t consumed = 0, produced = 0, yslot_i = 0, xt_i = 0;
+    FSK_STAMP_BEGIN
+    for (uint32_t t = 0; t < nt; t++) {
+      const uint32_t hidx = 2u * t;
+      if (produced < hidx + 2u || hidx + 2u - consumed > kBlkSlots) {
+        FSK_STAMP_W0
+        while (produced < hidx + 2u) {
+          produced = lds_peek(&ctr[C6_Y]);
+          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+        }
+        while (hidx + 2u - consumed > kBlkSlots) {           // x ring full: wait for the frame wave
+          consumed = lds_peek(&ctr[C6_CONS]);
+          if (hidx + 2u - consumed > kBlkSlots) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+        }
+        FSK_STAMP_W1
+      }
+      v4u32 cv;
+      lds_peek4_begin(ctr, cv);
+      const v4f *ztile = zt + (t & ZTM) * 8u;
+      const uint32_t zj = zmail[l];
+      const uint32_t kq = cmail[l3];
+      const uint32_t ow = 4u * hidx - cmail[320u + l3];      // decimated samples since the frame wave's own span began
+      v4f y4[4], zz[4];
+      {
+        const v4f *ys0 = yring + yslot_i * 2u * 64u;
+        yslot_i = yslot_i + 1u == NY ? 0u : yslot_i + 1u;
+        const v4f *ys1 = yring + yslot_i * 2u * 64u;
+        yslot_i = yslot_i + 1u == NY ? 0u : yslot_i + 1u;
+        y4[0] = ys0[l]; y4[1] = ys0[64u + l]; y4[2] = ys1[l]; y4[3] = ys1[64u + l];
+#pragma unroll
+        for (int i = 0; i < 4; i++) zz[i] = ztile[zoff + (uint32_t)i];
+      }
+      v4f *xt = xring + xt_i * kB6TileV4;
+      xt_i = xt_i + 1u == kB6XT ? 0u : xt_i + 1u;
+      // ---- iq half
+      float si[8];
+      auto quad = [&](const uint32_t c, const bool zeroing) {
+        const float y[4] = {y4[c].x, y4[c].y, y4[c].z, y4[c].w};
+        const float za[4] = {zz[c].x, zz[c].y, zz[c].z, zz[c].w};
+        const uint32_t pb = 8u * t + 2u * c;
+        float oi[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (zeroing && !(j & 1)) {
+            if (zj == pb + (uint32_t)(j >> 1)) LI.x1 = LI.x2 = LI.y = LI.v = 0.f;
+          }
+          oi[j] = lp_step(LI, lp_a2, lp_nd, y[j], za[j]);
+        }
+        si[2 * c] = oi[0] + oi[1]; si[2 * c + 1] = oi[2] + oi[3];
+      };
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(zj - 8u * t < 8u) != 0ull, 0)) {
+        asm volatile("s_nop 0");
+        quad(0, true); quad(1, true); quad(2, true); quad(3, true);
+      } else {
+        quad(0, false); quad(1, false); quad(2, false); quad(3, false);
+      }
+      {
+        v4f *xw = xt + tdel_x;
+        xw[xoff + l] = (v4f){si[0], si[1], si[2], si[3]};
+        xw[xoff + 64u + l] = (v4f){si[4], si[5], si[6], si[7]};
+      }
+      asm volatile("" ::: "memory");                          // (the pair sums are in LDS before anything below reads them: same wave, in order)
+      // ---- disc half
+      if (__builtin_expect((__builtin_amdgcn_ballot_w64((kq - 4u * hidx < 8u) | (ow < kHandPairs)) | qlive) != 0ull, 0)) {
+        // a hand-over due in this tile, a lane inside the frame wave's own span, a live correction: the stream's first lane
+        // takes the whole tile, in order (fsk_blk.hip's discriminator wave, op for op)
+        if (first) {
+          const v4f ua = xt[l3], ub = xt[64u + l3], uc = xt[128u + l3], ud = xt[192u + l3];
+          const float ui[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w}, uq[8] = {uc.x, uc.y, uc.z, uc.w, ud.x, ud.y, ud.z, ud.w};
+          float ph[8], am[8];
+          QLane H = {0.f, 0.f, 0.f, 0.f};
+          if (kq - 4u * hidx < 8u) {
+            H.ai = __builtin_bit_cast(float, cmail[64u + l3]); H.aq = __builtin_bit_cast(float, cmail[128u + l3]);
+            H.bi = __builtin_bit_cast(float, cmail[192u + l3]); H.bq = __builtin_bit_cast(float, cmail[256u + l3]);
+            const uint32_t steps = kq > kHandLag ? kHandLag : 0u;   // (posted inside this launch: kHandLag steps before its sample)
+            for (uint32_t g = 0; g < steps; g++) {
+              const float ni = __builtin_fmaf(c1, H.bi, -(c2 * H.ai)), nq = __builtin_fmaf(c1, H.bq, -(c2 * H.aq));
+              H.ai = H.bi; H.aq = H.bq; H.bi = ni; H.bq = nq;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            if (kq == 4u * hidx + (uint32_t)j) Qz = H;        // the frame wave's correction becomes this wave's here
+            const float wi = ui[j] - Qz.ai, wq = uq[j] - Qz.aq;
+            {
+              const float ni = __builtin_fmaf(c1, Qz.bi, -(c2 * Qz.ai)), nq = __builtin_fmaf(c1, Qz.bq, -(c2 * Qz.aq));
+              Qz.ai = Qz.bi; Qz.aq = Qz.bq; Qz.bi = ni; Qz.bq = nq;
+            }
+            ph[j] = atan2_amp_fma(wq, wi, am[j], tiny, sgn);
+            const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(Qz.ai), __builtin_fabsf(Qz.aq)),
+                                              __builtin_fmaxf(__builtin_fabsf(Qz.bi), __builtin_fabsf(Qz.bq)));
+            if (!(big > am[j] * rel)) { Qz.ai = 0.f; Qz.aq = 0.f; Qz.bi = 0.f; Qz.bq = 0.f; }
+            const bool own = ow + (uint32_t)j < kHandPairs;   // the frame wave evaluates these itself and needs the pair sums
+            ph[j] = own ? ui[j] : ph[j]; am[j] = own ? uq[j] : am[j];
+          }
+          v4f *xw = xt + tdel_x3;
+          xw[l3] = (v4f){ph[0], ph[1], ph[2], ph[3]}; xw[64u + l3] = (v4f){ph[4], ph[5], ph[6], ph[7]};
+          xw[128u + l3] = (v4f){am[0], am[1], am[2], am[3]}; xw[192u + l3] = (v4f){am[4], am[5], am[6], am[7]};
+        }
+        qlive = __builtin_amdgcn_ballot_w64(first & ((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f)));
+      } else {
+        // the plain discriminator is stateless: SP decimated samples per lane, PARTS lanes per stream
+        float *xf = reinterpret_cast<float *>(xt);
+        const uint32_t fi = ((part * (uint32_t)SP) >> 2) * 256u + l3 * 4u + ((part * (uint32_t)SP) & 3u);   // float index of this lane's first I value
+        float ui[SP], uq[SP], ph[SP], am[SP];
+        if (SP == 4) {
+          const v4f ua = *reinterpret_cast<const v4f *>(xf + fi), uc = *reinterpret_cast<const v4f *>(xf + fi + 512u);
+          const float ti[4] = {ua.x, ua.y, ua.z, ua.w}, tq[4] = {uc.x, uc.y, uc.z, uc.w};
+#pragma unroll
+          for (int j = 0; j < SP; j++) { ui[j] = ti[j & 3]; uq[j] = tq[j & 3]; }
+        } else if (SP == 2) {
+          const f2 ua = *reinterpret_cast<const f2 *>(xf + fi), uc = *reinterpret_cast<const f2 *>(xf + fi + 512u);
+          ui[0] = ua.x; ui[SP - 1] = ua.y; uq[0] = uc.x; uq[SP - 1] = uc.y;
+        } else {
+          ui[0] = xf[fi]; uq[0] = xf[fi + 512u];
+        }
+#pragma unroll
+        for (int j = 0; j < SP; j++) ph[j] = atan2_amp_fma(uq[j], ui[j], am[j], tiny, sgn);
+        float *xfw = xf + 4 * tdel_x3;
+        if (SP == 4) {
+          *reinterpret_cast<v4f *>(xfw + fi) = (v4f){ph[0], ph[1 % SP], ph[2 % SP], ph[3 % SP]};
+          *reinterpret_cast<v4f *>(xfw + fi + 512u) = (v4f){am[0], am[1 % SP], am[2 % SP], am[3 % SP]};
+        } else if (SP == 2) {
+          *reinterpret_cast<f2 *>(xfw + fi) = (f2){ph[0], ph[SP - 1]};
+          *reinterpret_cast<f2 *>(xfw + fi + 512u) = (f2){am[0], am[SP - 1]};
+        } else {
+          xfw[fi] = ph[0]; xfw[fi + 512u] = am[0];
+        }
+      }
+      b6_post(&ctr[C6_X], hidx + 2u);
+      produced = lds_peek4_get(cv, C6_Y); consumed = lds_peek4_get(cv, C6_CONS);
+    }
+    FSK_STAMP_END(3)
+    fin[(upper ? 64u : 0u) + l] = (v4f){LI.x1, LI.x2, LI.y, LI.v};
+    if (first) fin[128u + l3] = (v4f){Qz.ai, Qz.aq, Qz.bi, Qz.bq};
+    b6_post(&ctr[C6_X], nh + 1u);
   } else if (role == 4u) {
     // ---------------------------------------------------------------------------------------------- discriminator tail, post filter, slicer -- ahead of the frame logic
     BackLane B;
@@ -539,36 +779,25 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
     back_load<UNI, 0>(B, K, P, S, C, 0xFFFFFFFFu, nullptr, nullptr, 0);   // (the post filter, lastPhase and thf are what this wave uses of it)
     if (!C.valid) { B.px1 = B.px2 = B.py = B.pv = 0.f; B.last_phase = 0.f; B.thf = 0.f; }   // (zeros in, zeros out: see `trash`)
     uint32_t gen = 0, t = 0, xt_i = 0;
+    uint32_t rw_cur = 0;                                      // the rewind word this wave has adopted (tile | generation << 24)
     uint32_t *ctr1 = ctr + 4;
-    FSK_STAMP_BEGIN
-    for (;;) {
+    // One tile: `cur` holds its x ring entries (phase 0..3, 4..7, magnitude 0..3, 4..7); the NEXT tile's are read into `nxt`
+    // while this one is worked -- whether they were there yet is known from the counters read just before them (LDS answers a
+    // wave in order).  One branch per tile: the loop's.  Returns false when the next tile cannot follow at once.
+    auto tile = [&](const v4f (&cur)[4], v4f (&nxt)[4]) -> bool {
       v4u32 cv;
       lds_peek4_begin(ctr1, cv);
-      const uint32_t produced = lds_peek4_get(cv, 0), rw = lds_peek4_get(cv, 2), done = lds_peek4_get(cv, 3);
-      if (done != 0u) break;
-      if ((rw >> 24) != gen) {
-        // the frame wave took some tiles sample by sample and has posted what it ended with: drop what ran ahead, resume there
-        gen = rw >> 24; t = rw & 0xFFFFFFu;
-        xt_i = t % kB6XT;
-        const v4f a = rmail[lane], b = rmail[64u + lane];
-        B.px1 = a.x; B.px2 = a.y; B.py = a.z; B.pv = a.w; B.last_phase = b.x; B.thf = b.y;
-        continue;
-      }
-      if (t == nt || produced < 2u * t + 2u) {
-        FSK_STAMP_W0
-        __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
-        FSK_STAMP_W1
-        continue;
-      }
-      const v4f *xt = xring + xt_i * kB6TileV4;
       v4f *ft = fring + xt_i * kB6TileV4 + tdel_f;
       v4f *ht = hist + xt_i * 2u * 64u;
       xt_i = xt_i + 1u == kB6XT ? 0u : xt_i + 1u;
-      const v4f pa = xt[lane], pb = xt[64u + lane], aa = xt[128u + lane], ab = xt[192u + lane];
+      {
+        const v4f *xn = xring + xt_i * kB6TileV4;
+        nxt[0] = xn[lane]; nxt[1] = xn[64u + lane]; nxt[2] = xn[128u + lane]; nxt[3] = xn[192u + lane];
+      }
       ht[lane] = (v4f){B.px1, B.px2, B.py, B.pv};
       ht[64u + lane] = (v4f){B.last_phase, 0.f, 0.f, 0.f};
-      const float phs[kBlk] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-      float am[kBlk] = {aa.x, aa.y, aa.z, aa.w, ab.x, ab.y, ab.z, ab.w};
+      const float phs[kBlk] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
+      float am[kBlk] = {cur[2].x, cur[2].y, cur[2].z, cur[2].w, cur[3].x, cur[3].y, cur[3].z, cur[3].w};
       float nf[kBlk];
 #pragma unroll
       for (int j = 0; j < kBlk; j++) {
@@ -578,8 +807,50 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
       ft[lane] = (v4f){nf[0], nf[1], nf[2], nf[3]}; ft[64u + lane] = (v4f){nf[4], nf[5], nf[6], nf[7]};
       ft[128u + lane] = (v4f){am[0], am[1], am[2], am[3]}; ft[192u + lane] = (v4f){am[4], am[5], am[6], am[7]};
       t++;
-      if (t == nt) { fin[192u + lane] = (v4f){B.px1, B.px2, B.py, B.pv}; fin[256u + lane] = (v4f){B.last_phase, 0.f, 0.f, 0.f}; }
-      lds_post(&ctr[C6_P4], (gen << 24) | (2u * t));
+      b6_post(&ctr[C6_P4], (gen << 24) | (2u * t));
+      const uint32_t produced = lds_peek4_get(cv, 0), rw = lds_peek4_get(cv, 2), done = lds_peek4_get(cv, 3);
+      return (rw == rw_cur) & (done == 0u) & (t < nt) & (produced >= 2u * t + 2u);
+    };
+    FSK_STAMP_BEGIN
+    for (;;) {
+      // ---- until tile t can be worked, the frame wave rewinds this one, or the launch is over
+      bool over = false;
+      {
+        FSK_STAMP_W0
+        for (;;) {
+          v4u32 cv;
+          lds_peek4_begin(ctr1, cv);
+          const uint32_t produced = lds_peek4_get(cv, 0), rw = lds_peek4_get(cv, 2), done = lds_peek4_get(cv, 3);
+          if (done != 0u) { over = true; break; }
+          if (rw != rw_cur) {
+            // the frame wave took some tiles sample by sample and has posted what it ended with: drop what ran ahead, resume there
+            rw_cur = rw; gen = rw >> 24; t = rw & 0xFFFFFFu;
+            const v4f a = rmail[lane], b = rmail[64u + lane];
+            B.px1 = a.x; B.px2 = a.y; B.py = a.z; B.pv = a.w; B.last_phase = b.x; B.thf = b.y;
+            continue;
+          }
+          if (t < nt && produced >= 2u * t + 2u) break;
+          __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+        }
+        FSK_STAMP_W1
+      }
+      if (over) break;
+      xt_i = t % kB6XT;
+      v4f ta[4], tb[4];
+      {
+        const v4f *xt = xring + xt_i * kB6TileV4;
+        ta[0] = xt[lane]; ta[1] = xt[64u + lane]; ta[2] = xt[128u + lane]; ta[3] = xt[192u + lane];
+      }
+      for (;;) {
+        if (!tile(ta, tb)) break;
+        if (!tile(tb, ta)) break;
+      }
+      if (t == nt) {
+        // the launch's last tile is done (in this generation): leave the final state where the frame wave looks for it
+        fin[192u + lane] = (v4f){B.px1, B.px2, B.py, B.pv}; fin[256u + lane] = (v4f){B.last_phase, 0.f, 0.f, 0.f};
+        b6_post(&ctr[C6_P4], (gen << 24) | (nh + 1u));
+        t = nt + 1u;                                          // (nothing more to do but wait for `done` or a rewind)
+      }
     }
     FSK_STAMP_END(4)
   } else if (role == 5u) {
@@ -622,6 +893,17 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
     uint32_t rare_tiles = 0;
     uint32_t gen = 0;
     bool own_post = false;                                    // the post filter / lastPhase in B are this wave's (a per-sample run is in progress)
+    bool matched_stale = false;                               // lean blocks have run: B.matched is to be re-formed from the polyphase registers
+    auto matched_now = [&]() {
+      uint32_t m = 0;
+      for (uint32_t i = 0; i < P.d; i += 4u) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(prow + i);
+        m += (uint32_t)__builtin_popcount((r.x ^ K.qn) & K.mask) + (uint32_t)__builtin_popcount((r.y ^ K.qn) & K.mask) +
+             (uint32_t)__builtin_popcount((r.z ^ K.qn) & K.mask) + (uint32_t)__builtin_popcount((r.w ^ K.qn) & K.mask);
+      }
+      B.matched = m;
+      matched_stale = false;
+    };
     uint32_t *ctr1 = ctr + 4;
     FSK_STAMP_BEGIN
     uint32_t t = 0;                                           // half tiles consumed (a block = a tile = two of them)
@@ -633,7 +915,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
           gen = (gen + 1u) & 0xFFu;
           rmail[lane] = (v4f){B.px1, B.px2, B.py, B.pv};
           rmail[64u + lane] = (v4f){B.last_phase, B.thf, 0.f, 0.f};
-          lds_post(&ctr[C6_RW], (gen << 24) | (t >> 1));
+          b6_post(&ctr[C6_RW], (gen << 24) | (t >> 1));
           own_post = false;
         }
         uint32_t pw = 0;
@@ -642,7 +924,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
           for (;;) {
             pw = lds_peek(&ctr[C6_P4]);
             if ((pw >> 24) == gen && (pw & 0xFFFFFFu) >= t + 2u) break;
-            __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
+            __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
           }
           FSK_STAMP_W1
         }
@@ -650,20 +932,26 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
         uint32_t lim0 = (t | (kFlushBlocks - 1u)) + 1u;
         lim0 = lim0 < nh ? lim0 : nh;
         uint32_t lim = lim0 < (produced & ~1u) ? lim0 : (produced & ~1u);
-        for (;;) {
+        // One block: `cur` holds its f ring entries; the NEXT tile's are read into `nxt` meanwhile -- whether they were there
+        // yet is known from the counters read just before them.  Returns 0 to go on with the next tile at once, 1 to stop (the
+        // next tile is not there yet, or a flush point), 2 if this block has to be redone sample by sample (nothing committed).
+        auto ftile = [&](auto lean, const v4f (&cur)[4], v4f (&nxt)[4]) -> int {
           v4u32 cv;
           lds_peek4_begin(ctr1, cv);
           const uint32_t pidx2 = pidx + 4u >= P.d ? 0u : pidx + 4u;
-          const v4f *ft = fring + slot_t * kB6TileV4;
-          const v4f fa[4] = {ft[lane], ft[64u + lane], ft[128u + lane], ft[192u + lane]};
           const uint4 rpa = *reinterpret_cast<const uint4 *>(prow + pidx), rpb = *reinterpret_cast<const uint4 *>(prow + pidx2);
+          {
+            const uint32_t sn = slot_t + 1u == kB6XT ? 0u : slot_t + 1u;
+            const v4f *fn = fring + sn * kB6TileV4;
+            nxt[0] = fn[lane]; nxt[1] = fn[64u + lane]; nxt[2] = fn[128u + lane]; nxt[3] = fn[192u + lane];
+          }
           BackLane Bn = B;
           uint32_t rp[kBlk] = {rpa.x, rpa.y, rpa.z, rpa.w, rpb.x, rpb.y, rpb.z, rpb.w};
           float am[kBlk];
           uint32_t bqn = bq, nqn = nq;
-          const uint32_t rare = blk6_fast(Bn, K, Q, X.kv, fa, rp, am, bqn, nqn);
+          const uint32_t rare = blk6_fast<decltype(lean)::value>(Bn, K, Q, X.kv, cur, rp, am, bqn, nqn);
           FSK_STAMP_COUNT(0)
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)rare < 0) != 0ull, 0)) { rare_exit = true; break; }
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)rare < 0) != 0ull, 0)) return 2;
           B = Bn; bq = bqn; nq = nqn;
           *reinterpret_cast<uint4 *>(prow + pidx) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
           *reinterpret_cast<uint4 *>(prow + pidx2) = make_uint4(rp[4], rp[5], rp[6], rp[7]);
@@ -681,11 +969,49 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
           slot_t = slot_t + 1u == kB6XT ? 0u : slot_t + 1u;
           pidx = pidx2 + 4u >= P.d ? 0u : pidx2 + 4u;
           t += 2u;
-          lds_post(&ctr[C6_CONS], t);                           // slots free (this wave's reads of them are complete)
+          b6_post(&ctr[C6_CONS], t);                           // slots free (this wave's reads of them are complete)
           const uint32_t pn = lds_peek4_get(cv, 1);
           if ((pn >> 24) == gen) produced = pn & 0xFFFFFFu;
           lim = lim0 < (produced & ~1u) ? lim0 : (produced & ~1u);
-          if (!(t < lim)) break;
+          if (t < lim) return 0;
+          if (t >= lim0) return 1;
+          // The next tile was not there when this one began -- the counters above are a tile old, and P4 works one tile ahead of
+          // this wave, so that is the usual case: look again (and wait here while it still is not), then go on with entries read
+          // afresh.  Leaving the loop instead cost ~500 cycles per tile (the outer loop's polls, two exposed LDS round trips).
+          {
+            FSK_STAMP_W0
+            for (;;) {
+              const uint32_t pw2 = lds_peek(&ctr[C6_P4]);
+              if ((pw2 >> 24) == gen && (pw2 & 0xFFFFFFu) >= t + 2u) { produced = pw2 & 0xFFFFFFu; break; }
+              __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+            }
+            FSK_STAMP_W1
+          }
+          lim = lim0 < (produced & ~1u) ? lim0 : (produced & ~1u);
+          return 3;
+        };
+        auto fload = [&](v4f (&dst)[4]) {
+          const v4f *ft = fring + slot_t * kB6TileV4;
+          dst[0] = ft[lane]; dst[1] = ft[64u + lane]; dst[2] = ft[128u + lane]; dst[3] = ft[192u + lane];
+        };
+        v4f fa[4], fb[4];
+        fload(fa);
+        // every stream of the wave inside a frame (lanes without a stream do not count): the lean block, matched re-formed later
+        if (__builtin_amdgcn_ballot_w64(C.valid & (B.thr_eff != kStartedP)) == 0ull) {
+          matched_stale = true;
+          for (;;) {
+            int r = ftile(std::true_type(), fa, fb);
+            if (r == 3) { fload(fb); r = 0; }
+            if (r == 0) { r = ftile(std::true_type(), fb, fa); if (r == 3) { fload(fa); r = 0; } }
+            if (r != 0) { rare_exit = r == 2; break; }
+          }
+        } else {
+          for (;;) {
+            int r = ftile(std::false_type(), fa, fb);
+            if (r == 3) { fload(fb); r = 0; }
+            if (r == 0) { r = ftile(std::false_type(), fb, fa); if (r == 3) { fload(fa); r = 0; } }
+            if (r != 0) { rare_exit = r == 2; break; }
+          }
         }
       }
       if (rare_exit) {
@@ -696,7 +1022,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
             for (;;) {                                         // (P4 has produced this tile: its entry state is in the history)
               const uint32_t pw = lds_peek(&ctr[C6_P4]);
               if ((pw >> 24) == gen && (pw & 0xFFFFFFu) >= t + 2u) break;
-              __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
+              __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
             }
             const v4f *ht = hist + slot_t * 2u * 64u;
             const v4f a = ht[lane], b = ht[64u + lane];
@@ -707,10 +1033,11 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
         {
           uint32_t p3 = 0;
           FSK_STAMP_W0
-          while ((p3 = lds_peek(&ctr[C6_P3])) < t + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
+          while ((p3 = lds_peek(&ctr[C6_X])) < t + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
           FSK_STAMP_W1
         }
         if (X.zlive != 0u) { rare_tiles++; FSK_STAMP_COUNT(1) } else { FSK_STAMP_COUNT(3) }
+        if (matched_stale) matched_now();
         blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
         const v4f *ztile = zt + ((t >> 1) & ZTM) * 8u;
         const float *ztf = reinterpret_cast<const float *>(ztile);
@@ -743,25 +1070,31 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
         }
         (void)ztf;
         slot_t = slot_t + 1u == kB6XT ? 0u : slot_t + 1u;
-        lds_post(&ctr[C6_CONS], t);
+        b6_post(&ctr[C6_CONS], t);
       }
       if ((t & (kFlushBlocks - 1u)) == 0u) blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
     }
     blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
+    if (matched_stale) matched_now();
     FSK_STAMP_END(5)
     if (lane == 0 && S.blk_stat && (grp & 63u) == 0u) {
       __hip_atomic_fetch_add(&S.blk_stat[0], (uint32_t)n_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(&S.blk_stat[1], rare_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // the other waves' final states
-    while (lds_peek(&ctr[C6_P3]) <= nh) __builtin_amdgcn_s_sleep(1);
-    while (lds_peek(&ctr[C6_P2]) <= nh) __builtin_amdgcn_s_sleep(1);
+    while (lds_peek(&ctr[C6_X]) <= nh) __builtin_amdgcn_s_sleep(1);
+    if (!SPLIT) { while (lds_peek(&ctr[C6_IQ]) <= nh) __builtin_amdgcn_s_sleep(1); }
     if (!own_post) {
-      // (P4 has run the last tile in this generation -- this wave consumed it -- and left its state behind it)
+      // (P4 has run the last tile in this generation -- this wave consumed it -- and leaves its state behind it)
+      for (;;) {
+        const uint32_t pw = lds_peek(&ctr[C6_P4]);
+        if ((pw >> 24) == gen && (pw & 0xFFFFFFu) > nh) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
       const v4f a = fin[192u + lane], b = fin[256u + lane];
       B.px1 = a.x; B.px2 = a.y; B.py = a.z; B.pv = a.w; B.last_phase = b.x;
     }
-    lds_post(&ctr[C6_DONE], 1u);
+    b6_post(&ctr[C6_DONE], 1u);
     FrontLane F;
     {
       const v4f fi = fin[lane], fq = fin[64u + lane];
@@ -828,10 +1161,13 @@ hipError_t set_blk6_lds_limit(const DemodParams &P) {
 
 // default part of each wave: waves w and w + 4 of a workgroup share a SIMD (its six waves go round the CU's four): the two
 // heaviest instruction streams -- frame logic, AGC + pre-filter -- get a SIMD each, loader + post and iq + disc share
-uint32_t demod_blk6_default_rolemap() {
-  const uint32_t part_of_wave[6] = {0u, 2u, 5u, 1u, 4u, 3u};
+// 64-stream groups (parts 0 loader, 1 AGC + pre-filter, 2 iq, 3 disc, 4 post, 5 frame): frame and AGC + pre-filter get a SIMD each,
+// loader + post and iq + disc share.  Narrow groups (0 loader, 1 AGC, 2 pre-filter, 3 iq + disc, 4 post, 5 frame): frame and
+// iq + disc alone, loader + post and AGC + pre-filter share.
+uint32_t demod_blk6_default_rolemap(uint32_t lanes) {
+  const uint32_t wide[6] = {0u, 2u, 5u, 1u, 4u, 3u}, narrow[6] = {0u, 1u, 5u, 3u, 4u, 2u};
   uint32_t m = 0;
-  for (uint32_t w = 0; w < 6; w++) m |= part_of_wave[w] << (3u * w);
+  for (uint32_t w = 0; w < 6; w++) m |= (lanes == 64u ? wide[w] : narrow[w]) << (3u * w);
   return m;
 }
 
@@ -844,7 +1180,7 @@ hipError_t launch_demod_blk6(bool writeback, bool append, const DemodParams &P, 
   y_slots = y_slots < kBlkSlots ? kBlkSlots : y_slots > ymax ? ymax : y_slots;
   y_slots &= ~1u;
   const size_t lds = demod_blk6_lds_bytes(P, y_slots);
-  Blk6Z Z = {y_slots, blk6_zt_tiles(y_slots), rolemap ? rolemap : demod_blk6_default_rolemap()};
+  Blk6Z Z = {y_slots, blk6_zt_tiles(y_slots), rolemap ? rolemap : demod_blk6_default_rolemap(lanes)};
 #define FSK_LAUNCH_B6(WBV, LWV)                                                                                      \
   hipLaunchKernelGGL((demod_blk6_kernel<WBV, LWV>), dim3(blocks), dim3(384), lds, stream, P, S, samples, n, pitch, \
                      append ? 1 : 0, out, out_pitch, out_counts, eod_counts, Z)

@@ -30,7 +30,7 @@ static __device__ int g_ablate;
 // the cycles it spends in its hand-off wait loops and in its whole main loop (s_memtime), and writes both to g_stamp at
 // the end: which wave paces the group and how much slack the others have.  Compiled out of the shipped library.
 #ifdef FSK_STAMP
-static __device__ unsigned long long g_stamp[4 * 2048 * 8];   // [wave][group][wait, total, HW_ID, four event counters, s_memrealtime at the loop's start]
+static __device__ unsigned long long g_stamp[8 * 2048 * 8];   // [wave][group][wait, total, HW_ID, four event counters, s_memrealtime at the loop's start]
 #define FSK_STAMP_DECL unsigned long long st_wait = 0, st_t0 = 0, st_w0 = 0, st_r0 = 0; unsigned st_c0 = 0, st_c1 = 0, st_c2 = 0, st_c3 = 0;
 #define FSK_STAMP_COUNT(i) st_c##i += 1u;
 #define FSK_STAMP_BEGIN st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime();

@@ -110,8 +110,101 @@ class FIRFilter(FIRFilterBatch):
         return float(self.processBuffer(self._np.array([x], dtype=self._np.float32))[0])
 
 
+class IIRFilterBatch:
+    """`new IIRFilter(b, a)` (filters.ts:8-106) for n_streams streams on one GPU: `processBuffer` on a float32 [S, N]
+    block (Float32Array in, Float32Array out), `processSamples` on a float64 block (what `process(x)` returns sample by
+    sample, nothing rounded to float), histories carried across calls, `reset`, `getCoefficients` (normalised by a[0]).
+    The constructor's three errors are the reference's (filters.ts:19-21), raised as ValueError with its messages."""
+
+    def __init__(self, b, a, n_streams=1, device=0, precision=_lib.PRECISION_F64):
+        import numpy as np
+        self._np = np
+        b = [float(v) for v in (b if b is not None else [])]
+        a = [float(v) for v in (a if a is not None else [])]
+        # filters.ts:19-21 (checked here too so that the errors do not need a GPU; the library checks again)
+        if len(b) == 0:
+            raise ValueError("Feedforward coefficients (b) cannot be empty")
+        if len(a) == 0:
+            raise ValueError("Feedback coefficients (a) cannot be empty")
+        if a[0] == 0:
+            raise ValueError("First feedback coefficient (a[0]) cannot be zero")
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self._L.fskhip_iir_create(device, (C.c_double * len(b))(*b), len(b), (C.c_double * len(a))(*a), len(a),
+                                             n_streams, precision, C.byref(h)))
+        self._h = h
+        self.n_streams = n_streams
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fskhip_iir_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _run(self, x, dtype, fn):
+        np = self._np
+        x = np.ascontiguousarray(x, dtype=dtype)
+        single = x.ndim == 1
+        if single:
+            x = x[None, :]
+        if x.shape[0] != self.n_streams:
+            raise ValueError("input must be [n_streams, n]")
+        out = np.empty_like(x)
+        if x.shape[1]:
+            _lib.check(fn(self._h, x.ctypes.data, x.shape[1], x.shape[1], out.ctypes.data, x.shape[1]))
+        return out[0] if single else out
+
+    def processBuffer(self, x):
+        return self._run(x, self._np.float32, self._L.fskhip_iir_process_host)
+
+    def processSamples(self, x):
+        return self._run(x, self._np.float64, self._L.fskhip_iir_process_f64_host)
+
+    def process_device(self, d_in, n, in_pitch, d_out, out_pitch, stream=None):
+        _lib.check(self._L.fskhip_iir_process_device(self._h, d_in, n, in_pitch, d_out, out_pitch, stream))
+
+    def reset(self, stream=-1):
+        _lib.check(self._L.fskhip_iir_reset(self._h, stream))
+
+    def getCoefficients(self):
+        b, a = (C.c_double * 9)(), (C.c_double * 9)()
+        nb, na = C.c_uint32(), C.c_uint32()
+        _lib.check(self._L.fskhip_iir_get_coefficients(self._h, b, C.byref(nb), a, C.byref(na)))
+        return {"b": list(b[:nb.value]), "a": list(a[:na.value])}
+
+
+class IIRFilter(IIRFilterBatch):
+    """One IIRFilter with the reference's per-sample surface: process(x) takes and returns a number."""
+
+    def __init__(self, b, a, device=0, precision=_lib.PRECISION_F64):
+        super().__init__(b, a, 1, device, precision)
+
+    def process(self, x):
+        return float(self.processSamples(self._np.array([x], dtype=self._np.float64))[0])
+
+
 class FilterFactory:
-    """FilterFactory.createFIR* (filters.ts:346-368)."""
+    """FilterFactory.createIIR* (filters.ts:325-344) and createFIR* (346-368)."""
+
+    @staticmethod
+    def createIIRLowpass(cutoffFreq, sampleRate, **kw):
+        d = FilterDesign.butterworthLowpass(cutoffFreq, sampleRate)
+        return IIRFilter(d["b"], d["a"], **kw)
+
+    @staticmethod
+    def createIIRHighpass(cutoffFreq, sampleRate, **kw):
+        d = FilterDesign.butterworthHighpass(cutoffFreq, sampleRate)
+        return IIRFilter(d["b"], d["a"], **kw)
+
+    @staticmethod
+    def createIIRBandpass(centerFreq, bandwidth, sampleRate, **kw):
+        d = FilterDesign.butterworthBandpass(centerFreq, bandwidth, sampleRate)
+        return IIRFilter(d["b"], d["a"], **kw)
 
     @staticmethod
     def createFIRLowpass(cutoffFreq, sampleRate, numTaps=51, **kw):
