@@ -1100,8 +1100,23 @@ int fskhip_modulate_device(fskhip_engine *e, const uint8_t *d_payloads, const ui
   if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "FSK modulator not configured");
   if (!d_lens || !d_out || !d_out_lens) return fail(FSKHIP_E_INVALID, "null buffer");
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(launch_modulate(e->M, e->S.coef, d_payloads, d_lens, payload_pitch, d_out, out_pitch, d_out_lens,
-                          (hipStream_t)hip_stream));
+  hipStream_t st = (hipStream_t)hip_stream;
+  const bool timed = e->timing;     // (fskhip_timing_begin / _end bracket modulate launches too: bench.py --workload mod)
+  if (timed) {
+    if (e->ev_used + 2 > e->ev.size()) {
+      hipEvent_t a, b;
+      HIP_TRY(hipEventCreate(&a));
+      HIP_TRY(hipEventCreate(&b));
+      e->ev.push_back(a); e->ev.push_back(b);
+    }
+    e->timing_stream = st;
+    HIP_TRY(hipEventRecord(e->ev[e->ev_used], st));
+  }
+  HIP_TRY(launch_modulate(e->M, e->S.coef, d_payloads, d_lens, payload_pitch, d_out, out_pitch, d_out_lens, st));
+  if (timed) {
+    HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], st));
+    e->ev_used += 2;
+  }
   return FSKHIP_OK;
 }
 

@@ -168,8 +168,9 @@ __device__ inline float4 frame_next4(FrameGen &G, const ModParams &M, ByteFn pay
 
 // coalesced store of a 64-row x 32-sample LDS tile (rows = this wave's streams)
 __device__ inline void store_tile(const float4 *stage, float *out, size_t pitch, size_t t0, size_t row_len_limit,
-                                  uint32_t n_streams, const uint32_t *row_lens_lds, int vec_ok) {
-  const uint32_t lane = threadIdx.x, sub_row = lane / kChunks, chunk = lane % kChunks;
+                                  uint32_t n_streams, const uint32_t *row_lens_lds, int vec_ok, uint32_t lane = 0xFFFFFFFFu) {
+  if (lane == 0xFFFFFFFFu) lane = threadIdx.x;      // (one-wave blocks; modulate_wide_kernel passes the lane of its storing wave)
+  const uint32_t sub_row = lane / kChunks, chunk = lane % kChunks;
 #pragma unroll
   for (int i = 0; i < kChunks; i++) {
     uint32_t lr = (uint32_t)kRowsPerLoad * i + sub_row;
@@ -236,6 +237,145 @@ __global__ __launch_bounds__(64) void modulate_kernel(ModParams M, const double 
     store_tile(stage, out, out_pitch, t0, 0, M.n_streams, row_len, vec_ok);
   }
   (void)stage_f;
+}
+
+// ---- modulateData, several waves per 64-stream group (round 5) -----------------------------------------------------------
+// modulate_kernel above is one wave per 64 streams, and what it spends its time on is not the sine: every sample goes through
+// three nested per-lane conditionals (inside the frame? inside the tones? a new bit?), which compile to exec-mask branches
+// of ~35 cycles each for a lone wave -- ~250 of the ~300 cycles a sample takes -- and 16 384 streams are 256 waves on 1 024
+// SIMDs.  Here the control is UNIFORM: all streams of a call share samplesPerBit and start together, so sample positions, bit
+// boundaries and tile boundaries are scalars; per lane there is only the bit's value, the end of the lane's own tones (payload
+// lengths may differ) and the phase.  A tile is 32 samples; with samplesPerBit >= 32 it holds at most one bit boundary, so the
+// phase chain of a tile is 32 x {w = (j >= jb ? w_next : w_cur), masked by "this lane still has tones"; ph[j] = phase; phase +=
+// w} -- the reference's additions in the reference's order, straight-line.  EVERY wave of the workgroup runs that chain (it is
+// the only sequential part: one f64 addition per sample) and the wave that owns a tile -- tile index mod the number of waves
+// -- alone evaluates the tile's 32 sines, which are independent, and stores it.  Values are those of modulate_kernel bit for
+// bit (same phases, same sine).
+static constexpr int kModWaves = 7;     // (7 x 8 320 B of staging tiles: under the 64 KB of static LDS)
+template <bool EXACT>
+__global__ __launch_bounds__(64 * kModWaves) void modulate_wide_kernel(ModParams M, const double *__restrict__ coef,
+                                                                       const uint8_t *__restrict__ payloads,
+                                                                       const uint32_t *__restrict__ lens, size_t payload_pitch,
+                                                                       float *__restrict__ out, size_t out_pitch, int vec_ok,
+                                                                       uint32_t *__restrict__ out_lens) {
+  __shared__ float4 stage_all[kModWaves][kChunks * kSlotStride];
+  __shared__ uint32_t row_len[64];
+  __shared__ uint32_t max_len_s;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t stream = blockIdx.x * 64u + lane;
+  const bool valid = stream < M.n_streams;
+  const uint32_t row = valid ? stream : M.n_streams - 1;
+  const size_t ns = M.n_streams;
+  const uint32_t n_payload = lens[row];
+  const uint8_t *prow = payloads + (size_t)row * payload_pitch;
+  const double wm = coef[(size_t)CF_mark_w * ns + row], ws = coef[(size_t)CF_space_w * ns + row];
+  const uint32_t spb = M.spb;
+  const uint32_t total_bytes = M.n_pre + n_payload;
+  const uint32_t n_bits = total_bytes * M.bits_per_byte;            // this lane's tone bits
+  const uint32_t sig_begin = 2u * spb;                               // (lanes with nothing to send have no tones: n_bits = 0)
+  const uint32_t sig_end = total_bytes ? sig_begin + n_bits * spb : 0u;
+  const uint32_t frame_len = sig_end + M.bits_per_byte * spb;        // fsk.ts:391-394
+  uint32_t my_len = frame_len;
+  if ((size_t)my_len > out_pitch) my_len = (uint32_t)out_pitch;      // caller reports overflow from out_lens
+  if (q == 0) {
+    row_len[lane] = valid ? my_len : 0u;
+    if (valid) out_lens[stream] = frame_len;
+    uint32_t mx = my_len;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(mx, o, 64); mx = t > mx ? t : mx; }
+    if (lane == 0) max_len_s = mx;
+  }
+  __syncthreads();
+  const uint32_t max_len = max_len_s;
+  float4 *stage = stage_all[q];
+  // payload bytes one byte AHEAD of their use: the load's round trip (every wave needs the bit's value before it can go on
+  // adding) is off the chain.  Bits are asked for in order, so the byte index only ever moves on by one.
+  uint32_t pay_idx = 0;                                               // payload byte index of pay_cur
+  uint32_t pay_cur = n_payload > 0u ? prow[0] : 0u, pay_nxt = n_payload > 1u ? prow[1] : 0u;
+  auto pb = [&](uint32_t i) -> uint8_t {
+    if (i != pay_idx) {                                               // (i == pay_idx + 1)
+      pay_cur = pay_nxt; pay_idx = i;
+      pay_nxt = i + 1u < n_payload ? prow[i + 1u] : 0u;
+    }
+    return (uint8_t)pay_cur;
+  };
+  auto w_of_bit = [&](uint32_t b) -> double {                         // phase increment of tone bit b of this lane (0 beyond its tones)
+    uint32_t bit = 0u;
+    if (b < n_bits) bit = frame_bit(M, b, pb);
+    return b < n_bits ? (bit ? wm : ws) : 0.0;
+  };
+  double phase = 0.0;
+  double w_cur = 0.0;
+  uint32_t b_have = 0xFFFFFFFFu;                                       // the bit w_cur belongs to (uniform)
+  uint32_t tile = 0;
+  for (uint32_t t0 = 0; t0 < max_len; t0 += kTile, tile++) {
+    // ---- the tile's phases: every wave
+    const int32_t rel = (int32_t)t0 - (int32_t)sig_begin;             // position of sample 0 of the tile inside the tones (uniform)
+    double ph[kTile];
+    uint32_t tone = 0u;
+    if (rel + (int32_t)kTile > 0) {
+      const uint32_t r0 = rel > 0 ? (uint32_t)rel : 0u;
+      const uint32_t b0 = r0 / spb;                                   // bit of the tile's first tone sample
+      if (b0 != b_have) { w_cur = w_of_bit(b0); b_have = b0; }
+      const int32_t jb = (int32_t)((b0 + 1u) * spb) - rel;           // first sample of the tile in the next bit (>= kTile: none; spb >= kTile)
+      double w_next = 0.0;
+      if (jb < (int32_t)kTile) w_next = w_of_bit(b0 + 1u);
+#pragma unroll
+      for (int j = 0; j < kTile; j++) {
+        const bool in_tones = rel + j >= 0;                           // uniform
+        const bool act = in_tones && (t0 + (uint32_t)j) < sig_end;
+        const double wsel = j >= jb ? w_next : w_cur;                 // uniform choice between two per-lane values
+        const double wj = act ? wsel : 0.0;
+        ph[j] = phase;
+        phase = phase + wj;                                           // fsk.ts:404 (adding +0.0 outside the tones leaves it as it is)
+        tone |= act ? (1u << j) : 0u;
+      }
+      if (jb < (int32_t)kTile) { w_cur = w_next; b_have = b0 + 1u; }
+    }
+    if ((tile % (uint32_t)kModWaves) != q) continue;
+    // ---- this wave's tile: the sines (independent: scheduled as straight-line blocks of eight), transposed through LDS, stored
+    if (__builtin_amdgcn_ballot_w64(tone != 0u) == 0ull) {          // padding: zeros (fsk.ts:391-396)
+#pragma unroll
+      for (int c = 0; c < kChunks; c++) stage[c * kSlotStride + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int c = 0; c < kChunks; c += 2) {
+        float o[8];
+        double sv[8], p8[8];
+        bool tn[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          tn[j] = ((tone >> (4 * c + j)) & 1u) != 0u;
+          p8[j] = tn[j] ? ph[4 * c + j] : 4.0;                          // (any value of the straight-line case where there is no tone)
+        }
+        if (EXACT) {
+          bool slow[8];
+          bool any_slow = false;
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            sv[j] = fdlibm::sin_straight(p8[j], &slow[j]);
+            any_slow |= slow[j] & tn[j];
+          }
+          if (__builtin_amdgcn_ballot_w64(any_slow)) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+              if (slow[j] & tn[j]) sv[j] = ref_sin(p8[j]);              // first samples of a frame (phase < 3pi/4), near-multiples of pi/2, ...
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) sv[j] = sin(p8[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = tn[j] ? (float)sv[j] : 0.0f;
+        stage[c * kSlotStride + lane] = make_float4(o[0], o[1], o[2], o[3]);
+        stage[(c + 1) * kSlotStride + lane] = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // (one wave: its own writes, in order)
+    store_tile(stage, out, out_pitch, t0, 0, M.n_streams, row_len, vec_ok, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
 }
 
 // synthetic workload: see fskhip_synth_device in include/fskhip.h
@@ -495,6 +635,15 @@ hipError_t launch_modulate(const ModParams &M, const double *coef, const uint8_t
                            size_t payload_pitch, float *out, size_t out_pitch, uint32_t *out_lens, hipStream_t st) {
   const uint32_t blocks = (M.n_streams + 63u) / 64u;
   const int vec_ok = (out_pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+  if (M.spb >= (uint32_t)kTile) {      // (at most one bit boundary per 32-sample tile: the uniform-control kernel)
+    if (M.exact_sin)
+      hipLaunchKernelGGL(modulate_wide_kernel<true>, dim3(blocks), dim3(64 * kModWaves), 0, st, M, coef, payloads, lens, payload_pitch, out,
+                         out_pitch, vec_ok, out_lens);
+    else
+      hipLaunchKernelGGL(modulate_wide_kernel<false>, dim3(blocks), dim3(64 * kModWaves), 0, st, M, coef, payloads, lens, payload_pitch, out,
+                         out_pitch, vec_ok, out_lens);
+    return hipGetLastError();
+  }
   if (M.exact_sin)
     hipLaunchKernelGGL(modulate_kernel<true>, dim3(blocks), dim3(64), 0, st, M, coef, payloads, lens, payload_pitch, out,
                        out_pitch, vec_ok, out_lens);
