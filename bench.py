@@ -73,6 +73,10 @@ WORKLOADS = {
     # resets (fsk.ts:285-295), with independent timing per stream.
     "idle": dict(cfg=dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200), payload=100, snr=None, num="3 (idle variant)",
                  desc="Bell-202 1200 baud @48 kHz, ONE frame per stream then a noise floor 30 dB under it", idle_db=30.0),
+    # idle4 (round 5): the same idle regime with per-stream tone pairs (config #4's kind: per-lane NCO in the block path with resets)
+    "idle4": dict(cfg=dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200), payload=100, snr=None, num="4 (idle variant, 1200 baud)",
+                  desc="1200 baud @48 kHz, per-stream tone pairs, ONE frame per stream then a noise floor 30 dB under it", idle_db=30.0,
+                  per_stream=True, tones1200=True),
     # c1x: BASELINE config #1's tone pair as written (mark 1270 / space 1070: the polarity the reference does not decode) at
     # config #3's stream count: a bank that searches for a preamble all the time and never finds one (fsk.ts:297-328)
     "c1x": dict(cfg=dict(baudRate=300, markFrequency=1270, spaceFrequency=1070), payload=32, snr=None, num="1 (x 65 536)",
@@ -400,7 +404,7 @@ def worker_mod(args):
                        "streams_per_gpu": S, "frames_per_stream": m["frames"], "samples_per_frame": m["frame_len"],
                        "parallelism": "streams sharded across %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel": "fsk::modulate_kernel<%s>" % ("true" if args.precision == "f64" else "false"),
+                         "traffic": None, "kernel": "fsk::modulate_wide_kernel<%s>" % ("true" if args.precision == "f64" else "false"),
                          "avg_kernel_ms": round(m["kernel_ms_per_step"] / max(1, m["launches_per_step"]), 4), "launches": m["launches_per_step"] * args.steps,
                          "algorithmic_bytes_per_launch": alg / max(1, m["launches_per_step"]),
                          "binding_note": "4 B written per output sample; the kernel is bound by the f64 phase / sine chain of one lane per stream, not by HBM"},
@@ -476,6 +480,8 @@ def worker(args):
     def per_stream_cfgs(first, count):
         if not wl.get("per_stream"):   # config #4: every stream its own tone pair (per-stream constants in the kernels)
             return None
+        if wl.get("tones1200"):
+            return [dict(cfg, markFrequency=1200 + 7 * ((first + s) % 13), spaceFrequency=2200 + 5 * ((first + s) % 11)) for s in range(count)]
         return [dict(cfg, markFrequency=1000 + 10 * ((first + s) % 100), spaceFrequency=1200 + 10 * ((first + s) % 100))
                 for s in range(count)]
 
@@ -668,7 +674,7 @@ def worker(args):
             rm = mm["samples_per_step"] / (mm["kernel_ms_per_step"] / 1e3) / 1e6
             side["modulate"] = {"streams": s_mod, "frames_per_stream": mm["frames"], "samples_per_frame": mm["frame_len"],
                                 "Msamples_per_s": round(rm, 1), "write_GB_per_s": round(rm * 4 / 1e3, 1),
-                                "frac_of_hbm_peak": round(rm * 4 / 1e3 / HBM_PEAK_GBS, 4), "kernel": "fsk::modulate_kernel<false>",
+                                "frac_of_hbm_peak": round(rm * 4 / 1e3 / HBM_PEAK_GBS, 4), "kernel": "fsk::modulate_wide_kernel<false>",
                                 "note": "fskhip_modulate_device, kernel time from the library's HIP events; `bench.py --workload mod` is the full line"}
             del mm
             em.close()

@@ -14,6 +14,8 @@
 //   sincLowpass/sincHighpass(cutoff, sampleRate, numTaps), sincBandpass(center, bandwidth, sampleRate, numTaps) -> Float64Array
 //   firCreate(taps: Float64Array, nStreams, device, precision) -> handle;  firDestroy(handle)
 //   firProcess(handle, input: Float32Array, n, pitch, nStreams) -> Float32Array;  firReset(handle, stream)
+//   iirCreate(b, a: Float64Array, nStreams, device, precision) -> handle; iirProcess(handle, Float32Array | Float64Array, n, pitch, nStreams);
+//   iirCoefficients(handle), iirReset(handle, stream), iirDestroy(handle); butterworth(kind, f, bandwidth, sampleRate) -> [b0 b1 b2 a0 a1 a2]
 #include <node_api.h>
 
 #include <cstdint>
@@ -328,6 +330,88 @@ napi_value FirReset(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// ---- IIRFilter (src/dsp/filters.ts:8-106) ----
+napi_value IirCreate(napi_env env, napi_callback_info info) {   // (b: Float64Array, a: Float64Array, nStreams, device, precision)
+  ARGS(5);
+  void *b, *a; size_t nb, na;
+  if (!typed(env, argv[0], napi_float64_array, &b, &nb) || !typed(env, argv[1], napi_float64_array, &a, &na)) return nullptr;
+  fskhip_iir *f = nullptr;
+  int rc = fskhip_iir_create(i32(env, argv[3]), (const double *)b, (uint32_t)nb, (const double *)a, (uint32_t)na, u32(env, argv[2]), i32(env, argv[4]), &f);
+  if (rc != FSKHIP_OK) return throw_fsk(env, rc);
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, f, nullptr, nullptr, &ext));
+  return ext;
+}
+napi_value IirDestroy(napi_env env, napi_callback_info info) {
+  ARGS(1);
+  void *p = nullptr;
+  if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) fskhip_iir_destroy((fskhip_iir *)p);
+  return nullptr;
+}
+napi_value IirCoefficients(napi_env env, napi_callback_info info) {   // -> Float64Array [nb, na, b..., a...]
+  ARGS(1);
+  fskhip_iir *f = (fskhip_iir *)external(env, argv[0], "filter destroyed");
+  if (!f) return nullptr;
+  double b[9], a[9];
+  uint32_t nb = 0, na = 0;
+  int rc = fskhip_iir_get_coefficients(f, b, &nb, a, &na);
+  if (rc != FSKHIP_OK) return throw_fsk(env, rc);
+  void *out;
+  napi_value out_v = make_typed(env, napi_float64_array, 2 + nb + na, 8, &out);
+  double *o = (double *)out;
+  o[0] = nb; o[1] = na;
+  for (uint32_t i = 0; i < nb; i++) o[2 + i] = b[i];
+  for (uint32_t i = 0; i < na; i++) o[2 + nb + i] = a[i];
+  return out_v;
+}
+napi_value IirProcess(napi_env env, napi_callback_info info) {   // Float32Array in -> Float32Array (processBuffer); Float64Array in -> Float64Array (process)
+  ARGS(5);
+  fskhip_iir *f = (fskhip_iir *)external(env, argv[0], "filter destroyed");
+  if (!f) return nullptr;
+  napi_typedarray_type ty; size_t ilen; void *in; napi_value ab; size_t off;
+  if (napi_get_typedarray_info(env, argv[1], &ty, &ilen, &in, &ab, &off) != napi_ok || (ty != napi_float32_array && ty != napi_float64_array)) {
+    napi_throw_type_error(env, nullptr, "Float32Array or Float64Array expected");
+    return nullptr;
+  }
+  const uint32_t n = u32(env, argv[2]), pitch = u32(env, argv[3]), S = u32(env, argv[4]);
+  if (S == 0 || pitch < n || (size_t)pitch * (S - 1) + n > ilen) { napi_throw_range_error(env, nullptr, "input too short"); return nullptr; }
+  void *out;
+  int rc;
+  napi_value out_v;
+  if (ty == napi_float32_array) {
+    out_v = make_typed(env, napi_float32_array, (size_t)n * S, 4, &out);
+    rc = fskhip_iir_process_host(f, (const float *)in, n, pitch, (float *)out, n);
+  } else {
+    out_v = make_typed(env, napi_float64_array, (size_t)n * S, 8, &out);
+    rc = fskhip_iir_process_f64_host(f, (const double *)in, n, pitch, (double *)out, n);
+  }
+  if (rc != FSKHIP_OK) return throw_fsk(env, rc);
+  return out_v;
+}
+napi_value IirReset(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  fskhip_iir *f = (fskhip_iir *)external(env, argv[0], "filter destroyed");
+  if (!f) return nullptr;
+  int64_t s = -1;
+  napi_get_value_int64(env, argv[1], &s);
+  int rc = fskhip_iir_reset(f, s);
+  if (rc != FSKHIP_OK) return throw_fsk(env, rc);
+  return nullptr;
+}
+napi_value Butterworth(napi_env env, napi_callback_info info) {   // (kind 0 lowpass | 1 highpass | 2 bandpass, f, [bandwidth,] sampleRate) -> Float64Array [b0 b1 b2 a0 a1 a2]
+  ARGS(4);
+  const int kind = i32(env, argv[0]);
+  double b[3], a[3];
+  if (kind == 0) fskhip_butterworth_lowpass(f64(env, argv[1]), f64(env, argv[3]), b, a);
+  else if (kind == 1) fskhip_butterworth_highpass(f64(env, argv[1]), f64(env, argv[3]), b, a);
+  else fskhip_butterworth_bandpass(f64(env, argv[1]), f64(env, argv[2]), f64(env, argv[3]), b, a);
+  void *out;
+  napi_value out_v = make_typed(env, napi_float64_array, 6, 8, &out);
+  double *o = (double *)out;
+  for (int i = 0; i < 3; i++) { o[i] = b[i]; o[3 + i] = a[i]; }
+  return out_v;
+}
+
 }  // namespace
 
 napi_value InitNext(napi_env env, napi_value exports) {
@@ -350,6 +434,12 @@ napi_value InitNext(napi_env env, napi_value exports) {
       {"firDestroy", nullptr, FirDestroy, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"firProcess", nullptr, FirProcess, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"firReset", nullptr, FirReset, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"iirCreate", nullptr, IirCreate, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"iirDestroy", nullptr, IirDestroy, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"iirCoefficients", nullptr, IirCoefficients, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"iirProcess", nullptr, IirProcess, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"iirReset", nullptr, IirReset, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"butterworth", nullptr, Butterworth, nullptr, nullptr, nullptr, napi_default, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

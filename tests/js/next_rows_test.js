@@ -31,6 +31,11 @@ async function cpuTests() {
   if (M.addon.deviceCount() === 0) {
     assert.throws(() => X.CRC16.calculate(Uint8Array.of(1, 2, 3)), /no CPU fallback/);
     assert.throws(() => new F.FIRFilter([0.5, 0.5]), /no CPU fallback/);
+    assert.throws(() => new F.IIRFilter([], [1]), /Feedforward coefficients \(b\) cannot be empty/);        // filters.ts:19-21
+    assert.throws(() => new F.IIRFilter([1], []), /Feedback coefficients \(a\) cannot be empty/);
+    assert.throws(() => new F.IIRFilter([1], [0, 1]), /First feedback coefficient \(a\[0\]\) cannot be zero/);
+    assert.throws(() => new F.IIRFilter([1, 2], [1, 0.5]), /no CPU fallback/);
+    assert.strictEqual(F.FilterDesign.butterworthBandpass(1750, 2600, 48000).b[0], 0.1430310558532532);   // (host arithmetic: no GPU needed)
   }
   console.log('js next cpu tests ok');
 }
@@ -179,6 +184,36 @@ async function gpuTests() {
     const gain = lp.getCoefficients().reduce((a, b) => a + b, 0);
     assert.ok(Math.abs(dc[199] - gain) < 1e-6);       // DC gain = sum of taps
     lp.close();
+  }
+  // ---- IIR (src/dsp/filters.ts:8-106; tests/dsp/filters-advanced.node.test.ts:115-143) ----
+  {
+    // KATs of SURVEY.md section 8 (a4 / a5)
+    const lpd = F.FilterDesign.butterworthLowpass(1200, 48000);
+    assert.strictEqual(lpd.b[0], 0.005542717210280682); assert.strictEqual(lpd.a[1], -1.7786317778245848); assert.strictEqual(lpd.a[2], 0.8008026466657076);
+    const f = new F.IIRFilter([2.0, 1.0, 0.5], [2.0, -0.5, 0.25]);          // a0 normalisation
+    assert.deepStrictEqual(f.getCoefficients(), { b: [1.0, 0.5, 0.25], a: [1.0, -0.25, 0.125] });
+    // the difference equation by hand, in doubles, in the reference's order
+    const b = [1.0, 0.5, 0.25], a = [1.0, -0.25, 0.125], xs = [1, 0.5, -0.25, 0.125, 0, 0, 1, -1], want = [];
+    let x1 = 0, x2 = 0, y1 = 0, y2 = 0;
+    for (const x of xs) {
+      let o = 0; o += b[0] * x; o += b[1] * x1; o += b[2] * x2; o -= a[1] * y1; o -= a[2] * y2;
+      want.push(o); x2 = x1; x1 = x; y2 = y1; y1 = o;
+    }
+    assert.deepStrictEqual(xs.map((x) => f.process(x)), want);
+    f.reset();
+    assert.deepStrictEqual(Array.from(f.processBuffer(Float32Array.from(xs))), want.map((v) => Math.fround(v)));
+    f.close();
+    const lp = F.FilterFactory.createIIRLowpass(1200, 48000);
+    const dc = lp.processBuffer(new Float32Array(2000).fill(1));
+    assert.ok(Math.abs(dc[1999] - 1) < 1e-4);                                  // unity DC gain
+    lp.close();
+    const many = new F.IIRFilterBatch(lpd.b, lpd.a, 70);
+    const blk = new Float32Array(70 * 64);
+    for (let i = 0; i < blk.length; i++) blk[i] = Math.sin(i * 0.37) * ((i >> 6) + 1);
+    const ym = many.processBuffer(blk);
+    const one = new F.IIRFilter(lpd.b, lpd.a);
+    assert.deepStrictEqual(Array.from(ym.subarray(69 * 64, 70 * 64)), Array.from(one.processBuffer(blk.subarray(69 * 64, 70 * 64))));
+    one.close(); many.close();
   }
   console.log('js next gpu tests ok');
 }

@@ -901,3 +901,65 @@ def test_six_wave_is_the_default_for_small_uniform_batches():
         assert want in eng.last_kernel(), (S, n, eng.last_kernel())
         eng.device_free(d_x)
         eng.close()
+
+
+def test_idle_receiver_bank_with_per_stream_tone_pairs():
+    """Round 5: the idle regime for streams that each have their OWN tone pair (BASELINE config #4's kind): one
+    frame per stream, then a floor 30 dB under it, every stream firing 'eod' and resetting on its own schedule.  The block path
+    that takes resets now evaluates the direct instance's NCO phasors and lastPhase per lane (demod_blk_kernel_rp); it, the plain
+    four-wave kernel (per-sample path), the two-wave kernel and several call schedules must agree for every stream -- bytes,
+    'eod' counts, carried state words -- and a strided sample with the oracle."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    S, N, payload, lead_max = 700, 120000, 40, 400
+    cfgs = [dict(BELL, markFrequency=1200 + 7 * (s % 13), spaceFrequency=2200 + 5 * (s % 11)) for s in range(S)]
+    gen = wm.FSKEngine(S, cfgs, precision=wm.PRECISION_F32)
+    frame_len = gen.modulated_length(payload)
+    n0 = (lead_max + frame_len + 31) // 32 * 32
+    d_x = gen.device_malloc(S * N * 4)
+    gen.synth_device(d_x, n0, N, payload, SEED + 41, lead_max, 0.1, 1.0)
+    gen.synchronize()
+    row = np.empty(N, np.float32)
+    rng = np.random.RandomState(11)
+    x = np.zeros((S, N), np.float32)
+    for s in range(S):
+        gen.d2h(row, d_x + s * N * 4)
+        lead, _amp = gen.synth_stream_params(SEED + 41, s, lead_max, 0.1, 1.0)
+        end = lead + frame_len
+        x[s, :end] = row[:end]
+        p_frame = float(np.mean(row[lead:end].astype(np.float64) ** 2))
+        x[s] += rng.normal(0.0, np.sqrt(p_frame / 1000.0), N).astype(np.float32)
+    gen.h2d(d_x, x)
+    results = {}
+    for name, opts, schedule in (("plain", {"kernel": "four-wave", "blk_resets": 0}, [N]), ("resets", {"kernel": "four-wave", "blk_resets": 1}, [N]),
+                                 ("resets_quanta", {"kernel": "four-wave", "blk_resets": 1}, [4800, 128, 17, 30000]),
+                                 ("resets_redo", {"kernel": "four-wave", "blk_resets": 2}, [16000]), ("two_wave", {"kernel": "two-wave"}, [N]),
+                                 ("auto", {}, [24000])):
+        eng = wm.FSKEngine(S, cfgs, precision=wm.PRECISION_F32, options=opts)
+        rows, eod = _demod_schedule(eng, d_x, N, N, schedule)
+        if name == "resets":
+            assert eng.last_kernel().startswith("fsk::demod_blk_kernel_rp<"), eng.last_kernel()
+        if name == "plain":
+            assert eng.last_kernel().startswith("fsk::demod_blk_kernel<false, false"), eng.last_kernel()
+        if name == "auto":
+            assert eng.last_kernel().startswith("fsk::demod_blk_kernel_rp<"), eng.last_kernel()      # (the statistics of four calls of floor behind it)
+        results[name] = (rows, eod, [eng.debug_state(s_) for s_ in range(0, S, 23)])
+        eng.close()
+    base = _digest(results["plain"][0], results["plain"][1])
+    for name, r in results.items():
+        assert _digest(r[0], r[1]) == base, name
+    for name in ("resets", "resets_redo", "two_wave"):      # (same number of samples in: the state words must be the same too)
+        for (ra, ia), (rb, ib) in zip(results["plain"][2], results[name][2]):
+            assert np.array_equal(np.asarray(ra).view(np.uint64), np.asarray(rb).view(np.uint64)), name
+            assert ia == ib, name
+    rows1, eod1 = results["plain"][0], results["plain"][1]
+    hit = 0
+    sample = list(range(0, S, S // 10)) + [S - 1]
+    for s in sample:
+        ob, oe = po.OracleCore(cfgs[s]).demodulate(x[s])
+        assert rows1[s] == ob and int(eod1[s]) == oe, s
+        hit += gen.synth_payload(SEED + 41, s, 0, payload) in rows1[s]
+    assert hit >= len(sample) * 0.6
+    assert int(np.median(eod1)) >= 50
+    gen.device_free(d_x)
+    gen.close()

@@ -893,7 +893,6 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
             ((blk_fits && n_fast / 16 >= e->blk_min_tiles) || e->split_forced)) {
           engine_refresh_kernel_choice(e);
           uint32_t med = e->blk_medium == 3u ? (e->blk_med_now ? 1u : 0u) : e->blk_medium;
-          if (!e->P.uni_cfg) med = 0u;
           // six waves per group: narrow groups (<= 32 streams: the stages that are not recurrences spread over the idle lanes;
           // measured x1.20 at <= 2 048 streams, x1.14 at 4 096, x1.06 at 8 192 and x0.93 with whole-wave groups at 16 384,
           // profiles/r05_six_wave.txt), every workgroup a compute unit to itself, a uniform configuration, resets rare (the
@@ -937,6 +936,10 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
               "fsk::demod_blk_kernel<true, true, false>", "fsk::demod_blk_kernel<true, true, true>",
               "fsk::demod_blk_kernel_r<false, false>", "fsk::demod_blk_kernel_r<false, true>",
               "fsk::demod_blk_kernel_r<true, false>", "fsk::demod_blk_kernel_r<true, true>"};
+          static const char *const names_rp[4] = {"fsk::demod_blk_kernel_rp<false, false>", "fsk::demod_blk_kernel_rp<false, true>",
+                                                  "fsk::demod_blk_kernel_rp<true, false>", "fsk::demod_blk_kernel_rp<true, true>"};
+          if (med && !e->P.uni_cfg) e->last_kernel = names_rp[(wb ? 2 : 0) + (e->last_sliced ? 1 : 0)];
+          else
           e->last_kernel = med ? names[8 + (wb ? 2 : 0) + (e->last_sliced ? 1 : 0)]                  // <writeback, time-sliced>
                                : names[(wb ? 4 : 0) + (e->P.uni_cfg ? 2 : 0) + (e->last_sliced ? 1 : 0)];   // <writeback, uniform, time-sliced>
           }

@@ -130,10 +130,15 @@ __device__ inline void med_unstash(BackLane &B, __amdgpu_buffer_rsrc_t rs, uint3
 }
 
 // (works on Bn IN PLACE: the caller has parked the entry state with med_stash)
+// UNI = false (round 5: per-stream tone pairs, BASELINE config #4's kind): every lane has its own NCO, so the direct instance's
+// phasors are evaluated here per lane (nco_phasor of the lane's free-running accumulator: what zir_step does without a phasor
+// tile) and so is lastPhase after a reset (back_reset's expression); k0 = decimated samples of the launch before the tile.
+template <bool UNI>
 __device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t matched_min, uint32_t kv0,
                                       const v4f *slot, const v4f *slot2, const v4f *ys0, const v4f *ys1, uint32_t lane,
                                       const v4f *ztile, const float (&thf8)[kBlk], const uint32_t *prow, uint32_t pidx, uint32_t pidx2,
-                                      float (&am)[kBlk], uint32_t &bq, uint32_t &nq, MedEv &E, uint32_t &w_out) {
+                                      float (&am)[kBlk], uint32_t &bq, uint32_t &nq, MedEv &E, uint32_t &w_out,
+                                      uint64_t free0 = 0, uint64_t inc = 0, uint32_t k0 = 0) {
   uint32_t w = 0, hard = 0;
   uint32_t matched = Bn.matched, thr_cur = Bn.thr_eff, ls = Bn.ls;
   E.jr = 0; E.jc = 0; E.cai = E.caq = E.cbi = E.cbq = 0.f;
@@ -142,7 +147,8 @@ __device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &
   // ones from the old ones and the block's slicer bits), the phasors.  Read one pair AHEAD of the arithmetic (the wave runs
   // alone: an LDS round trip it waits for is ~120 cycles of nothing); the fences keep the compiler from reading all eight
   // samples' inputs up front -- 40 registers it does not have.
-  v4f pe_n = slot[lane], ye_n = ys0[lane], zz0_n = ztile[0], zz1_n = ztile[1];
+  v4f pe_n = slot[lane], ye_n = ys0[lane], zz0_n = {}, zz1_n = {};
+  if (UNI) { zz0_n = ztile[0]; zz1_n = ztile[1]; }
   uint2 rp_n = *reinterpret_cast<const uint2 *>(prow + pidx);
 #pragma unroll
   for (int jj = 0; jj < kBlk / 2; jj++) {
@@ -154,7 +160,7 @@ __device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &
       pe_n = (jn < 2 ? slot : slot2)[(jn & 1) * 64 + (int)lane];
       ye_n = (jn < 2 ? ys0 : ys1)[(jn & 1) * 64 + (int)lane];
       rp_n = *reinterpret_cast<const uint2 *>(prow + (jn < 2 ? pidx : pidx2) + 2 * (jn & 1));
-      zz0_n = ztile[2 * jn]; zz1_n = ztile[2 * jn + 1];
+      if (UNI) { zz0_n = ztile[2 * jn]; zz1_n = ztile[2 * jn + 1]; }
     }
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -163,7 +169,19 @@ __device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &
     const float e0 = h ? pe.z : pe.x, e1 = h ? pe.w : pe.y;
     const float y0 = h ? ye2.z : ye2.x, y1 = h ? ye2.w : ye2.y;
     const uint32_t kvj = kv0 + (uint32_t)(j + 1);
-    const v4f z = h ? zz1 : zz0;                                             // (c0, s0, c1, s1) of the pair's two input samples
+    v4f z = h ? zz1 : zz0;                                                   // (c0, s0, c1, s1) of the pair's two input samples
+    float thf_j = thf8[j];
+    if (!UNI) {
+      const uint64_t n0 = (uint64_t)(2u * (k0 + (uint32_t)j));
+      float c0, s0, c1, s1;
+      nco_phasor(free0 + inc * n0, c0, s0);
+      nco_phasor(free0 + inc * (n0 + 1ull), c1, s1);
+      z = (v4f){c0, s0, c1, s1};
+      const uint64_t fr0 = free0 + inc * (uint64_t)(2u * (k0 + (uint32_t)j + 1u));
+      double r = (double)fr0 * 5.42101086242752217e-20 * 6.283185307179586476925;   // 2^-64 turns -> radians (back_reset)
+      r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
+      thf_j = (float)r;
+    }
     // ---- zir_step<UNI, HAND = true>, flat
     const uint32_t dph0 = Bn.dph;
     float wi = e0 - Bn.qai, wq = e1 - Bn.qaq;
@@ -236,8 +254,8 @@ __device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &
     hard |= me & (0u - E.jr);                                                // a second reset in the block
     E.jr = bsel(me, (uint32_t)(j + 1), E.jr);
     asm volatile("" : "+v"(E.jr), "+v"(hard));
-    Bn.last_phase = bself(me, thf8[j], Bn.last_phase);
-    Bn.thf = bself(me, thf8[j], Bn.thf);
+    Bn.last_phase = bself(me, thf_j, Bn.last_phase);
+    Bn.thf = bself(me, thf_j, Bn.thf);
     const uint32_t keep = ~me;
     Bn.dph &= keep;
     Bn.dix1 = bzero(keep, Bn.dix1); Bn.dix2 = bzero(keep, Bn.dix2); Bn.diy = bzero(keep, Bn.diy); Bn.dvi = bzero(keep, Bn.dvi);
@@ -937,7 +955,7 @@ __device__ __forceinline__ void demod_blk_body(
       // 'eod' from a sync candidate at the fast loop's exit would keep blk_fast's second flag word alive in this kernel: 3.6 % at
       // 8 192 streams)
       if (!MED && rare_exit && X.zlive != 0u) rare_tiles++;
-      if (MED && rare_exit && !hard_exit && UNI && Z.medium != 0u) {
+      if (MED && rare_exit && !hard_exit && Z.medium != 0u) {
         // an 'eod' in the tile at t, or a lane inside this wave's own span after one: the block path that takes resets
         // (blk_medium), in place, the tile's entry state parked in the engine's stash
         const uint32_t slot_j = slot_i + 1u;
@@ -949,8 +967,8 @@ __device__ __forceinline__ void demod_blk_body(
         const v4f *ztile = zt + ((t >> 1) & ZTM) * 8u;
         // lastPhase after a resetState() at the end of sample j of this tile: the free-running frame's phase there
         // (back_reset's expression; lane j evaluates it, the wave reads it back as a scalar)
-        float thf8[kBlk];
-        {
+        float thf8[kBlk] = {};
+        if (UNI) {
           const uint64_t fr0 = X.free0 + inc * (uint64_t)(2u * (X.k + (lane & 7u) + 1u));
           double r = (double)fr0 * 5.42101086242752217e-20 * 6.283185307179586476925;
           r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
@@ -962,8 +980,8 @@ __device__ __forceinline__ void demod_blk_body(
         float am[kBlk];
         uint32_t bqn = bq, nqn = nq, wbits;
         MedEv E;
-        const uint32_t hard = blk_medium(B, Ks, Qs, P.matched_min, X.kv, slot, slot2, ys0, ys1, lane, ztile, thf8, prow, pidx, pidx2,
-                                         am, bqn, nqn, E, wbits);
+        const uint32_t hard = blk_medium<UNI>(B, Ks, Qs, P.matched_min, X.kv, slot, slot2, ys0, ys1, lane, ztile, thf8, prow, pidx, pidx2,
+                                              am, bqn, nqn, E, wbits, X.free0, inc, X.k);
         FSK_STAMP_COUNT(2)
         if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)hard < 0) != 0ull || Z.medium == 2u, 0)) {
           med_unstash(B, stash_rsrc, M.avoff, amp_quad_bytes);   // a sync candidate or a bad bit after all: from the entry state, sample by sample
@@ -1129,13 +1147,21 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel(
     uint32_t *__restrict__ eod_counts, BlkSched Z) {
   demod_blk_body<WB, UNI, SL, false>(P, S, samples, n_call, pitch, append_call, out, out_pitch, out_counts, eod_counts, Z);
 }
-// ... with the block path that takes resets (uniform configurations: its lastPhase table is the wave's)
+// ... with the block path that takes resets
 template <bool WB, bool SL>
 __global__ __launch_bounds__(256, 4) void demod_blk_kernel_r(
     DemodParams P, DemodState S, float *__restrict__ samples, size_t n_call, size_t pitch, int append_call,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
     uint32_t *__restrict__ eod_counts, BlkSched Z) {
   demod_blk_body<WB, true, SL, true>(P, S, samples, n_call, pitch, append_call, out, out_pitch, out_counts, eod_counts, Z);
+}
+// ... and for per-stream tone pairs (round 5)
+template <bool WB, bool SL>
+__global__ __launch_bounds__(256, 4) void demod_blk_kernel_rp(
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n_call, size_t pitch, int append_call,
+    uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
+    uint32_t *__restrict__ eod_counts, BlkSched Z) {
+  demod_blk_body<WB, false, SL, true>(P, S, samples, n_call, pitch, append_call, out, out_pitch, out_counts, eod_counts, Z);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -1164,6 +1190,12 @@ hipError_t set_blk_lds_limit(const DemodParams &P) {
 #define FSK_ATTR(WBV, SLV)                                                                                       \
   if (e == hipSuccess)                                                                                           \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk_kernel_r<WBV, SLV>),                      \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  FSK_ATTR(false, false) FSK_ATTR(false, true) FSK_ATTR(true, false) FSK_ATTR(true, true)
+#undef FSK_ATTR
+#define FSK_ATTR(WBV, SLV)                                                                                       \
+  if (e == hipSuccess)                                                                                           \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk_kernel_rp<WBV, SLV>),                     \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   FSK_ATTR(false, false) FSK_ATTR(false, true) FSK_ATTR(true, false) FSK_ATTR(true, true)
 #undef FSK_ATTR
@@ -1268,6 +1300,15 @@ hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, c
     return hipGetLastError();
   }
 #undef FSK_LAUNCH_BLKR
+#define FSK_LAUNCH_BLKRP(WBV, SLV)                                                                              \
+  hipLaunchKernelGGL((demod_blk_kernel_rp<WBV, SLV>), dim3(grid), dim3(256), lds, stream, P, S, samples, n, pitch, \
+                     append ? 1 : 0, out, out_pitch, out_counts, eod_counts, Z)
+  if (!uni && medium != 0u) {
+    if (sliced) { if (writeback) FSK_LAUNCH_BLKRP(true, true); else FSK_LAUNCH_BLKRP(false, true); }
+    else { if (writeback) FSK_LAUNCH_BLKRP(true, false); else FSK_LAUNCH_BLKRP(false, false); }
+    return hipGetLastError();
+  }
+#undef FSK_LAUNCH_BLKRP
   if (sliced) {
     if (writeback) { if (uni) FSK_LAUNCH_BLK(true, true, true); else FSK_LAUNCH_BLK(true, false, true); }
     else { if (uni) FSK_LAUNCH_BLK(false, true, true); else FSK_LAUNCH_BLK(false, false, true); }
