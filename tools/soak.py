@@ -79,8 +79,9 @@ def fp32_mismatch_is_marginal(cfg_s, xs, resets_seen):
         lo = max(0, k0 - 700)   # (>= samplesForEOD at every configuration of this soak)
         for t in THR_SEEN:
             for i in range(lo, k0):
-                if abs(a64[i] - t) <= 1e-5 * t and abs(a32[i] - t) <= 1e-5 * t:
-                    if True:
+                # (both within 1e-5 of the threshold AND on different sides of it -- or one exactly on it)
+                if abs(a64[i] - t) <= 1e-5 * t and abs(a32[i] - t) <= 1e-5 * t and (a64[i] - t) * (a32[i] - t) <= 0.0:
+                    if i + 1 <= k0:
                         return True, ("silence compare within 1e-5 of the threshold %.9g at decimated sample %d (%.9g fp64, %.9g fp32); the engines "
                                       "part at sample %d" % (t, i, a64[i], a32[i], k0))
     return False, "first differing bit at decimated sample %d: post filter %.3e (fp64) vs %.3e (fp32), magnitude %.3e" % (
@@ -111,6 +112,10 @@ def main(budget=None, seed=None, max_rounds=None):
         # group width -- drawn from a generator of their own, so that earlier rounds' seeds still replay the same signals
         os.environ["FSKHIP_BLK_RESETS"] = ["auto", "0", "1", "2", "1"][int(rng2.integers(5))]
         os.environ["FSKHIP_BLK_LANES"] = ["auto", "64", "16"][int(rng2.integers(3))]
+        # round 5: half of the four-wave rounds go to the six-wave small-batch kernel instead (uniform configurations; others
+        # fall back to four waves), drawn from the second generator like the choices above
+        if os.environ["FSKHIP_SPLIT"] == "4" and rng2.random() < 0.5:
+            os.environ["FSKHIP_SPLIT"] = "6"
         if target and os.environ.get("SOAK_FORCE_SPLIT"):
             os.environ["FSKHIP_SPLIT"] = os.environ["SOAK_FORCE_SPLIT"]
         os.environ["FSKHIP_SPLIT_LAST"] = os.environ["FSKHIP_SPLIT"]

@@ -293,6 +293,10 @@ __device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &
 #ifndef FSK_BLK_PRIO
 #define FSK_BLK_PRIO 1
 #endif
+// the back wave's lean block (blk_fast<true>, fsk_blk_dev.h) while every stream of its group is inside a frame
+#ifndef FSK_BLK_LEAN
+#define FSK_BLK_LEAN 0
+#endif
 // s_sleep argument (x 64 cycles) of each wave's hand-off poll
 #ifndef FSK_BLK_SLEEP_A
 #define FSK_BLK_SLEEP_A 1
@@ -881,6 +885,19 @@ __device__ __forceinline__ void demod_blk_body(
     uint32_t *prow = poly + lane * PS;
     uint32_t yb = 0, yb_t = 0;                                // y-ring slot of half tile yb_t (kept while consecutive tiles need it)
     uint32_t rare_tiles = 0;                                  // tiles of this item that blk_medium took, or would be given
+#if FSK_BLK_LEAN
+    bool matched_stale = false;                               // lean blocks have run: B.matched is to be re-formed from the polyphase registers
+    auto matched_now = [&]() {
+      uint32_t m = 0;
+      for (uint32_t i = 0; i < P.d; i += 4u) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(prow + i);
+        m += (uint32_t)__builtin_popcount((r.x ^ Ks.qn) & Ks.mask) + (uint32_t)__builtin_popcount((r.y ^ Ks.qn) & Ks.mask) +
+             (uint32_t)__builtin_popcount((r.z ^ Ks.qn) & Ks.mask) + (uint32_t)__builtin_popcount((r.w ^ Ks.qn) & Ks.mask);
+      }
+      B.matched = m;
+      matched_stale = false;
+    };
+#endif
     FSK_STAMP_BEGIN
     uint32_t t = 0;                                           // half tiles consumed (a block = a tile = two of them)
     while (t < nh) {
@@ -912,6 +929,49 @@ __device__ __forceinline__ void demod_blk_body(
                                                               // time-sliced instantiation's fast loop was one register short)
       const BackK &K = MED ? Kf : Kp;                         // (without blk_medium: pinned once, for the fast loop and the per-sample path)
       const BlkK &Q = MED ? Qs : Qp;
+#if FSK_BLK_LEAN
+      // every stream of the wave inside a frame (lanes without a stream do not count): the lean block, `matched` re-formed later
+      if (!MED && !rare_exit && __builtin_amdgcn_ballot_w64(C.valid & (B.thr_eff != kStartedP)) == 0ull) {
+        matched_stale = true;
+      for (;;) {
+          v4u32 cv;
+          lds_peek4_begin(ctr, cv);
+          const uint32_t slot_j = slot_i + 1u;                  // (kBlkSlots is even and blocks start on even slots)
+          const uint32_t pidx2 = pidx + 4u >= P.d ? 0u : pidx + 4u;
+          const v4f *slot = ring + slot_i * kBlkSlotV4, *slot2 = ring + slot_j * kBlkSlotV4;
+          const v4f pa[4] = {slot[lane], slot[64u + lane], slot2[lane], slot2[64u + lane]};
+          const uint4 rpa = *reinterpret_cast<const uint4 *>(prow + pidx), rpb = *reinterpret_cast<const uint4 *>(prow + pidx2);
+          BackLane Bn = B;
+          uint32_t rp[kBlk] = {rpa.x, rpa.y, rpa.z, rpa.w, rpb.x, rpb.y, rpb.z, rpb.w};
+          float am[kBlk];
+          uint32_t bqn = bq, nqn = nq;
+          const uint32_t rare = blk_fast<true>(Bn, K, Q, X.kv, pa, rp, am, bqn, nqn, hardw);
+          FSK_STAMP_COUNT(0)                                    // blocks
+          if (__builtin_expect((__builtin_amdgcn_ballot_w64((int32_t)rare < 0) != 0ull) & !FSK_ABL(3), 0)) { rare_exit = true; break; }
+          B = Bn; bq = bqn; nq = nqn;
+          *reinterpret_cast<uint4 *>(prow + pidx) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
+          *reinterpret_cast<uint4 *>(prow + pidx2) = make_uint4(rp[4], rp[5], rp[6], rp[7]);
+          {                                                      // syncAmplitudeBuffer.put x 8 = two quads
+            uint32_t q2 = X.amp_soff + amp_quad_bytes; q2 = q2 == amp_wrap ? 0u : q2;
+            __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, am[0]), __builtin_bit_cast(uint32_t, am[1]),
+                                                          __builtin_bit_cast(uint32_t, am[2]), __builtin_bit_cast(uint32_t, am[3])},
+                                                   amp_rsrc, M.avoff, X.amp_soff, COH);
+            __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, am[4]), __builtin_bit_cast(uint32_t, am[5]),
+                                                          __builtin_bit_cast(uint32_t, am[6]), __builtin_bit_cast(uint32_t, am[7])},
+                                                   amp_rsrc, M.avoff, q2, COH);
+            X.amp_soff = q2 + amp_quad_bytes; X.amp_soff = X.amp_soff == amp_wrap ? 0u : X.amp_soff;
+          }
+          X.k += (uint32_t)kBlk; X.kv += (uint32_t)kBlk;
+          slot_i = slot_i + 2u == kBlkSlots ? 0u : slot_i + 2u;
+          pidx = pidx2 + 4u >= P.d ? 0u : pidx2 + 4u;
+          t += 2u;
+          lds_post(&ctr[3], t);                                 // slots free (this wave's reads of them are complete)
+          produced = lds_peek4_get(cv, 2);
+          lim = lim0 < (produced & ~1u) ? lim0 : (produced & ~1u);
+          if (!(t < lim)) break;
+        }
+      } else
+#endif
       if (!rare_exit) for (;;) {
         v4u32 cv;
         lds_peek4_begin(ctr, cv);
@@ -1042,6 +1102,9 @@ __device__ __forceinline__ void demod_blk_body(
       if (rare_exit) {
         // something rare in the tile at t: sample by sample from its entry state (the round-2 path, unchanged)
         if (X.zlive != 0u) { FSK_STAMP_COUNT(1) } else { FSK_STAMP_COUNT(3) }
+#if FSK_BLK_LEAN
+        if (matched_stale) matched_now();
+#endif
         blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
         // (round 4: a half tile's inputs -- ring entries, pre-filter outputs, polyphase registers, the NCO phasors wave 0 left
         // in LDS -- are read up front and its four decimated samples run unrolled on registers: the per-sample order and
@@ -1083,6 +1146,9 @@ __device__ __forceinline__ void demod_blk_body(
       if ((t & (kFlushBlocks - 1u)) == 0u) blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
     }
     blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
+#if FSK_BLK_LEAN
+    if (matched_stale) matched_now();
+#endif
     FSK_STAMP_END(3)
     // what the host picks the next call's kernel by: a sample -- every 64th group reports (two atomics on two words from every
     // workgroup of a launch serialise at one L2 channel: +16 us on a 40-us call of 65 536 streams x 128 samples)

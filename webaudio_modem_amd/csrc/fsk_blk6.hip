@@ -148,6 +148,9 @@ __device__ __forceinline__ float front_bp(FrontLane &F, const FrontK &K, float x
 #ifndef FSK_B6_SLEEP
 #define FSK_B6_SLEEP 1
 #endif
+#ifndef FSK_B6_LEAN
+#define FSK_B6_LEAN 1
+#endif
 // Hand-off counters.  FSK_B6_POSTWAIT = 1: a wave waits for its own LDS writes (lgkmcnt(0)) before it writes the counter that
 // publishes them, as fsk_blk.hip does; 0: it does not -- the LDS executes a wave's instructions in order, so the counter's write
 // is performed after the data's, and a reader that has seen the counter reads after both.  The wait costs the producer ~100
@@ -997,7 +1000,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
         v4f fa[4], fb[4];
         fload(fa);
         // every stream of the wave inside a frame (lanes without a stream do not count): the lean block, matched re-formed later
-        if (__builtin_amdgcn_ballot_w64(C.valid & (B.thr_eff != kStartedP)) == 0ull) {
+        if (FSK_B6_LEAN && __builtin_amdgcn_ballot_w64(C.valid & (B.thr_eff != kStartedP)) == 0ull) {
           matched_stale = true;
           for (;;) {
             int r = ftile(std::true_type(), fa, fb);

@@ -83,6 +83,10 @@ __device__ inline uint32_t blk_clock(BackLane &Bn, const BackK &K, const BlkK &Q
 // The fast path of one block (a tile: eight decimated samples).  Works on copies (Bn, rp, bq, nq): the caller commits
 // them only if the returned flag word has its sign bit clear in every lane.  kv0 = pushes before the block.  hard_out:
 // the same without the 'eod' bound -- a sync candidate or a bad start / stop bit, which only the per-sample path takes.
+// LEAN (round 5): every stream of the wave is inside a frame (thr_eff = kStartedP: no sync search, fsk.ts:297), so the
+// correlator's running count cannot matter before a rare path is taken: it is not carried (seven of the vector instructions
+// per decimated sample) and the caller re-forms it from the polyphase registers when it next needs it.
+template <bool LEAN = false>
 __device__ inline uint32_t blk_fast(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t kv0, const v4f (&pa)[4],
                                     uint32_t (&rp)[kBlk], float (&am)[kBlk], uint32_t &bq, uint32_t &nq, uint32_t &hard_out) {
   const float phs[kBlk] = {pa[0].x, pa[0].z, pa[1].x, pa[1].z, pa[2].x, pa[2].z, pa[3].x, pa[3].z};
@@ -104,14 +108,16 @@ __device__ inline uint32_t blk_fast(BackLane &Bn, const BackK &K, const BlkK &Q,
     const uint32_t rold = rp[j];
     const uint32_t r = __builtin_amdgcn_alignbit(rold, nf, 31);              // syncSamplesBuffer.put(bit)
     rp[j] = r;
-    dm += (uint32_t)__builtin_popcount((r ^ K.qn) & K.mask);
-    dm -= (uint32_t)__builtin_popcount((rold ^ K.qn) & K.mask);
-    hard |= ~dm;                                                             // sign set <=> matched >= thr_eff (sync candidate)
+    if (!LEAN) {
+      dm += (uint32_t)__builtin_popcount((r ^ K.qn) & K.mask);
+      dm -= (uint32_t)__builtin_popcount((rold ^ K.qn) & K.mask);
+      hard |= ~dm;                                                           // sign set <=> matched >= thr_eff (sync candidate)
+    }
     const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, am[j] - Bn.thr));   // fsk.ts:285
     lsr = (lsr & silent) | ((uint32_t)(j + 1) & ~silent);
     w = __builtin_amdgcn_alignbit(w, nf, 31);                                // sample 1 ends up in bit kBlk - 1
   }
-  Bn.matched = dm + Bn.thr_eff;
+  if (!LEAN) Bn.matched = dm + Bn.thr_eff;
   Bn.ls = lsr + kv0;
   // 'eod' (fsk.ts:288): no silence run inside the block is longer than the one a wholly silent block would end with
   // (eod_m1 - ((kv0 + kBlk) - ls at entry))
