@@ -247,20 +247,25 @@ __global__ __launch_bounds__(64) void modulate_kernel(ModParams M, const double 
 // boundaries and tile boundaries are scalars; per lane there is only the bit's value, the end of the lane's own tones (payload
 // lengths may differ) and the phase.  A tile is 32 samples; with samplesPerBit >= 32 it holds at most one bit boundary, so the
 // phase chain of a tile is 32 x {w = (j >= jb ? w_next : w_cur), masked by "this lane still has tones"; ph[j] = phase; phase +=
-// w} -- the reference's additions in the reference's order, straight-line.  EVERY wave of the workgroup runs that chain (it is
-// the only sequential part: one f64 addition per sample) and the wave that owns a tile -- tile index mod the number of waves
-// -- alone evaluates the tile's 32 sines, which are independent, and stores it.  Values are those of modulate_kernel bit for
-// bit (same phases, same sine).
-static constexpr int kModWaves = 7;     // (7 x 8 320 B of staging tiles: under the 64 KB of static LDS)
+// w} -- the reference's additions in the reference's order, straight-line.  ONE wave of the workgroup, the chain wave, runs
+// that chain for every tile (it is the only sequential part: one f64 addition per sample, plus the bits' values) and hands
+// every tile's start phase and its two increments per lane to the six owner waves through an LDS ring; the owner of a tile
+// -- tile index mod 6 -- repeats the tile's 32 additions from that start phase (the same operations on the same operands),
+// evaluates the 32 sines, which are independent, and stores the tile.  Values are those of modulate_kernel bit for bit.
+static constexpr int kModWaves = 7;     // one chain wave + six owner waves (6 x 8 320 B of staging tiles + the hand-off ring: under 64 KB of static LDS)
+static constexpr int kModOwners = kModWaves - 1;
+static constexpr int kModRing = kModOwners;       // tiles of (start phase, w, w after the bit boundary) per lane between the chain wave and the owners
 template <bool EXACT>
 __global__ __launch_bounds__(64 * kModWaves) void modulate_wide_kernel(ModParams M, const double *__restrict__ coef,
                                                                        const uint8_t *__restrict__ payloads,
                                                                        const uint32_t *__restrict__ lens, size_t payload_pitch,
                                                                        float *__restrict__ out, size_t out_pitch, int vec_ok,
                                                                        uint32_t *__restrict__ out_lens) {
-  __shared__ float4 stage_all[kModWaves][kChunks * kSlotStride];
+  __shared__ float4 stage_all[kModOwners][kChunks * kSlotStride];
+  __shared__ double hand[kModRing][3][64];
   __shared__ uint32_t row_len[64];
   __shared__ uint32_t max_len_s;
+  __shared__ uint32_t mctr[16];                                       // [0] tiles the chain wave has published, [1 + o] tiles owner o has taken
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t stream = blockIdx.x * 64u + lane;
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(64 * kModWaves) void modulate_wide_kernel(ModParams
   const uint32_t frame_len = sig_end + M.bits_per_byte * spb;        // fsk.ts:391-394
   uint32_t my_len = frame_len;
   if ((size_t)my_len > out_pitch) my_len = (uint32_t)out_pitch;      // caller reports overflow from out_lens
+  if (threadIdx.x < 16) mctr[threadIdx.x] = 0;
   if (q == 0) {
     row_len[lane] = valid ? my_len : 0u;
     if (valid) out_lens[stream] = frame_len;
@@ -288,60 +294,106 @@ __global__ __launch_bounds__(64 * kModWaves) void modulate_wide_kernel(ModParams
   }
   __syncthreads();
   const uint32_t max_len = max_len_s;
-  float4 *stage = stage_all[q];
-  // payload bytes one byte AHEAD of their use: the load's round trip (every wave needs the bit's value before it can go on
-  // adding) is off the chain.  Bits are asked for in order, so the byte index only ever moves on by one.
-  uint32_t pay_idx = 0;                                               // payload byte index of pay_cur
-  uint32_t pay_cur = n_payload > 0u ? prow[0] : 0u, pay_nxt = n_payload > 1u ? prow[1] : 0u;
-  auto pb = [&](uint32_t i) -> uint8_t {
-    if (i != pay_idx) {                                               // (i == pay_idx + 1)
-      pay_cur = pay_nxt; pay_idx = i;
-      pay_nxt = i + 1u < n_payload ? prow[i + 1u] : 0u;
+  const uint32_t n_tiles = (max_len + (uint32_t)kTile - 1u) / (uint32_t)kTile;
+  auto peek = [&](const uint32_t *p) -> uint32_t {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  };
+  auto post = [&](uint32_t *p, uint32_t v) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" : : "v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
+  };
+  // One tile's phases from its start phase: the reference's additions in the reference's order (fsk.ts:404), straight-line; jb =
+  // first sample of the tile in the next bit (>= kTile: none), rel = position of the tile's sample 0 inside the tones.  The chain
+  // wave runs it for every tile (for the phase it hands on), an owner for its own tiles (for the 32 phases): the same operations
+  // on the same operands, so the same values.
+  auto tile_phases = [&](double phase, double w_cur, double w_next, uint32_t t0, int32_t rel, int32_t jb, double (&ph)[kTile], uint32_t &tone) -> double {
+    tone = 0u;
+#pragma unroll
+    for (int j = 0; j < kTile; j++) {
+      const bool in_tones = rel + j >= 0;                             // uniform
+      const bool act = in_tones && (t0 + (uint32_t)j) < sig_end;
+      const double wsel = j >= jb ? w_next : w_cur;                   // uniform choice between two per-lane values
+      const double wj = act ? wsel : 0.0;
+      ph[j] = phase;
+      phase = phase + wj;                                             // (adding +0.0 outside the tones leaves it as it is)
+      tone |= act ? (1u << j) : 0u;
     }
-    return (uint8_t)pay_cur;
+    return phase;
   };
-  auto w_of_bit = [&](uint32_t b) -> double {                         // phase increment of tone bit b of this lane (0 beyond its tones)
-    uint32_t bit = 0u;
-    if (b < n_bits) bit = frame_bit(M, b, pb);
-    return b < n_bits ? (bit ? wm : ws) : 0.0;
-  };
-  double phase = 0.0;
-  double w_cur = 0.0;
-  uint32_t b_have = 0xFFFFFFFFu;                                       // the bit w_cur belongs to (uniform)
-  uint32_t tile = 0;
-  for (uint32_t t0 = 0; t0 < max_len; t0 += kTile, tile++) {
-    // ---- the tile's phases: every wave
-    const int32_t rel = (int32_t)t0 - (int32_t)sig_begin;             // position of sample 0 of the tile inside the tones (uniform)
+  if (q == 0) {
+    // ---------------------------------------------------------------- the chain wave: bit values, the phase at every tile's start
+    // payload bytes one byte AHEAD of their use (bits are asked for in order: the byte index only ever moves on by one)
+    uint32_t pay_idx = 0;
+    uint32_t pay_cur = n_payload > 0u ? prow[0] : 0u, pay_nxt = n_payload > 1u ? prow[1] : 0u;
+    auto pb = [&](uint32_t i) -> uint8_t {
+      if (i != pay_idx) {                                             // (i == pay_idx + 1)
+        pay_cur = pay_nxt; pay_idx = i;
+        pay_nxt = i + 1u < n_payload ? prow[i + 1u] : 0u;
+      }
+      return (uint8_t)pay_cur;
+    };
+    auto w_of_bit = [&](uint32_t b) -> double {                       // phase increment of tone bit b of this lane (0 beyond its tones)
+      uint32_t bit = 0u;
+      if (b < n_bits) bit = frame_bit(M, b, pb);
+      return b < n_bits ? (bit ? wm : ws) : 0.0;
+    };
+    double phase = 0.0, w_cur = 0.0;
+    uint32_t b_have = 0xFFFFFFFFu;                                     // the bit w_cur belongs to (uniform)
+    for (uint32_t tile = 0; tile < n_tiles; tile++) {
+      const uint32_t t0 = tile * (uint32_t)kTile;
+      const int32_t rel = (int32_t)t0 - (int32_t)sig_begin;
+      double w_next = 0.0;
+      int32_t jb = kTile;
+      const bool tones = rel + (int32_t)kTile > 0;
+      if (tones) {
+        const uint32_t r0 = rel > 0 ? (uint32_t)rel : 0u;
+        const uint32_t b0 = r0 / spb;                                 // bit of the tile's first tone sample
+        if (b0 != b_have) { w_cur = w_of_bit(b0); b_have = b0; }
+        jb = (int32_t)((b0 + 1u) * spb) - rel;
+        if (jb < (int32_t)kTile) w_next = w_of_bit(b0 + 1u);
+      }
+      // the slot of tile - kModRing belongs to the same owner: it must have taken that one
+      if (tile >= (uint32_t)kModRing) {
+        const uint32_t o = tile % (uint32_t)kModOwners;
+        while (peek(&mctr[1u + o]) + (uint32_t)kModRing <= tile) __builtin_amdgcn_s_sleep(1);
+      }
+      double *h = &hand[tile % (uint32_t)kModRing][0][0];
+      h[lane] = phase; h[64 + lane] = w_cur; h[128 + lane] = w_next;
+      post(&mctr[0], tile + 1u);
+      if (tones) {
+        double ph[kTile];
+        uint32_t tone;
+        phase = tile_phases(phase, w_cur, w_next, t0, rel, jb, ph, tone);
+        if (jb < (int32_t)kTile) { w_cur = w_next; b_have = (uint32_t)(((rel > 0 ? (uint32_t)rel : 0u) / spb) + 1u); }
+      }
+    }
+    return;
+  }
+  // ------------------------------------------------------------------ an owner wave: every kModOwners-th tile -- its 32 sines, transposed through LDS, stored
+  const uint32_t o = q - 1u;
+  float4 *stage = stage_all[o];
+  for (uint32_t tile = o; tile < n_tiles; tile += (uint32_t)kModOwners) {
+    const uint32_t t0 = tile * (uint32_t)kTile;
+    const int32_t rel = (int32_t)t0 - (int32_t)sig_begin;
+    while (peek(&mctr[0]) <= tile) __builtin_amdgcn_s_sleep(1);
+    const double *h = &hand[tile % (uint32_t)kModRing][0][0];
+    const double phase0 = h[lane], w_cur = h[64 + lane], w_next = h[128 + lane];
+    post(&mctr[1u + o], tile + 1u);                                   // (taken: the chain wave may reuse the slot)
     double ph[kTile];
     uint32_t tone = 0u;
     if (rel + (int32_t)kTile > 0) {
       const uint32_t r0 = rel > 0 ? (uint32_t)rel : 0u;
-      const uint32_t b0 = r0 / spb;                                   // bit of the tile's first tone sample
-      if (b0 != b_have) { w_cur = w_of_bit(b0); b_have = b0; }
-      const int32_t jb = (int32_t)((b0 + 1u) * spb) - rel;           // first sample of the tile in the next bit (>= kTile: none; spb >= kTile)
-      double w_next = 0.0;
-      if (jb < (int32_t)kTile) w_next = w_of_bit(b0 + 1u);
-#pragma unroll
-      for (int j = 0; j < kTile; j++) {
-        const bool in_tones = rel + j >= 0;                           // uniform
-        const bool act = in_tones && (t0 + (uint32_t)j) < sig_end;
-        const double wsel = j >= jb ? w_next : w_cur;                 // uniform choice between two per-lane values
-        const double wj = act ? wsel : 0.0;
-        ph[j] = phase;
-        phase = phase + wj;                                           // fsk.ts:404 (adding +0.0 outside the tones leaves it as it is)
-        tone |= act ? (1u << j) : 0u;
-      }
-      if (jb < (int32_t)kTile) { w_cur = w_next; b_have = b0 + 1u; }
+      const int32_t jb = (int32_t)((r0 / spb + 1u) * spb) - rel;
+      (void)tile_phases(phase0, w_cur, w_next, t0, rel, jb, ph, tone);
     }
-    if ((tile % (uint32_t)kModWaves) != q) continue;
-    // ---- this wave's tile: the sines (independent: scheduled as straight-line blocks of eight), transposed through LDS, stored
     if (__builtin_amdgcn_ballot_w64(tone != 0u) == 0ull) {          // padding: zeros (fsk.ts:391-396)
 #pragma unroll
       for (int c = 0; c < kChunks; c++) stage[c * kSlotStride + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
 #pragma unroll
       for (int c = 0; c < kChunks; c += 2) {
-        float o[8];
+        float ov[8];
         double sv[8], p8[8];
         bool tn[8];
 #pragma unroll
@@ -367,9 +419,9 @@ __global__ __launch_bounds__(64 * kModWaves) void modulate_wide_kernel(ModParams
           for (int j = 0; j < 8; j++) sv[j] = sin(p8[j]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = tn[j] ? (float)sv[j] : 0.0f;
-        stage[c * kSlotStride + lane] = make_float4(o[0], o[1], o[2], o[3]);
-        stage[(c + 1) * kSlotStride + lane] = make_float4(o[4], o[5], o[6], o[7]);
+        for (int j = 0; j < 8; j++) ov[j] = tn[j] ? (float)sv[j] : 0.0f;
+        stage[c * kSlotStride + lane] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        stage[(c + 1) * kSlotStride + lane] = make_float4(ov[4], ov[5], ov[6], ov[7]);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // (one wave: its own writes, in order)
