@@ -210,6 +210,9 @@ int fskhip_demod_supported(const fskhip_engine *e);
  */
 int fskhip_trace_enable(fskhip_engine *e, int64_t stream, size_t capacity);
 int fskhip_trace_read(fskhip_engine *e, double *amp, double *post, uint8_t *bit, size_t cap, size_t *n);
+/* ... and the pre-filter's output (fsk.ts:202: the Float32Array the band-pass returns), one value per INPUT sample of the traced
+ * stream, up to 2 x `capacity` of them (n = count), in the reference's scale. */
+int fskhip_trace_read_pre(fskhip_engine *e, double *pre, size_t cap, size_t *n);
 
 /* Measurement tooling: streams d_buf with the demodulator's fast-path read pattern and nothing else, so
  * a FETCH_SIZE counter pass over it can be calibrated against the known n_streams*n*4 bytes. */

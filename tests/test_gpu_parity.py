@@ -113,7 +113,7 @@ def test_intermediates_match_reference(name, pname, prec, tol):
     ref_post = g.array(c["trace"]["post_out"])
     ref_bit = g.array(c["trace"]["bit"])
     eng = _engine(c["config"], prec)
-    eng.trace_enable(0, ref_amp.size + 8)
+    eng.trace_enable(0, ref_amp.size + 8)      # (capacity in decimated samples; the pre-filter trace holds twice as many)
     eng.demodulate_data(x.reshape(1, -1))
     tr = eng.trace_read()
     assert tr["amp"].size == ref_amp.size
@@ -122,6 +122,14 @@ def test_intermediates_match_reference(name, pname, prec, tol):
     assert rel.max() <= tol, rel.max()
     assert np.abs(tr["post_out"] - ref_post).max() <= (1e-9 if prec == 1 else 2e-5)
     assert np.array_equal(tr["bit"], ref_bit)
+    # the pre-filter's Float32Array (fsk.ts:202), one value per input sample: the fp64 path stores the very
+    # float the reference stores; the fp32 path within 1e-5 of the stream's peak
+    ref_pre = g.array(c["trace"]["pre_out"]).astype(np.float64)
+    assert tr["pre_out"].size == ref_pre.size == x.size
+    if prec == 1:
+        assert np.array_equal(tr["pre_out"].astype(np.float32).view(np.uint32), ref_pre.astype(np.float32).view(np.uint32))
+    else:
+        assert np.abs(tr["pre_out"] - ref_pre).max() <= 1e-5 * np.abs(ref_pre).max()
     eng.close()
 
 

@@ -83,6 +83,7 @@ _SYMBOLS = [
     ("fskhip_add_awgn_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, C.c_uint64, _P]),
     ("fskhip_demod_supported", C.c_int, [_P]),
     ("fskhip_trace_enable", C.c_int, [_P, C.c_int64, C.c_size_t]),
+    ("fskhip_trace_read_pre", C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("fskhip_trace_read", C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("fskhip_probe_read_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P]),
     ("fskhip_butterworth_lowpass", None, [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -1336,13 +1336,33 @@ int fskhip_trace_enable(fskhip_engine *e, int64_t stream, size_t capacity) {
   if (stream >= (int64_t)e->n_streams) return fail(FSKHIP_E_INVALID, "stream out of range");
   const size_t cap = capacity ? capacity : 1;
   HIP_TRY(hipMalloc((void **)&e->S.trace_amp, sizeof(double) * cap));
-  HIP_TRY(hipMalloc((void **)&e->S.trace_post, sizeof(double) * cap));
+  HIP_TRY(hipMalloc((void **)&e->S.trace_post, sizeof(double) * cap * 3));      // [0, cap) post filter, [cap, 3 cap) pre-filter output per input sample
   HIP_TRY(hipMalloc((void **)&e->S.trace_bit, cap));
-  HIP_TRY(hipMalloc((void **)&e->S.trace_n, sizeof(uint32_t)));
-  HIP_TRY(hipMemset(e->S.trace_n, 0, sizeof(uint32_t)));
+  HIP_TRY(hipMalloc((void **)&e->S.trace_n, 2 * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(e->S.trace_n, 0, 2 * sizeof(uint32_t)));
   e->S.trace_stream = (uint32_t)stream;
   e->S.trace_cap = (uint32_t)cap;
   e->trace_cap = (uint32_t)cap;
+  return FSKHIP_OK;
+}
+
+int fskhip_trace_read_pre(fskhip_engine *e, double *pre, size_t cap, size_t *n) {
+  if (!e || !n) return fail(FSKHIP_E_INVALID, "null argument");
+  if (!e->S.trace_n) return fail(FSKHIP_E_INVALID, "trace not enabled");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  uint32_t cnt[2] = {0, 0};
+  HIP_TRY(hipMemcpy(cnt, e->S.trace_n, sizeof(cnt), hipMemcpyDeviceToHost));
+  size_t m = cnt[1] < 2u * e->trace_cap ? cnt[1] : 2u * e->trace_cap;
+  m = m < cap ? m : cap;
+  if (pre && m) HIP_TRY(hipMemcpy(pre, e->S.trace_post + e->trace_cap, sizeof(double) * m, hipMemcpyDeviceToHost));
+  // fp32 lock-step engines carry the pre-filter's output times the low-pass gain b0 / 2 and 2^60 (fsk_pipe_dev.h): back to the
+  // reference's scale here.  (fp64 engines and the generic fp32 kernel record the reference's own value.)
+  if (pre && m && e->precision == FSKHIP_PRECISION_F32 && e->ds_uniform && !e->force_generic && !e->P.wide && !e->P.frac) {
+    const double g = 0.5 * e->P.lp_b0 * 1152921504606846976.0;
+    for (size_t i = 0; i < m; i++) pre[i] /= g;
+  }
+  *n = cnt[1];
   return FSKHIP_OK;
 }
 

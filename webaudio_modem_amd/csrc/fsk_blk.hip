@@ -79,18 +79,6 @@ namespace fsk {
 //   * the bit clock once per block (blk_clock), for lanes without a reset in it.
 // Everything else -- a sync candidate, a bad start / stop bit, a second reset or a reset plus a bit decision of one lane in
 // one block -- sets the returned word's sign bit: the caller puts the entry state back and redoes the block sample by sample.
-struct MedEv {
-  uint32_t jr;                   // 1..8: resetState() ran at the end of this sample of the block; 0 = no reset
-  uint32_t jc;                   // 1..8: the correction's start values were formed at this sample; 0 = not in this block
-  float cai, caq, cbi, cbq;      // those values (zq_a, zq_b right after their formation)
-};
-__device__ inline uint32_t bsel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
-__device__ inline float bself(uint32_t m, float a, float b) {
-  return __builtin_bit_cast(float, bsel(m, __builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b)));
-}
-__device__ inline float bzero(uint32_t keep, float a) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, a) & keep); }
-__device__ inline uint32_t eq_mask(uint32_t v, uint32_t c) { return neg_mask((v ^ c) - 1u); }   // all ones <=> v == c (small values)
-
 // The entry state of a block that blk_medium is about to work on IN PLACE (a copy in registers would not fit beside it:
 // the kernel's 128-VGPR budget), as seven 16-byte stores per lane to a buffer of the engine's: fire and forget -- read back
 // (med_unstash) only if the block turns out to need the per-sample path.  Everything blk_medium writes.
@@ -182,106 +170,10 @@ __device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &
       r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
       thf_j = (float)r;
     }
-    // ---- zir_step<UNI, HAND = true>, flat
-    const uint32_t dph0 = Bn.dph;
-    float wi = e0 - Bn.qai, wq = e1 - Bn.qaq;
-    {
-      const float ni = __builtin_fmaf(K.c1, Bn.qbi, -(K.c2 * Bn.qai));
-      const float nq2 = __builtin_fmaf(K.c1, Bn.qbq, -(K.c2 * Bn.qaq));
-      Bn.qai = Bn.qbi; Bn.qaq = Bn.qbq; Bn.qbi = ni; Bn.qbq = nq2;
-    }
-    float di, dq;
-    {
-      const float mi = y0 * z.x, mq = y0 * z.y;
-      const float ti = __builtin_fmaf(2.0f, Bn.dix1, mi) + Bn.dix2, tq = __builtin_fmaf(2.0f, Bn.dqx1, mq) + Bn.dqx2;
-      Bn.dvi = __builtin_fmaf(K.lp_a2, Bn.dvi, __builtin_fmaf(K.lp_nd, Bn.diy, ti));
-      Bn.dqv = __builtin_fmaf(K.lp_a2, Bn.dqv, __builtin_fmaf(K.lp_nd, Bn.dqy, tq));
-      Bn.diy += Bn.dvi; Bn.dqy += Bn.dqv;
-      Bn.dix2 = Bn.dix1; Bn.dix1 = mi; Bn.dqx2 = Bn.dqx1; Bn.dqx1 = mq;
-      di = Bn.diy; dq = Bn.dqy;
-    }
-    {
-      const float mi = y1 * z.z, mq = y1 * z.w;
-      const float ti = __builtin_fmaf(2.0f, Bn.dix1, mi) + Bn.dix2, tq = __builtin_fmaf(2.0f, Bn.dqx1, mq) + Bn.dqx2;
-      Bn.dvi = __builtin_fmaf(K.lp_a2, Bn.dvi, __builtin_fmaf(K.lp_nd, Bn.diy, ti));
-      Bn.dqv = __builtin_fmaf(K.lp_a2, Bn.dqv, __builtin_fmaf(K.lp_nd, Bn.dqy, tq));
-      Bn.diy += Bn.dvi; Bn.dqy += Bn.dqv;
-      Bn.dix2 = Bn.dix1; Bn.dix1 = mi; Bn.dqx2 = Bn.dqx1; Bn.dqx1 = mq;
-      di += Bn.diy; dq += Bn.dqy;
-    }
-    // (lanes past the direct instance run it on as well: its state is not theirs any more -- pipe_store writes zeros for it
-    // once zr_dph has reached kDirectPairs, whichever path the samples took)
-    const uint32_t m_dir = neg_mask(dph0 - kDirectPairs);                    // zr_dph < kDirectPairs: the direct instance's output
-    wi = bself(m_dir, di, wi); wq = bself(m_dir, dq, wq);
-    {
-      const float qi = e0 - di, qq = e1 - dq;                                // U - d: the free-running filters' zero-input response
-      const uint32_t m24 = eq_mask(dph0, kZeroLagPairs), m25 = eq_mask(dph0, kZeroLagPairs + 1u);
-      const float nai = __builtin_fmaf(K.c1, qi, -(K.c2 * Bn.q0i)), naq = __builtin_fmaf(K.c1, qq, -(K.c2 * Bn.q0q));
-      const float nbi = __builtin_fmaf(K.c1, nai, -(K.c2 * qi)), nbq = __builtin_fmaf(K.c1, naq, -(K.c2 * qq));
-      Bn.q0i = bself(m24, qi, Bn.q0i); Bn.q0q = bself(m24, qq, Bn.q0q);
-      Bn.qai = bself(m25, nai, Bn.qai); Bn.qaq = bself(m25, naq, Bn.qaq);
-      Bn.qbi = bself(m25, nbi, Bn.qbi); Bn.qbq = bself(m25, nbq, Bn.qbq);
-      E.cai = bself(m25, nai, E.cai); E.caq = bself(m25, naq, E.caq);
-      E.cbi = bself(m25, nbi, E.cbi); E.cbq = bself(m25, nbq, E.cbq);
-      E.jc = bsel(m25, (uint32_t)(j + 1), E.jc);
-      // (materialised here: left to itself the compiler spills the eight samples' candidates and forms these in the rare
-      // branch that posts them, behind sixteen scratch round trips)
-      asm volatile("" : "+v"(E.cai), "+v"(E.caq), "+v"(E.cbi), "+v"(E.cbq), "+v"(E.jc));
-    }
-    const uint32_t m_own = neg_mask(dph0 - kHandPairs);                      // the span is this wave's
-    Bn.dph = dph0 - m_own;                                                   // + 1, saturating at kHandPairs
-    {
-      const uint32_t keep = ~eq_mask(dph0, kHandPairs - 1u);                 // handed over: the discriminator wave's from here on
-      Bn.qai = bzero(keep, Bn.qai); Bn.qaq = bzero(keep, Bn.qaq); Bn.qbi = bzero(keep, Bn.qbi); Bn.qbq = bzero(keep, Bn.qbq);
-    }
-    float a2;
-    const float p2 = atan2_amp_fma(wq, wi, a2, K.tiny, K.sgn);
-    const float ph = bself(m_own, p2, e0);
-    am[j] = bself(m_own, a2, e1);
-    // ---- discriminator tail, slicer, correlator, silence run (as blk_fast)
-    const float f = disc_post(Bn, K, ph, am[j]);
-    const uint32_t nf = __builtin_bit_cast(uint32_t, 0.0f - f);
-    const uint32_t rold = h ? rp2.y : rp2.x;
-    const uint32_t r = __builtin_amdgcn_alignbit(rold, nf, 31);
-    matched += (uint32_t)__builtin_popcount((r ^ K.qn) & K.mask);
-    matched -= (uint32_t)__builtin_popcount((rold ^ K.qn) & K.mask);
-    hard |= ~(matched - thr_cur);                                            // sync candidate
-    const uint32_t silent = neg_mask(__builtin_bit_cast(uint32_t, am[j] - Bn.thr));
-    ls = (ls & silent) | (kvj & ~silent);
-    w = __builtin_amdgcn_alignbit(w, nf, 31);
-    // ---- 'eod' (fsk.ts:288) -> resetState() at the end of this sample (back_reset, masked)
-    const uint32_t me = neg_mask(K.eod_m1 - (kvj - ls));
-    hard |= me & (0u - E.jr);                                                // a second reset in the block
-    E.jr = bsel(me, (uint32_t)(j + 1), E.jr);
-    asm volatile("" : "+v"(E.jr), "+v"(hard));
-    Bn.last_phase = bself(me, thf_j, Bn.last_phase);
-    Bn.thf = bself(me, thf_j, Bn.thf);
-    const uint32_t keep = ~me;
-    Bn.dph &= keep;
-    Bn.dix1 = bzero(keep, Bn.dix1); Bn.dix2 = bzero(keep, Bn.dix2); Bn.diy = bzero(keep, Bn.diy); Bn.dvi = bzero(keep, Bn.dvi);
-    Bn.dqx1 = bzero(keep, Bn.dqx1); Bn.dqx2 = bzero(keep, Bn.dqx2); Bn.dqy = bzero(keep, Bn.dqy); Bn.dqv = bzero(keep, Bn.dqv);
-    Bn.px1 = bzero(keep, Bn.px1); Bn.px2 = bzero(keep, Bn.px2); Bn.py = bzero(keep, Bn.py); Bn.pv = bzero(keep, Bn.pv);
-    ls = bsel(me, kvj, ls);
-    thr_cur = bsel(me, matched_min, thr_cur);
+    med_sample(Bn, K, j, e0, e1, y0, y1, z, thf_j, h ? rp2.y : rp2.x, kvj, matched_min, matched, thr_cur, ls, w, hard, E, am[j]);
     }
   }
-  Bn.matched = matched;
-  Bn.ls = ls;
-  // ---- bit clock, once per block, from the entry state; a lane that was reset in this block may not also decide a bit
-  uint32_t md;
-  hard |= blk_clock(Bn, K, Q, kv0, w, bq, nq, md);
-  const uint32_t mjr = neg_mask(0u - E.jr);
-  hard |= md & mjr;
-  {
-    // what resetState() leaves of the bit clock: the vote holds the bits sliced after the reset, no decision pending
-    const uint32_t after = w & ((1u << (((uint32_t)kBlk - E.jr) & 31u)) - 1u);
-    const uint32_t park = kv0 + E.jr + kBigWait;
-    Bn.acc = bsel(mjr, (uint32_t)__builtin_popcount(after), Bn.acc);
-    Bn.T = bsel(mjr, park, Bn.T);
-    Bn.tlast = bsel(mjr, park, Bn.tlast);
-    Bn.sreg = bsel(mjr, 1u, Bn.sreg);
-  }
-  Bn.thr_eff = thr_cur;
+  hard |= med_finish(Bn, K, Q, kv0, matched, thr_cur, ls, w, bq, nq, E);
   w_out = w;
   return hard;
 }

@@ -76,7 +76,7 @@ __host__ __device__ inline uint32_t blk6_zt_tiles(uint32_t y_slots) {
 // of their masked match counts, by construction of the incremental update).
 template <bool LEAN>
 __device__ inline uint32_t blk6_fast(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t kv0, const v4f (&fa)[4],
-                                     uint32_t (&rp)[kBlk], float (&am)[kBlk], uint32_t &bq, uint32_t &nq) {
+                                     uint32_t (&rp)[kBlk], float (&am)[kBlk], uint32_t &bq, uint32_t &nq, uint32_t &hard_out) {
   // (floats first: __builtin_bit_cast applied to a vector ELEMENT expression read element 0 for every component -- hipcc 7.2)
   const float nff[kBlk] = {fa[0].x, fa[0].y, fa[0].z, fa[0].w, fa[1].x, fa[1].y, fa[1].z, fa[1].w};
   uint32_t nfv[kBlk];
@@ -108,7 +108,38 @@ __device__ inline uint32_t blk6_fast(BackLane &Bn, const BackK &K, const BlkK &Q
   const uint32_t soft = K.eod_m1 - (uint32_t)kBlk + lsr0;                    // 'eod' bound, as blk_fast
   uint32_t md;
   hard |= blk_clock(Bn, K, Q, kv0, w, bq, nq, md);
+  hard_out = hard;                                                           // a sync candidate or a bad start / stop bit: only the per-sample path takes those
   return hard | soft;
+}
+
+// The block path that takes resets (blk_medium, fsk_blk.hip), for the frame wave's own-span tiles: the same per-sample
+// function (med_sample, fsk_blk_dev.h) on this kernel's ring layouts, the tile's inputs read up front (the wave has 256
+// registers here) and the entry state kept as a register copy by the caller instead of a stash in memory.  xa = the x ring
+// tile (I or phase 0..3, 4..7; Q or magnitude 0..3, 4..7), ya = its four y ring entries, zc / zs = the tile's cos / sin rows,
+// ro = the eight polyphase registers.
+__device__ inline uint32_t blk6_medium(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t matched_min, uint32_t kv0, const v4f (&xa)[4],
+                                       const v4f (&ya)[4], const v4f (&zc)[4], const v4f (&zs)[4], const uint32_t (&ro)[kBlk],
+                                       const float (&thf8)[kBlk], float (&am)[kBlk], uint32_t &bq, uint32_t &nq, MedEv &E, uint32_t &w_out) {
+  uint32_t w = 0, hard = 0;
+  uint32_t matched = Bn.matched, thr_cur = Bn.thr_eff, ls = Bn.ls;
+  E.jr = 0; E.jc = 0; E.cai = E.caq = E.cbi = E.cbq = 0.f;
+  const float e0v[kBlk] = {xa[0].x, xa[0].y, xa[0].z, xa[0].w, xa[1].x, xa[1].y, xa[1].z, xa[1].w};
+  const float e1v[kBlk] = {xa[2].x, xa[2].y, xa[2].z, xa[2].w, xa[3].x, xa[3].y, xa[3].z, xa[3].w};
+  const float yv[2 * kBlk] = {ya[0].x, ya[0].y, ya[0].z, ya[0].w, ya[1].x, ya[1].y, ya[1].z, ya[1].w,
+                              ya[2].x, ya[2].y, ya[2].z, ya[2].w, ya[3].x, ya[3].y, ya[3].z, ya[3].w};
+  const float cv[2 * kBlk] = {zc[0].x, zc[0].y, zc[0].z, zc[0].w, zc[1].x, zc[1].y, zc[1].z, zc[1].w,
+                              zc[2].x, zc[2].y, zc[2].z, zc[2].w, zc[3].x, zc[3].y, zc[3].z, zc[3].w};
+  const float sv[2 * kBlk] = {zs[0].x, zs[0].y, zs[0].z, zs[0].w, zs[1].x, zs[1].y, zs[1].z, zs[1].w,
+                              zs[2].x, zs[2].y, zs[2].z, zs[2].w, zs[3].x, zs[3].y, zs[3].z, zs[3].w};
+#pragma unroll
+  for (int j = 0; j < kBlk; j++) {
+    const v4f z = (v4f){cv[2 * j], sv[2 * j], cv[2 * j + 1], sv[2 * j + 1]};
+    med_sample(Bn, K, j, e0v[j], e1v[j], yv[2 * j], yv[2 * j + 1], z, thf8[j], ro[j], kv0 + (uint32_t)(j + 1), matched_min, matched, thr_cur, ls,
+               w, hard, E, am[j]);
+  }
+  hard |= med_finish(Bn, K, Q, kv0, matched, thr_cur, ls, w, bq, nq, E);
+  w_out = w;
+  return hard;
 }
 
 // one branch of the free-running I/Q low-pass (front_mix_lp's instruction sequence for one of its two chains)
@@ -150,6 +181,10 @@ __device__ __forceinline__ float front_bp(FrontLane &F, const FrontK &K, float x
 #endif
 #ifndef FSK_B6_LEAN
 #define FSK_B6_LEAN 1
+#endif
+// the frame wave's own-span tiles on the block path that takes resets (blk6_medium) instead of sample by sample
+#ifndef FSK_B6_MEDIUM
+#define FSK_B6_MEDIUM 1
 #endif
 // Hand-off counters.  FSK_B6_POSTWAIT = 1: a wave waits for its own LDS writes (lgkmcnt(0)) before it writes the counter that
 // publishes them, as fsk_blk.hip does; 0: it does not -- the LDS executes a wave's instructions in order, so the counter's write
@@ -912,6 +947,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
     uint32_t t = 0;                                           // half tiles consumed (a block = a tile = two of them)
     while (t < nh) {
       bool rare_exit = X.zlive != 0u || amp_misaligned;
+      uint32_t hardw = 0;                                     // the block test's hard flags of the tile that left the block loop
       if (!rare_exit) {
         if (own_post) {
           // back on the block path: P4 resumes at this tile with the state the per-sample run ended with
@@ -952,7 +988,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
           uint32_t rp[kBlk] = {rpa.x, rpa.y, rpa.z, rpa.w, rpb.x, rpb.y, rpb.z, rpb.w};
           float am[kBlk];
           uint32_t bqn = bq, nqn = nq;
-          const uint32_t rare = blk6_fast<decltype(lean)::value>(Bn, K, Q, X.kv, cur, rp, am, bqn, nqn);
+          const uint32_t rare = blk6_fast<decltype(lean)::value>(Bn, K, Q, X.kv, cur, rp, am, bqn, nqn, hardw);
           FSK_STAMP_COUNT(0)
           if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)rare < 0) != 0ull, 0)) return 2;
           B = Bn; bq = bqn; nq = nqn;
@@ -1041,6 +1077,87 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
         }
         if (X.zlive != 0u) { rare_tiles++; FSK_STAMP_COUNT(1) } else { FSK_STAMP_COUNT(3) }
         if (matched_stale) matched_now();
+        // ---- an 'eod' in the tile, or a lane inside the own span after one -- and no sync candidate or bad start / stop bit the
+        // block test has seen: the block path that takes resets (blk_medium's sequence, straight-line: a rare tile sample by
+        // sample is ~2 200 instructions and 240 branches, 13 fast tiles' time, and nothing upstream can run ahead meanwhile)
+        bool medium_done = false;
+        if (FSK_B6_MEDIUM && !amp_misaligned && __builtin_amdgcn_ballot_w64((int32_t)hardw < 0) == 0ull) {
+          const v4f *xt = xring + slot_t * kB6TileV4;
+          const v4f *ztile = zt + ((t >> 1) & ZTM) * 8u;
+          const v4f *ys0 = yring + (t % NY) * 2u * 64u, *ys1 = yring + ((t + 1u) % NY) * 2u * 64u;
+          const uint32_t pidx2 = pidx + 4u >= P.d ? 0u : pidx + 4u;
+          const v4f xa[4] = {xt[lane], xt[64u + lane], xt[128u + lane], xt[192u + lane]};
+          const v4f ya[4] = {ys0[lane], ys0[64u + lane], ys1[lane], ys1[64u + lane]};
+          const v4f zc[4] = {ztile[0], ztile[1], ztile[2], ztile[3]}, zs[4] = {ztile[4], ztile[5], ztile[6], ztile[7]};
+          const uint4 oa = *reinterpret_cast<const uint4 *>(prow + pidx), ob = *reinterpret_cast<const uint4 *>(prow + pidx2);
+          const uint32_t ro[kBlk] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
+          // lastPhase after a resetState() at the end of sample j of this tile: the free-running frame's phase there
+          // (back_reset's expression; lane j evaluates it, the wave reads it back as a scalar)
+          float thf8[kBlk];
+          {
+            const uint64_t fr0 = X.free0 + inc * (uint64_t)(2u * (X.k + (lane & 7u) + 1u));
+            double r = (double)fr0 * 5.42101086242752217e-20 * 6.283185307179586476925;
+            r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
+            const float thfv = (float)r;
+#pragma unroll
+            for (int j = 0; j < kBlk; j++) thf8[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thfv), j));
+          }
+          BackLane Bn = B;
+          float am[kBlk];
+          uint32_t bqn = bq, nqn = nq, wbits;
+          MedEv E;
+          const uint32_t hard = blk6_medium(Bn, K, Q, P.matched_min, X.kv, xa, ya, zc, zs, ro, thf8, am, bqn, nqn, E, wbits);
+          FSK_STAMP_COUNT(2)
+          if (__builtin_amdgcn_ballot_w64((int32_t)hard < 0) == 0ull) {
+            B = Bn; bq = bqn; nq = nqn;
+            // syncSamplesBuffer.put x 8: old register << 1 | the sample's slicer bit (sample 1 is bit 7 of wbits)
+            *reinterpret_cast<uint4 *>(prow + pidx) = make_uint4((oa.x << 1) | ((wbits >> 7) & 1u), (oa.y << 1) | ((wbits >> 6) & 1u),
+                                                                 (oa.z << 1) | ((wbits >> 5) & 1u), (oa.w << 1) | ((wbits >> 4) & 1u));
+            *reinterpret_cast<uint4 *>(prow + pidx2) = make_uint4((ob.x << 1) | ((wbits >> 3) & 1u), (ob.y << 1) | ((wbits >> 2) & 1u),
+                                                                  (ob.z << 1) | ((wbits >> 1) & 1u), (ob.w << 1) | (wbits & 1u));
+            {
+              uint32_t q2 = X.amp_soff + amp_quad_bytes; q2 = q2 == amp_wrap ? 0u : q2;
+              __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, am[0]), __builtin_bit_cast(uint32_t, am[1]),
+                                                            __builtin_bit_cast(uint32_t, am[2]), __builtin_bit_cast(uint32_t, am[3])},
+                                                     amp_rsrc, M.avoff, X.amp_soff, COH);
+              __builtin_amdgcn_raw_buffer_store_b128((v4u){__builtin_bit_cast(uint32_t, am[4]), __builtin_bit_cast(uint32_t, am[5]),
+                                                            __builtin_bit_cast(uint32_t, am[6]), __builtin_bit_cast(uint32_t, am[7])},
+                                                     amp_rsrc, M.avoff, q2, COH);
+              X.amp_soff = q2 + amp_quad_bytes; X.amp_soff = X.amp_soff == amp_wrap ? 0u : X.amp_soff;
+            }
+            const uint32_t k0 = X.k;
+            X.k += (uint32_t)kBlk; X.kv += (uint32_t)kBlk;
+            pidx = pidx2 + 4u >= P.d ? 0u : pidx2 + 4u;
+            t += 2u;
+            // what the tile's resets owe memory and the other waves' mailboxes, once, before the tile's slots are released
+            if (__builtin_amdgcn_ballot_w64((E.jr | E.jc) != 0u)) {
+              if (E.jc != 0u) {                                // (zir_step: the correction's start values, for the discriminator wave)
+                cmail[64u + lane] = __builtin_bit_cast(uint32_t, E.cai); cmail[128u + lane] = __builtin_bit_cast(uint32_t, E.caq);
+                cmail[192u + lane] = __builtin_bit_cast(uint32_t, E.cbi); cmail[256u + lane] = __builtin_bit_cast(uint32_t, E.cbq);
+                cmail[lane] = k0 + E.jc + kHandLag;
+              }
+              if (E.jr != 0u) {                                // (back_pair's 'eod' + back_reset)
+                const uint32_t kr = k0 + E.jr;
+                ist_add<COH>(M, IF_eod_total, 1u);
+                if (eod_counts && M.voff < 0xFFFFFFF0u) __hip_atomic_fetch_add(&eod_counts[M.voff >> 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t off = 0ull - (X.free0 + inc * (uint64_t)(2u * kr));
+                ist_store<COH>(M, IF_fr_lo, (uint32_t)off);
+                ist_store<COH>(M, IF_fr_hi, (uint32_t)(off >> 32));
+                ist_store<COH>(M, IF_gsc, 0u - kr);
+                zmail[lane] = kr + kZeroLagPairs;
+                cmail[lane] = 0xFFFFFFFFu;
+                cmail[320u + lane] = kr;
+                B.rho = kr % P.cadence;
+              }
+            }
+            X.zlive = __builtin_amdgcn_ballot_w64(B.dph < kHandPairs) != 0ull ? 1u : 0u;
+            X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) != 0ull ? kDirectPairs : 0u;
+            slot_t = slot_t + 1u == kB6XT ? 0u : slot_t + 1u;
+            b6_post(&ctr[C6_CONS], t);
+            medium_done = true;
+          }
+        }
+        if (!medium_done) {
         blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
         const v4f *ztile = zt + ((t >> 1) & ZTM) * 8u;
         const float *ztf = reinterpret_cast<const float *>(ztile);
@@ -1074,6 +1191,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
         (void)ztf;
         slot_t = slot_t + 1u == kB6XT ? 0u : slot_t + 1u;
         b6_post(&ctr[C6_CONS], t);
+        }
       }
       if ((t & (kFlushBlocks - 1u)) == 0u) blk_flush(B, bq, nq, M, out, (uint32_t)out_pitch);
     }

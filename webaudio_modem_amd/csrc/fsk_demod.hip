@@ -802,6 +802,7 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
   // generic path: one sample at a time, per-lane decimator phase (fsk.ts:224-276 as written)
   auto step_generic = [&](float x, float &wbv) {
     float pre_y = pre_stage(L, C, agc_on, x, wbv);
+    if (TRACE) { if (stream == S.trace_stream) trace_pre_put(S, (double)pre_y); }
     Real fi, fq;
     mix_lp(L, C, pre_y, fi, fq);
     L.acc_i += fi;
@@ -863,6 +864,12 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
       pre_y[k] = pre_stage(L, C, agc_on, x[k], wbv[k]);
       mix_lp<true>(L, C, pre_y[k], fi[k], fq[k]);
     }
+    if (TRACE) {
+      if (stream == S.trace_stream) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) trace_pre_put(S, (double)pre_y[k]);
+      }
+    }
     Real amp0, post0, amp1, post1;
     const bool bit0 = discriminate(L, C, fi[0] + fi[1], fq[0] + fq[1], amp0, post0);
     bool bit1 = discriminate(L, C, fi[2] + fi[3], fq[2] + fq[3], amp1, post1);
@@ -904,6 +911,7 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
   auto block16 = [&](const float (&x)[16], float (&wbv)[16]) -> bool {
     const Lane<Real> L0 = L;                                   // everything this block may touch (poly / amplitude ring / output: written at the end)
     Real amp[8], post[8];
+    float pre16[16];                                            // (traced engines: recorded once the block stands)
     uint32_t w = 0;                                             // slicer bits, sample 1 in bit 7
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -912,10 +920,17 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
       mix_lp<true>(L, C, y0, fi0, fq0);
       const float y1 = pre_stage(L, C, agc_on, x[2 * j + 1], wbv[2 * j + 1]);
       mix_lp<true>(L, C, y1, fi1, fq1);
+      pre16[2 * j] = y0; pre16[2 * j + 1] = y1;
       const bool bit = discriminate(L, C, fi0 + fi1, fq0 + fq1, amp[j], post[j]);
       w = (w << 1) | (bit ? 1u : 0u);
     }
     if (!block_fsm8<Real, PolyT, TRACE>(L, P, S, poly, R, O, lane, row, stream, valid, amp, post, w)) { L = L0; return false; }
+    if (TRACE) {
+      if (stream == S.trace_stream) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) trace_pre_put(S, (double)pre16[k]);
+      }
+    }
     return true;
   };
 

@@ -118,6 +118,15 @@ __device__ inline void ist_add(const FastMem &M, uint32_t field, uint32_t v) {
 }
 
 
+// Intermediate capture of the pre-filter's output (fsk.ts:202: the Float32Array the band-pass returns), one value per INPUT
+// sample of the traced stream, behind the post-filter trace in the same buffer: trace_post[cap .. 3 cap), counted by
+// trace_n[1] (the kernels' argument block stays as it is).  Called by the traced stream's lane only.
+__device__ inline void trace_pre_put(const DemodState &S, double v) {
+  const uint32_t kk = S.trace_n[1];
+  if (kk < 2u * S.trace_cap) S.trace_post[S.trace_cap + kk] = v;
+  S.trace_n[1] = kk + 1u;
+}
+
 // ---- opt-in signal-quality estimates (definition: include/fskhip.h) -- rare paths only, state read-modify-written -----
 template <typename Real>
 __device__ inline Real &q_real(const DemodState &S, uint32_t n, int field, uint32_t row) { return ((Real *)S.rs)[(size_t)field * n + row]; }

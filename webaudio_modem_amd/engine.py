@@ -262,7 +262,10 @@ class FSKEngine:
         n = C.c_size_t(0)
         _lib.check(self._L.fskhip_trace_read(self._h, amp.ctypes.data, post.ctypes.data, bit.ctypes.data, cap,
                                              C.byref(n)))
-        return {"amp": amp[:n.value], "post_out": post[:n.value], "bit": bit[:n.value]}
+        pre = np.zeros(2 * cap, np.float64)
+        npre = C.c_size_t(0)
+        _lib.check(self._L.fskhip_trace_read_pre(self._h, pre.ctypes.data, 2 * cap, C.byref(npre)))
+        return {"amp": amp[:n.value], "post_out": post[:n.value], "bit": bit[:n.value], "pre_out": pre[:min(npre.value, 2 * cap)]}
 
     # ---- measurement tooling -------------------------------------------------------------------
     def synth_device(self, d_out, n_per_stream, pitch, payload_len, seed, lead_max, amp_lo, amp_hi, stream=None):
