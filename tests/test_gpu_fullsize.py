@@ -745,11 +745,11 @@ def test_idle_receiver_bank_one_frame_then_a_noise_floor():
             assert eng.last_kernel().startswith("fsk::demod_blk_kernel_r<"), eng.last_kernel()      # three calls of floor behind it
         digests.append(_digest(rows, eod))
         eng.close()
-    # round 5's own choice for a batch this small: six waves first (resets rare as far as the engine knows), then, the first
-    # call's statistics in, the idle-bank kernel; and the six-wave kernel pinned for the whole run (every tile on its rare paths)
+    # round 5's own choice for a batch this small: six waves (its frame wave takes own-span tiles on the block path with resets too);
+    # and the six-wave kernel pinned, on another call schedule
     eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
     rows, eod = _demod_schedule(eng, d_x, N, N, [48000])
-    assert eng.last_kernel().startswith("fsk::demod_blk_kernel_r<"), eng.last_kernel()
+    assert "demod_blk6_kernel" in eng.last_kernel(), eng.last_kernel()      # (narrow groups: six waves also where resets are frequent)
     digests.append(_digest(rows, eod))
     eng.close()
     eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options={"kernel": "six-wave"})

@@ -895,11 +895,13 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
           uint32_t med = e->blk_medium == 3u ? (e->blk_med_now ? 1u : 0u) : e->blk_medium;
           // six waves per group: narrow groups (<= 32 streams: the stages that are not recurrences spread over the idle lanes;
           // measured x1.20 at <= 2 048 streams, x1.14 at 4 096, x1.06 at 8 192 and x0.93 with whole-wave groups at 16 384,
-          // profiles/r05_six_wave.txt), every workgroup a compute unit to itself, a uniform configuration, resets rare (the
-          // idle-bank kernel keeps its calls), a call long enough to fill six stages
+          // profiles/r05_six_wave.txt), every workgroup a compute unit to itself, a uniform configuration, a call long enough to
+          // fill six stages.  Idle receiver banks included: its frame wave takes own-span tiles on the block path with resets
+          // too, and in narrow groups that beats demod_blk_kernel_r (17.0 against 14.8 Gsamples/s at 2 048 streams, 64.2 against
+          // 57.6 at 8 192)
           const uint32_t six_blocks = (e->n_streams + e->blk_lanes - 1u) / e->blk_lanes;
           const bool six = e->use_six != 0u && quad_aligned && demod_blk6_applicable(e->P) && n_fast <= demod_blk6_max_samples() &&
-                           (e->use_six == 1u || (med == 0u && e->blk_lanes <= 32u && e->cus > 0 && six_blocks <= (uint32_t)e->cus && n_fast / 16 >= e->six_min_tiles));
+                           (e->use_six == 1u || (e->blk_lanes <= 32u && e->cus > 0 && six_blocks <= (uint32_t)e->cus && n_fast / 16 >= e->six_min_tiles));
           if (six) {
             HIP_TRY(launch_demod_blk6(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
                                       e->blk_lanes, e->six_y_slots ? e->six_y_slots : demod_blk6_y_slots(e->P), e->six_rolemap));
