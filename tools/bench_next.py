@@ -98,6 +98,16 @@ def main():
                           "ms": round(ms, 3), "Msamples_per_s": round(Sf * Nf / ms / 1e3, 1),
                           "algorithmic_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000, 4)}))
         f.close()
+    # ---- IIR (round 5): the biquad low-pass the demodulator is wired from, as the generic batched IIRFilter ------------
+    bw = wm.FilterDesign.butterworthLowpass(1200, 48000)
+    for prec, name in ((wm.PRECISION_F64, "f64"), (wm.PRECISION_F32, "f32")):
+        f = wm.IIRFilterBatch(bw["b"], bw["a"], Sf, precision=prec)
+        ms = timed(lambda: f.process_device(xin.data_ptr(), Nf, Nf, yout.data_ptr(), Nf, sh), 10)
+        gbs = 8.0 * Sf * Nf / ms / 1e6
+        print(json.dumps({"row": "f3' IIRFilter.processBuffer, order 2", "dtype": name, "streams": Sf, "samples": Nf,
+                          "ms": round(ms, 3), "Msamples_per_s": round(Sf * Nf / ms / 1e3, 1),
+                          "algorithmic_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000, 4)}))
+        f.close()
     del xin, yout
 
     # ---- XModem scan / CRC ------------------------------------------------------------------------------

@@ -260,6 +260,35 @@ def blk_checks():
     return problems
 
 
+def blk6_resources():
+    """fsk_blk6.hip (six waves per group, one workgroup per CU): eight kernel bodies <write-back, group width>, each within the
+    256 VGPRs two waves per SIMD leave a wave, none with scratch memory (its frame wave keeps a register copy of the lane state
+    where the four-wave kernel parks it in memory)."""
+    src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_blk6.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+               "-c", src, "-o", os.path.join(tmp, "d.o"), "-Rpass-analysis=kernel-resource-usage"]
+        out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    res, cur = {}, None
+    for line in out.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            res[cur] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill): (\d+)", line)
+        if m and cur:
+            res[cur][m.group(1)] = int(m.group(2))
+    problems = []
+    k6 = {k: v for k, v in res.items() if "demod_blk6_kernel" in k}
+    if len(k6) != 8:
+        problems.append(("demod_blk6_kernel", "expected 8 kernel bodies, found %d" % len(k6)))
+    for k, v in k6.items():
+        if v.get("VGPRs", 999) > 256 or v.get("ScratchSize [bytes/lane]", 1) != 0 or v.get("VGPRs Spill", 1) != 0:
+            problems.append((k, "resources %s" % v))
+    return problems
+
+
 if __name__ == "__main__":
     for name, what in prefetch_register_hazards() + pipe_prefetch_hazards() + blk_checks():
         print("HAZARD", name[:50], what)
