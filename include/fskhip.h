@@ -24,7 +24,7 @@ extern "C" {
 /* 2: fskhip_max_bytes, fskhip_last_kernel.  3: fskhip_carry_over, fskhip_host_alloc / _free, the pipelined
  * fskhip_demodulate_host, fskhip_enable_signal_quality / fskhip_get_signal_quality.  4: fskhip_set_option (the library reads no
  * environment variable any more), fskhip_clock_probe_begin / _end, fskhip_debug_state.  5: fskhip_blk_lanes, option
- * "blk_lanes" (additions only).  6: kernel = six-wave / auto-r04, options "six_min_tiles" / "six_y_slots" / "six_roles"; the batched
+ * "blk_lanes" (additions only).  6: kernel = seven-wave / auto-r04, options "stage_min_tiles" / "stage_y_slots" / "stage_roles"; the batched
  * IIRFilter of fskhip_next.h (additions only). */
 #define FSKHIP_ABI_VERSION 6
 #define FSKHIP_MAX_PATTERN_BYTES 16
@@ -278,13 +278,15 @@ int fskhip_timing_end(fskhip_engine *e, uint32_t *n_launches, double *total_ms);
  * fskhip_carry_over copies do not count), for unknown names and for values that are not numbers or out of range.  None
  * changes a result: every choice computes the same bytes (tests/test_gpu_parity.py runs the goldens through each kernel).
  * The library reads no environment variable.
- *   "kernel"         auto | auto-r04 | auto-r02 | six-wave | four-wave | two-wave | one-wave   which whole-tile fp32 kernel.
- *                    auto (default): six waves per group (demod_blk6_kernel) for uniform configurations in narrow groups
- *                    (<= 32 streams per workgroup, i.e. batches of up to 32 x compute units streams) on calls of at least
- *                    "six_min_tiles" tiles, four waves (demod_blk_kernel / _r) otherwise wherever they apply; auto-r04: never six
- *   "six_min_tiles"  n              calls with fewer whole tiles stay off the six-wave kernel (default 64)
- *   "six_y_slots"    6 .. 24        depth of the six-wave kernel's y ring (default: what the LDS of a compute unit allows)
- *   "six_roles"      auto | six digits, a permutation of 0..5: the part each of a workgroup's six waves plays (measurements)
+ *   "kernel"         auto | auto-r04 | auto-r02 | seven-wave | four-wave | two-wave | one-wave   which whole-tile fp32 kernel.
+ *                    auto (default): seven waves per group (demod_blk6_kernel) for uniform configurations in batches of up
+ *                    to 64 x compute units streams (every workgroup a compute unit to itself) on calls of at least
+ *                    "stage_min_tiles" tiles, four waves (demod_blk_kernel / _r / _rp) otherwise wherever they apply;
+ *                    auto-r04: never seven ("six-wave" was this kernel's name before it had seven)
+ *   "stage_min_tiles" n             calls with fewer whole tiles stay off the seven-wave kernel (default 64)
+ *   "stage_y_slots"  6 .. 24        depth of the seven-wave kernel's y ring (default: what the LDS of a compute unit allows; at least 2 + the
+ *                                   half tiles its iq wave may lead the frame wave by)
+ *   "stage_roles"    auto | seven digits, a permutation of 0..6: the part each of a workgroup's seven waves plays (measurements)
  *   "force_generic"  0 | 1          never a whole-tile kernel: the sample-serial kernel only
  *   "blk_y_slots"    6 .. 28        depth of the four-wave kernel's first ring (checked against the LDS it needs)
  *   "blk_min_tiles"  n              calls with fewer whole tiles stay off the four-wave kernel
@@ -311,7 +313,7 @@ int fskhip_clock_probe_begin(fskhip_engine *e, double spin_ms);
 int fskhip_clock_probe_end(fskhip_engine *e, double *shader_ghz, double *covered_ms);
 
 /*
- * Hand-off waits (a property of the multi-wave kernels, not an entry point).  The four- and six-wave demodulator kernels pass
+ * Hand-off waits (a property of the multi-wave kernels, not an entry point).  The four- and seven-wave demodulator kernels pass
  * tiles from wave to wave through LDS rings guarded by counters; a wave that finds its input not there yet polls the counter
  * with s_sleep in between, WITHOUT a bound: the producer is a wave of the same workgroup and is always running (every part is
  * played exactly once: the waves settle their parts among themselves at the start), so the wait ends -- but a lost counter

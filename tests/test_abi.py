@@ -163,7 +163,7 @@ def test_whole_tile_kernels_never_spill():
     # the four-wave block kernel (fsk_blk.hip): within 128 VGPRs, no scratch access inside the per-tile loops, the
     # asynchronous hand-off counter read's registers untouched until a wait covers it
     assert check_isa.blk_checks() == []
-    # the six-wave small-batch kernel (fsk_blk6.hip): within 256 VGPRs (two waves per SIMD), no scratch memory at all
+    # the seven-wave small-batch kernel (fsk_blk6.hip): within 256 VGPRs (two waves per SIMD), no scratch memory at all
     assert check_isa.blk6_resources() == []
 
 

@@ -202,7 +202,7 @@ def test_whole_tile_kernels_agree_on_ragged_batches(S, monkeypatch):
     gen.synchronize()
     digests = {}
     for name, env in (("split", {"FSKHIP_SPLIT": "1"}), ("one_wave", {"FSKHIP_SPLIT": "0"}),
-                      ("four_wave", {"FSKHIP_SPLIT": "4"}), ("six_wave", {"FSKHIP_SPLIT": "6"}), ("generic", {"FSKHIP_FORCE_GENERIC": "1"})):
+                      ("four_wave", {"FSKHIP_SPLIT": "4"}), ("seven_wave", {"FSKHIP_SPLIT": "6"}), ("generic", {"FSKHIP_FORCE_GENERIC": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
@@ -211,7 +211,7 @@ def test_whole_tile_kernels_agree_on_ragged_batches(S, monkeypatch):
         rows, eod = _demod_schedule(eng, d_x, N, N, [4096, 16, 1000, 48, 20000])
         digests[name] = (_digest(rows, eod), sum(len(r) for r in rows))
         eng.close()
-    assert digests["split"] == digests["one_wave"] == digests["four_wave"] == digests["six_wave"] == digests["generic"], digests
+    assert digests["split"] == digests["one_wave"] == digests["four_wave"] == digests["seven_wave"] == digests["generic"], digests
     assert digests["split"][1] >= 12 * S * 0.5
     gen.device_free(d_x)
     gen.close()
@@ -228,7 +228,7 @@ def test_y_ring_depth_does_not_change_results(S, monkeypatch):
     gen.synth_device(d_x, N, N, 12, SEED + 11, 300, 0.1, 1.0)
     gen.synchronize()
     digests = {}
-    monkeypatch.setenv("FSKHIP_SPLIT", "c")      # (auto-r04: the four-wave kernel is what this test is about; small batches default to six waves since round 5)
+    monkeypatch.setenv("FSKHIP_SPLIT", "c")      # (auto-r04: the four-wave kernel is what this test is about; small batches default to seven waves since round 5)
     for y in ("auto", "6", "7", "12", "28"):
         if y != "auto":
             monkeypatch.setenv("FSKHIP_BLK_YSLOTS", y)
@@ -258,7 +258,7 @@ def test_time_sliced_persistent_launch_matches_one_workgroup_per_group(S, reside
     gen.synth_device(d_x, N, N, 12, SEED + 7, 300, 0.1, 1.0)
     gen.synchronize()
     digests = {}
-    for name, env in (("plain", {"FSKHIP_SLICE_TILES": "off", "FSKHIP_SPLIT": "c"}),      # ("c" = auto-r04: never the six-wave kernel, which is never sliced)
+    for name, env in (("plain", {"FSKHIP_SLICE_TILES": "off", "FSKHIP_SPLIT": "c"}),      # ("c" = auto-r04: never the seven-wave kernel, which is never sliced)
                       ("sliced", {"FSKHIP_BLK_RESIDENT": str(resident), "FSKHIP_SLICE_TILES": str(slice_tiles), "FSKHIP_SPLIT": "c"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -664,7 +664,7 @@ def test_config2_full_length_480000_samples():
     """BASELINE config #2 as written: 4 096 V.21-tone 300-baud streams x 480 000 samples (10 s) in ONE call, against the oracle
     on a strided sample, and against the same buffer in 1 s calls (VERDICT r02 #7)."""
     kernel, nbytes = _full_length_check(4096, V21, 480000, 32, 1600, 12, 48000)
-    assert "demod_blk6_kernel" in kernel      # (round 5: 4 096 streams = 256 groups of 16: the six-wave small-batch kernel)
+    assert "demod_blk6_kernel" in kernel      # (round 5: 4 096 streams = 256 groups of 16: the seven-wave small-batch kernel)
     assert nbytes >= 4096 * 32 * 4          # eight 32-byte frames fit into 10 s; most of them decode
 
 
@@ -745,14 +745,14 @@ def test_idle_receiver_bank_one_frame_then_a_noise_floor():
             assert eng.last_kernel().startswith("fsk::demod_blk_kernel_r<"), eng.last_kernel()      # three calls of floor behind it
         digests.append(_digest(rows, eod))
         eng.close()
-    # round 5's own choice for a batch this small: six waves (its frame wave takes own-span tiles on the block path with resets too);
-    # and the six-wave kernel pinned, on another call schedule
+    # round 5's own choice for a batch this small: seven waves (its frame wave takes own-span tiles on the block path with resets too);
+    # and the seven-wave kernel pinned, on another call schedule
     eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
     rows, eod = _demod_schedule(eng, d_x, N, N, [48000])
-    assert "demod_blk6_kernel" in eng.last_kernel(), eng.last_kernel()      # (narrow groups: six waves also where resets are frequent)
+    assert "demod_blk6_kernel" in eng.last_kernel(), eng.last_kernel()      # (narrow groups: seven waves also where resets are frequent)
     digests.append(_digest(rows, eod))
     eng.close()
-    eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options={"kernel": "six-wave"})
+    eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options={"kernel": "seven-wave"})
     rows, eod = _demod_schedule(eng, d_x, N, N, [30000, 128, 17, 48000])
     assert "demod_blk6_kernel" in eng.last_kernel(), eng.last_kernel()
     digests.append(_digest(rows, eod))
@@ -799,7 +799,7 @@ def test_config1_polarity_bank_never_syncs():
     gen.close()
 
 
-@pytest.mark.parametrize("kernel", ["six-wave", "four-wave", "two-wave", "one-wave"])
+@pytest.mark.parametrize("kernel", ["seven-wave", "four-wave", "two-wave", "one-wave"])
 def test_agc_write_back_on_dword_aligned_tiles(kernel):
     """Round 4: after an odd-length call the whole tiles of the next start 4, 8 or 12 bytes off a 16-byte boundary (the head only
     realigns the decimator and the amplitude ring).  With FSKHIP_DEMOD_WRITEBACK_AGC the kernels also STORE 16 bytes per lane
@@ -841,14 +841,14 @@ def test_agc_write_back_on_dword_aligned_tiles(kernel):
     assert results[0][0] == results[1][0]
     assert np.array_equal(results[0][1], results[1][1])
     assert not np.array_equal(results[0][1], x[:, :N])                    # (something was written back)
-    want = {"six-wave": "demod_blk6_kernel", "four-wave": "demod_blk_kernel", "two-wave": "demod_pipe_kernel", "one-wave": "demod_fused_kernel"}[kernel]
+    want = {"seven-wave": "demod_blk6_kernel", "four-wave": "demod_blk_kernel", "two-wave": "demod_pipe_kernel", "one-wave": "demod_fused_kernel"}[kernel]
     assert any(want in k for k in results[1][2]), results[1][2]
     gen.device_free(d_src)
     gen.close()
 
 
 @pytest.mark.parametrize("S,lanes", [(2048, None), (4096, None), (700, "32"), (150, "64"), (96, "16")])
-def test_six_wave_kernel_is_the_four_wave_kernel_bit_for_bit(S, lanes, monkeypatch):
+def test_seven_wave_kernel_is_the_four_wave_kernel_bit_for_bit(S, lanes, monkeypatch):
     """Round 5: demod_blk6_kernel (fsk_blk6.hip) -- the small-batch kernel whose stages that are not recurrences run on the idle
     lanes of a narrow group and whose post filter runs ahead of the frame logic and is rewound after a reset -- against
     demod_blk_kernel on the same buffers: config #3's signal at 10 dB SNR on top of random lead-ins and levels, a ragged call
@@ -864,7 +864,7 @@ def test_six_wave_kernel_is_the_four_wave_kernel_bit_for_bit(S, lanes, monkeypat
     gen.synchronize()
     sched = [4096, 19, 128, 128, 30000, 7, 2049, 16, 48000, 3]
     res = {}
-    for name, opts in (("four", {"kernel": "four-wave"}), ("six", {"kernel": "six-wave"})):
+    for name, opts in (("four", {"kernel": "four-wave"}), ("six", {"kernel": "seven-wave"})):
         if lanes:
             opts = dict(opts, blk_lanes=lanes)
         eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options=opts)
@@ -886,8 +886,8 @@ def test_six_wave_kernel_is_the_four_wave_kernel_bit_for_bit(S, lanes, monkeypat
     gen.close()
 
 
-def test_six_wave_is_the_default_for_small_uniform_batches():
-    """The engine's own choice: narrow groups of a uniform configuration on a long enough call -> six waves; per-stream tone
+def test_seven_wave_is_the_default_for_small_uniform_batches():
+    """The engine's own choice: narrow groups of a uniform configuration on a long enough call -> seven waves; per-stream tone
     pairs, whole-wave groups and short calls stay on four."""
     import webaudio_modem_amd as wm
     N = 48000

@@ -42,12 +42,12 @@ def _check_status(st, ref, tol, agc_gain):
 # golden runs on an 8-lane group by default; "f32-four-wave-64" pins whole-wave groups)
 # "-resets": demod_blk_kernel_r, whose block path takes 'eod' resets itself (the default picks it only after a call whose
 # tiles mostly left the fast path); "-redo": the same, every such block then put back and redone sample by sample
-# (round 5: "f32-six-wave": demod_blk6_kernel, the small-batch kernel -- loader | AGC | pre-filter | iq + discriminator on the idle
+# (round 5: "f32-seven-wave": demod_blk6_kernel, the small-batch kernel -- loader | AGC | pre-filter | iq + discriminator on the idle
 # lanes of a narrow group | post filter running ahead of the frame logic with rewind | frame logic; a one-stream golden runs it
 # on an 8-lane group; "-64" pins whole-wave groups, whose six parts are cut differently)
 GOLDEN_VARIANTS = PRECISIONS + [("f32-one-wave", 0, 1e-5), ("f32-four-wave", 0, 1e-5), ("f32-four-wave-64", 0, 1e-5),
                                 ("f32-four-wave-resets", 0, 1e-5), ("f32-four-wave-redo", 0, 1e-5),
-                                ("f32-six-wave", 0, 1e-5), ("f32-six-wave-64", 0, 1e-5)]
+                                ("f32-seven-wave", 0, 1e-5), ("f32-seven-wave-64", 0, 1e-5)]
 
 
 @pytest.mark.parametrize("pname,prec,tol", GOLDEN_VARIANTS)
@@ -64,7 +64,7 @@ def test_demod_matches_reference_golden(name, pname, prec, tol, monkeypatch):
     elif pname in ("f32-four-wave-resets", "f32-four-wave-redo"):
         monkeypatch.setenv("FSKHIP_SPLIT", "4")
         monkeypatch.setenv("FSKHIP_BLK_RESETS", "1" if pname.endswith("resets") else "2")
-    elif pname in ("f32-six-wave", "f32-six-wave-64"):
+    elif pname in ("f32-seven-wave", "f32-seven-wave-64"):
         monkeypatch.setenv("FSKHIP_SPLIT", "6")
         if pname.endswith("64"):
             monkeypatch.setenv("FSKHIP_BLK_LANES", "64")

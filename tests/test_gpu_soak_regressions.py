@@ -22,7 +22,7 @@ CASES = [
     ("soak_r02_sync075_s131.npy", {"syncThreshold": 0.75}, [129, 17, 4096, 1000]),
     ("soak_r02_v21_s8.npy", {"baudRate": 300, "markFrequency": 1070, "spaceFrequency": 1270}, [1000, 128, 128, 1000]),
 ]
-PATHS = [("six-wave", {"FSKHIP_SPLIT": "6"}), ("four-wave", {"FSKHIP_SPLIT": "4"}), ("two-wave", {"FSKHIP_SPLIT": "1"}), ("one-wave", {"FSKHIP_SPLIT": "0"}),
+PATHS = [("seven-wave", {"FSKHIP_SPLIT": "6"}), ("four-wave", {"FSKHIP_SPLIT": "4"}), ("two-wave", {"FSKHIP_SPLIT": "1"}), ("one-wave", {"FSKHIP_SPLIT": "0"}),
          ("generic", {"FSKHIP_FORCE_GENERIC": "1"})]
 KEYS = ["frameStarted", "globalSampleCounter", "receivedBitsLength", "syncDetections"]
 

@@ -1,16 +1,16 @@
 """FSKHIP_* environment variables -> fskhip_set_option() names (tests/conftest.py and the measurement tools install this as
 webaudio_modem_amd.engine.option_hook; the package and libfskhip.so themselves read no environment variable).
 
-  FSKHIP_SPLIT=0|1|4|6|a|b|c  kernel = one-wave | two-wave | four-wave | six-wave | auto | auto-r02 | auto-r04
+  FSKHIP_SPLIT=0|1|4|6|a|b|c  kernel = one-wave | two-wave | four-wave | seven-wave | auto | auto-r02 | auto-r04
   FSKHIP_FORCE_GENERIC=1      force_generic
   FSKHIP_BLK_YSLOTS=<n>       blk_y_slots          FSKHIP_BLK_MIN_TILES=<n>   blk_min_tiles
   FSKHIP_BLK_RESIDENT=<n>     blk_resident         FSKHIP_SLICE_TILES=<n>|off slice_tiles
   FSKHIP_HOST_SLAB=<n>        host_slab
-  FSKHIP_SIX_MIN_TILES=<n>    six_min_tiles        FSKHIP_SIX_YSLOTS=<n>      six_y_slots      FSKHIP_SIX_ROLES=<6 digits> six_roles
+  FSKHIP_SIX_MIN_TILES=<n>    stage_min_tiles      FSKHIP_SIX_YSLOTS=<n>      stage_y_slots    FSKHIP_SIX_ROLES=<7 digits> stage_roles
 """
 import os
 
-_KERNEL = {"0": "one-wave", "1": "two-wave", "4": "four-wave", "6": "six-wave", "a": "auto", "b": "auto-r02", "c": "auto-r04"}
+_KERNEL = {"0": "one-wave", "1": "two-wave", "4": "four-wave", "6": "seven-wave", "a": "auto", "b": "auto-r02", "c": "auto-r04"}
 
 
 def from_env(n_streams=None, precision=None):
@@ -23,7 +23,7 @@ def from_env(n_streams=None, precision=None):
     for env, name in (("FSKHIP_BLK_YSLOTS", "blk_y_slots"), ("FSKHIP_BLK_MIN_TILES", "blk_min_tiles"),
                       ("FSKHIP_BLK_RESIDENT", "blk_resident"), ("FSKHIP_SLICE_TILES", "slice_tiles"),
                       ("FSKHIP_BLK_LANES", "blk_lanes"), ("FSKHIP_BLK_RESETS", "blk_resets"),
-                      ("FSKHIP_SIX_MIN_TILES", "six_min_tiles"), ("FSKHIP_SIX_YSLOTS", "six_y_slots"), ("FSKHIP_SIX_ROLES", "six_roles"),
+                      ("FSKHIP_SIX_MIN_TILES", "stage_min_tiles"), ("FSKHIP_SIX_YSLOTS", "stage_y_slots"), ("FSKHIP_SIX_ROLES", "stage_roles"),
                       ("FSKHIP_HOST_SLAB", "host_slab")):
         v = os.environ.get(env)
         if v is not None and v != "":

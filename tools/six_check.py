@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""six_check.py (GPU box): the six-wave small-batch kernel (fsk_blk6.hip) against the four-wave kernel on the same synthetic
+"""six_check.py (GPU box): the seven-wave small-batch kernel (fsk_blk6.hip) against the four-wave kernel on the same synthetic
 buffers -- decoded bytes, counts, 'eod' counts and the carried per-stream state words must be IDENTICAL (the same float
 instruction sequence per decimated sample, whoever runs it) -- and their kernel times.
 
@@ -35,7 +35,7 @@ else:
 torch.cuda.synchronize()
 g.close()
 res = {}
-for name, opts in (("four", {"kernel": "auto-r04"}), ("six", {"kernel": "six-wave"})):
+for name, opts in (("four", {"kernel": "auto-r04"}), ("six", {"kernel": "seven-wave"})):
     opts = dict(opts)
     for kv in filter(None, os.environ.get("SIX_OPTS", "").split(",")):
         k, _, v = kv.partition("=")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""six_diag.py (GPU box): where the six-wave kernel first leaves the four-wave kernel's results.  For growing call lengths
+"""six_diag.py (GPU box): where the seven-wave kernel first leaves the four-wave kernel's results.  For growing call lengths
 (whole tiles) it demodulates the same buffer from the reset state with both kernels and names the state words that differ:
 the first length at which a stream's words differ localises the tile.   tools/six_diag.py S N [workload] [step]"""
 import os
@@ -41,7 +41,7 @@ def run(kernel, n):
 
 
 def diff(n):
-    a, b = run("auto-r04", n), run("six-wave", n)
+    a, b = run("auto-r04", n), run("seven-wave", n)
     bad = {}
     for s, ((ra, ia), (rb, ib)) in enumerate(zip(a[2], b[2])):
         names = [REAL[i] for i in range(len(ra)) if np.float64(ra[i]).view(np.uint64) != np.float64(rb[i]).view(np.uint64)]

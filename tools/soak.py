@@ -112,7 +112,7 @@ def main(budget=None, seed=None, max_rounds=None):
         # group width -- drawn from a generator of their own, so that earlier rounds' seeds still replay the same signals
         os.environ["FSKHIP_BLK_RESETS"] = ["auto", "0", "1", "2", "1"][int(rng2.integers(5))]
         os.environ["FSKHIP_BLK_LANES"] = ["auto", "64", "16"][int(rng2.integers(3))]
-        # round 5: half of the four-wave rounds go to the six-wave small-batch kernel instead (uniform configurations; others
+        # round 5: half of the four-wave rounds go to the seven-wave small-batch kernel instead (uniform configurations; others
         # fall back to four waves), drawn from the second generator like the choices above
         if os.environ["FSKHIP_SPLIT"] == "4" and rng2.random() < 0.5:
             os.environ["FSKHIP_SPLIT"] = "6"

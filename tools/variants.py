@@ -38,7 +38,7 @@ if wl == "idle":      # bench.py --workload idle: one frame per stream, then a f
         x[:, c0:n0] *= (torch.arange(c0, n0, device="cuda")[None, :] < torch.as_tensor(ends, device="cuda")[:, None])
     eng.add_awgn_device(x.data_ptr(), N, N, 30.0 - 10.0 * math.log10(N / float(fl)), 0xF5C0DE ^ 0xA36, st)
 else:
-    eng.synth_device(x.data_ptr(), N, N, 100 if wl == "c3" else 32, 0xF5C0DE, 400, 0.1, 1.0, st)
+    eng.synth_device(x.data_ptr(), N, N, 100 if wl == "c3" else 32, 0xF5C0DE, int(os.environ.get("VAR_LEAD", "400")), 0.1, 1.0, st)
 torch.cuda.synchronize()
 def step():
     eng.demodulate_device(x.data_ptr(), N, N, out.data_ptr(), op, cnt.data_ptr(), 0, 0, st)

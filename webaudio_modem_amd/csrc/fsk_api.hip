@@ -47,7 +47,7 @@ void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t 
 uint32_t demod_blk_slices(const DemodParams &P, const DemodState &S, size_t n, uint32_t resident_wgs, uint32_t slice_tiles,
                           uint32_t *slice_tiles_out);
 size_t demod_blk_queue_words(uint32_t groups);
-// fsk_blk6.hip: six waves per group, for batches that leave every workgroup a compute unit of its own
+// fsk_blk6.hip: seven waves per group, for batches that leave every workgroup a compute unit of its own
 size_t demod_blk6_lds_bytes(const DemodParams &P, uint32_t y_slots);
 uint32_t demod_blk6_y_slots(const DemodParams &P);
 bool demod_blk6_applicable(const DemodParams &P);
@@ -210,13 +210,13 @@ struct fskhip_engine {
   volatile unsigned long long *h_stat = nullptr;   // pinned: {tiles, tiles off the fast loop} as the last completed copy left them
   uint32_t stat_tiles = 0, stat_rare = 0;          // ... as of the last look
   uint32_t stat_skip = 0;                          // short calls since the last fetch
-  // six waves per group (demod_blk6_kernel, fsk_blk6.hip): the whole-tile kernel of batches small enough to give every workgroup a
-  // compute unit of its own (uniform configurations, calls of at least six_min_tiles tiles, resets rare): 0 never, 1 wherever it
-  // applies ("kernel" = six-wave), 2 auto
+  // seven waves per group (demod_blk6_kernel, fsk_blk6.hip): the whole-tile kernel of batches small enough to give every workgroup a
+  // compute unit of its own (uniform configurations, calls of at least six_min_tiles tiles): 0 never, 1 wherever it applies
+  // ("kernel" = seven-wave), 2 auto
   uint32_t use_six = 2;
-  uint32_t six_min_tiles = 64;   // shorter calls stay on the four-wave kernel: six stages take longer to fill and drain
+  uint32_t six_min_tiles = 64;   // shorter calls stay on the four-wave kernel: seven stages take longer to fill and drain
   uint32_t six_y_slots = 0;      // 0 = as deep as the LDS allows
-  uint32_t six_rolemap = 0;      // 0 = the default placement of the six parts on a workgroup's waves
+  uint32_t six_rolemap = 0;      // 0 = the default placement of the seven parts on a workgroup's waves
   int cus = 0;
   bool demodulated = false;      // a demodulate call has been issued or replayed (fskhip_set_option refuses from then on)
   uint32_t blk_lanes = 64;       // streams per workgroup of demod_blk_kernel: 64, or 32 / 16 / 8 for batches that leave CUs idle (fsk_blk.hip)
@@ -718,13 +718,13 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
     const uint32_t n_blocks = e->n_blocks;
     e->use_six = 0u;
     if (v == "auto") { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; e->use_six = 2u; }
-    else if (v == "auto-r04") { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; }   // (round 4's choice: never six waves)
+    else if (v == "auto-r04") { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; }   // (round 4's choice: never seven waves)
     else if (v == "auto-r02") { e->use_blk = false; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; }
-    else if (v == "six-wave") { e->use_blk = true; e->use_split = true; e->split_forced = true; e->use_six = 1u; }   // (four waves where six do not apply)
+    else if (v == "seven-wave" || v == "six-wave") { e->use_blk = true; e->use_split = true; e->split_forced = true; e->use_six = 1u; }   // (four waves where seven do not apply; "six-wave": its first name)
     else if (v == "four-wave") { e->use_blk = true; e->use_split = true; e->split_forced = true; }
     else if (v == "two-wave") { e->use_blk = false; e->use_split = true; e->split_forced = true; }
     else if (v == "one-wave") { e->use_blk = false; e->use_split = false; e->split_forced = true; }
-    else return fail(FSKHIP_E_INVALID, "fskhip_set_option(kernel): '%s' is none of auto, auto-r04, auto-r02, six-wave, four-wave, two-wave, one-wave", value);
+    else return fail(FSKHIP_E_INVALID, "fskhip_set_option(kernel): '%s' is none of auto, auto-r04, auto-r02, seven-wave, four-wave, two-wave, one-wave", value);
     return FSKHIP_OK;
   }
   if (k == "blk_resets") {      // 1: the four-wave kernel's block path takes resets (default), 0: such blocks go sample by sample
@@ -733,27 +733,26 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
     e->blk_medium = (uint32_t)x;
     return FSKHIP_OK;
   }
-  if (k == "six_min_tiles") {
+  if (k == "stage_min_tiles") {
     if ((rc = number(0, 1u << 30, &x)) != FSKHIP_OK) return rc;
     e->six_min_tiles = (uint32_t)x;
     return FSKHIP_OK;
   }
-  if (k == "six_y_slots") {
+  if (k == "stage_y_slots") {
     if ((rc = number(6, 24, &x)) != FSKHIP_OK) return rc;
     e->six_y_slots = (uint32_t)x & ~1u;
     return FSKHIP_OK;
   }
-  if (k == "six_roles") {       // measurements: the part each of the six waves plays, e.g. 025143 (every part exactly once)
+  if (k == "stage_roles") {       // measurements: the part each of the seven waves plays, e.g. 0135426 (every part exactly once)
     if (v == "auto") { e->six_rolemap = 0u; return FSKHIP_OK; }
     uint32_t m = 0, seen = 0;
-    if (v.size() != 6) return fail(FSKHIP_E_INVALID, "fskhip_set_option(six_roles): '%s' is not six digits 0..5", value);
-    for (uint32_t w = 0; w < 6; w++) {
+    if (v.size() != 7) return fail(FSKHIP_E_INVALID, "fskhip_set_option(stage_roles): '%s' is not seven digits 0..6", value);
+    for (uint32_t w = 0; w < 7; w++) {
       const uint32_t r = (uint32_t)(v[w] - '0');
-      if (r > 5u || (seen & (1u << r))) return fail(FSKHIP_E_INVALID, "fskhip_set_option(six_roles): '%s' is not a permutation of 0..5", value);
+      if (r > 6u || (seen & (1u << r))) return fail(FSKHIP_E_INVALID, "fskhip_set_option(stage_roles): '%s' is not a permutation of 0..6", value);
       seen |= 1u << r; m |= r << (3u * w);
     }
-    e->six_rolemap = m ? m : 0u;
-    if (!m) return fail(FSKHIP_E_INVALID, "fskhip_set_option(six_roles): '%s'", value);
+    e->six_rolemap = m;
     return FSKHIP_OK;
   }
   if (k == "force_generic") {
@@ -893,15 +892,14 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
             ((blk_fits && n_fast / 16 >= e->blk_min_tiles) || e->split_forced)) {
           engine_refresh_kernel_choice(e);
           uint32_t med = e->blk_medium == 3u ? (e->blk_med_now ? 1u : 0u) : e->blk_medium;
-          // six waves per group: narrow groups (<= 32 streams: the stages that are not recurrences spread over the idle lanes;
-          // measured x1.20 at <= 2 048 streams, x1.14 at 4 096, x1.06 at 8 192 and x0.93 with whole-wave groups at 16 384,
-          // profiles/r05_six_wave.txt), every workgroup a compute unit to itself, a uniform configuration, a call long enough to
-          // fill six stages.  Idle receiver banks included: its frame wave takes own-span tiles on the block path with resets
-          // too, and in narrow groups that beats demod_blk_kernel_r (17.0 against 14.8 Gsamples/s at 2 048 streams, 64.2 against
-          // 57.6 at 8 192)
+          // seven waves per group: every workgroup a compute unit to itself (in narrow groups -- <= 32 streams -- the stages that
+          // are not recurrences spread over the idle lanes), a uniform configuration, a call long enough to fill seven stages.
+          // Measured against the four-wave kernel: x 1.56 at 2 048 streams, x 1.48 at 4 096, x 1.42 at 8 192, x 1.13 with whole-wave
+          // groups at 16 384 (profiles/r05_lag.txt).  Idle receiver banks included: its frame wave takes own-span tiles on the
+          // block path with resets too.
           const uint32_t six_blocks = (e->n_streams + e->blk_lanes - 1u) / e->blk_lanes;
           const bool six = e->use_six != 0u && quad_aligned && demod_blk6_applicable(e->P) && n_fast <= demod_blk6_max_samples() &&
-                           (e->use_six == 1u || (e->blk_lanes <= 32u && e->cus > 0 && six_blocks <= (uint32_t)e->cus && n_fast / 16 >= e->six_min_tiles));
+                           (e->use_six == 1u || (e->cus > 0 && six_blocks <= (uint32_t)e->cus && n_fast / 16 >= e->six_min_tiles));
           if (six) {
             HIP_TRY(launch_demod_blk6(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
                                       e->blk_lanes, e->six_y_slots ? e->six_y_slots : demod_blk6_y_slots(e->P), e->six_rolemap));

@@ -1,4 +1,5 @@
-// fsk_blk6.hip -- round-5 SMALL-BATCH whole-tile fp32 demodulator for gfx950 (MI355X): SIX waves per stream group.
+// fsk_blk6.hip -- round-5 SMALL-BATCH whole-tile fp32 demodulator for gfx950 (MI355X): SEVEN waves per stream group
+// (the file and the kernel keep the name of the first, six-wave cut).
 //
 // Why.  At <= 64 x (compute units) streams every workgroup of the four-wave kernel (fsk_blk.hip) has a compute unit to itself:
 // one wave per SIMD, and a lone wave issues one instruction per ~4.9 cycles whatever it is (profiles/r02_valu_probe*.txt), so
@@ -6,35 +7,44 @@
 // against 105 / 104 / 94 for the others (profiles/r03_blk_final_stamps.txt) -- while three quarters of every SIMD's issue slots
 // and, with narrow groups, half to seven eighths of the lanes sit idle (BASELINE configs #2, #3-as-sharded
 // and #5-as-sharded run at 2-7 % of the roofline; eight GPUs would buy config #3 2.0x).  There a workgroup may have the whole
-// CU's registers and LDS, so this kernel cuts the same chain into SIX waves, and uses the idle lanes of a narrow group where a
-// stage is not a recurrence:
-//   P0 loader   tile loads (three register sets in flight) -> a ring of staging tiles; the tile's sixteen NCO phasors
-//   P1 agc-bp   AGC + pre-filter (what resetState() never touches)                                   -> y ring
-//   P2 iq       mixer + free-running I/Q low-pass + pair sums U.  Groups of <= 32 streams: the I chain in lanes 0..31 and
-//               the Q chain in lanes 32..63 of the SAME wave (two independent recurrences: half the instructions)  -> x ring
-//   P3 disc     ZIR correction (once it is this wave's) + branch-free atan2 / magnitude, x ring IN PLACE.  Stateless while no
-//               correction is live, so a group of W streams spreads a tile's eight decimated samples over 64 / W lanes per
-//               stream (W = 32: two lanes x four samples ... W = 8: eight lanes x one sample)
-//   P4 post     discriminator tail + post filter + slicer (disc_post, the very function every other kernel calls), running
-//               AHEAD of the frame logic on the assumption that no resetState() intervenes         -> f ring (+ its entry
-//               state per tile)
-//   P5 frame    sync correlator, silence run, bit clock, byte assembly, 'eod' -- blk_fast without its disc_post -- and every
-//               rare path (the per-sample back_pair, unchanged), which is where resets come from
+// CU's registers and LDS, so this kernel cuts the same chain into SEVEN waves, and uses the idle lanes of a narrow group where
+// a stage is not a recurrence (parts, as the role map numbers them):
+//   0 loader   tile loads (three register sets in flight) -> a ring of staging tiles; the tile's sixteen NCO phasors
+//   1 agc      the AGC (a recurrence of ten dependent instructions per sample), IN PLACE in the staging tile
+//   2 bp       the pre-filter (with the AGC: what resetState() never touches)                         -> y ring
+//   3 iq       mixer + free-running I/Q low-pass + pair sums U.  Groups of <= 32 streams: the I chain in lanes 0..31 and
+//              the Q chain in lanes 32..63 of the SAME wave (two independent recurrences: half the instructions)  -> x ring
+//   6 disc     ZIR correction (once it is this wave's) + branch-free atan2 / magnitude, x ring IN PLACE.  Stateless while no
+//              correction is live, so a group of W streams spreads a tile's eight decimated samples over 64 / W lanes per
+//              stream (W = 32: two lanes x four samples ... W = 8: eight lanes x one sample)
+//   4 post     discriminator tail + post filter + slicer (disc_post, the very function every other kernel calls), running
+//              AHEAD of the frame logic on the assumption that no resetState() intervenes         -> f ring (+ its entry
+//              state per tile)
+//   5 frame    sync correlator, silence run, bit clock, byte assembly, 'eod' -- blk_fast without its disc_post -- and every
+//              rare path (blk_medium's sequence for own-span tiles, the per-sample back_pair), which is where resets come from
+// Four stages work on the x ring -- iq, disc, post, frame -- and the reset feedback bounds how far they may spread: the iq
+// wave learns of a resetState() kZeroLagPairs decimated samples late, the discriminator wave is handed the correction
+// kHandLag ahead of its sample (fsk_params.h), so they may lead the frame wave by kZeroLagPairs / 8 and kHandLag / 8 tiles
+// and no more.  At 24 / 24 (round 4's constants) that was three tiles for four stages: the ring turned once per SUM of the
+// stage times and the hand-offs / 3 (x 1.04 - 1.22 over the four-wave kernel, profiles/r05_six_wave.txt).  Round 5 raised both
+// to 48 -- six tiles -- which is what makes the stages overlap (profiles/r05_lag.txt: x 1.40 at 8 192 streams, x 1.54 at 2 048;
+// every kernel of the library takes the same constants, so their results stay one another's bit for bit).
 // Speculate and rewind (DESIGN.md section 9 of round 4, VERDICT r04 #1c).  resetState() (fsk.ts:175-188) zeroes the post filter
-// and lastPhase from inside the frame logic, i.e. P5 feeds back into P4.  P4 therefore records the state it ENTERED every
-// tile with; a tile whose block test trips in P5 (a sync candidate, a bad start / stop bit, a possible 'eod') -- and every
-// tile while a lane is inside the own span after a reset -- is redone by P5 sample by sample from that entry state, exactly as
-// the four-wave kernel's back wave redoes it; when P5 returns to its block loop it posts the state it ended with and the
-// tile to resume at (a generation number makes P4's stale output recognisable), P4 drops what it ran ahead and restarts
-// there.  P4's float sequence per decimated sample is disc_post's, its inputs are the x ring's, so the values do not depend
-// on who computed them or how often: bytes, counters and carried state are the four-wave kernel's bit for bit
-// (tests/test_gpu_parity.py runs every golden through this kernel, tests/test_gpu_fullsize.py compares state words).
+// and lastPhase from inside the frame logic, i.e. the frame wave feeds back into the post wave.  The post wave therefore
+// records the state it ENTERED every tile with; a tile whose block test trips in the frame wave (a sync candidate, a bad
+// start / stop bit, a possible 'eod') -- and every tile while a lane is inside the own span after a reset -- is redone by the
+// frame wave from that entry state, exactly as the four-wave kernel's back wave redoes it; when it returns to its block loop
+// it posts the state it ended with and the tile to resume at (a generation number makes the post wave's stale output
+// recognisable), the post wave drops what it ran ahead and restarts there.  Its float sequence per decimated sample is
+// disc_post's, its inputs are the x ring's, so the values do not depend on who computed them or how often: bytes, counters
+// and carried state are the four-wave kernel's bit for bit (tests/test_gpu_parity.py runs every golden through this kernel,
+// tests/test_gpu_fullsize.py compares state words).
 // Uniform configurations only (per-stream tone pairs stay on the four-wave kernel); never time-sliced (a batch this small is
-// one round of workgroups by definition); the idle-bank kernel demod_blk_kernel_r keeps its calls.
-// LDS (one workgroup per CU): stage [4 tiles][4][65] v4f | yring [y_slots][2][64] v4f | xring [3 tiles][4][64] v4f (I or phase 0..3,
-//      4..7; Q or magnitude 0..3, 4..7) | fring [3][4][64] v4f (-f 0..3, 4..7; magnitude 0..3, 4..7) | trash [3][4][64] v4f | hist [3][2][64] v4f | rmail
-//      [2][64] v4f | fin [5][64] v4f | zt [tiles][8] v4f (cos[16], sin[16]) | poly [64][PS] u32 | counters [16] | zmail [64] |
-//      cmail [6][64]
+// one round of workgroups by definition).
+// LDS (one workgroup per CU; XT = kZeroLagPairs / 8 tiles): stage [4 tiles][4][65] v4f | yring [y_slots][2][64] v4f | xring [XT][4][64]
+//      v4f (I or phase 0..3, 4..7; Q or magnitude 0..3, 4..7) | fring [XT][4][64] v4f (-f 0..3, 4..7; magnitude 0..3, 4..7) | trash
+//      [4][64] v4f | hist [XT][2][64] v4f | rmail [2][64] v4f | fin [5][64] v4f | zt [tiles][8] v4f (cos[16], sin[16]) | poly [64][PS]
+//      u32 | counters [16] | zmail [64] | cmail [6][64]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -48,14 +58,18 @@
 namespace fsk {
 
 static constexpr uint32_t kB6Stage = 4;                    // staging tiles between the loader and the AGC wave
-static constexpr uint32_t kB6XT = kBlkSlots / 2;           // tiles in the x ring, the f ring and the entry-state history
+static constexpr uint32_t kB6XT = kZeroLagPairs / 8;       // tiles in the x ring, the f ring and the entry-state history: as far as the wave that
+                                                           // owns the I/Q low-pass may run ahead of the frame wave (a reset reaches it kZeroLagPairs late)
+static constexpr uint32_t kB6DT = kHandLag / 8;            // ... and the discriminator wave (the correction is handed to it kHandLag ahead of its sample)
+static constexpr uint32_t kB6Waves = 7;
+static constexpr uint32_t kB6YMin = 2 * kB6XT + 2;         // half tiles of y ring at least: the frame wave's tile, those the iq wave is ahead, one being written
+static_assert(kZeroLagPairs % 8 == 0 && kHandLag % 8 == 0 && kB6DT <= kB6XT, "whole tiles");
 static constexpr uint32_t kB6TileV4 = 4 * 64;              // v4f per x / f ring tile
 static constexpr uint32_t kB6YMax = 24;
-// counters (LDS words, half tiles): quad 0 = [0] loader, [1] AGC done in place (narrow groups) or pair sums in the x ring (64-stream
-//                       groups), [2] y ring produced, [3] frame consumed;
+// counters (LDS words, half tiles): quad 0 = [0] loader, [1] AGC done in place, [2] y ring produced, [3] frame consumed;
 //                       quad 1 = [4] x ring holds (phase, magnitude), [5] post produced | generation << 24, [6] rewind: tile |
-//                                generation << 24, [7] frame done
-enum { C6_LD = 0, C6_AGC = 1, C6_IQ = 1, C6_Y = 2, C6_CONS = 3, C6_X = 4, C6_P4 = 5, C6_RW = 6, C6_DONE = 7 };
+//                                generation << 24, [7] frame done;  quad 2 = [8] pair sums in the x ring
+enum { C6_LD = 0, C6_AGC = 1, C6_Y = 2, C6_CONS = 3, C6_X = 4, C6_P4 = 5, C6_RW = 6, C6_DONE = 7, C6_IQ = 8 };
 
 struct Blk6Z {
   uint32_t y_slots;              // half tiles in the y ring
@@ -207,7 +221,7 @@ __device__ inline void b6_post(uint32_t *p, uint32_t v) {
 #endif
 
 template <bool WB, int LW>
-__global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
+__global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
     DemodParams P, DemodState S, float *__restrict__ samples, size_t n_call, size_t pitch, int append,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
     uint32_t *__restrict__ eod_counts, Blk6Z Z) {
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
   v4f *xring = yring + NY * 2 * 64;
   v4f *fring = xring + kB6XT * kB6TileV4;
   v4f *trash = fring + kB6XT * kB6TileV4;                  // where the lanes without a stream write instead (below)
-  v4f *hist = trash + kB6XT * kB6TileV4;                   // [tile % 3][0] (px1, px2, py, pv), [1].x lastPhase: P4's state on entering the tile
+  v4f *hist = trash + kB6TileV4;                           // [tile % XT][0] (px1, px2, py, pv), [1].x lastPhase: P4's state on entering the tile
   v4f *rmail = hist + kB6XT * 2 * 64;                      // P5 -> P4: the state to resume with ([1] = lastPhase, thf)
   v4f *fin = rmail + 2 * 64;                               // final states: [0] I, [1] Q low-pass, [2] correction, [3] post filter, [4].x lastPhase
   v4f *zt = fin + 5 * 64;
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
   constexpr uint32_t W = (uint32_t)LW;
   const uint32_t grp = blockIdx.x, s0 = grp * W;
   // which stream a lane works for: P2 (split) lanes 32.. mirror lanes 0.., P3 lanes l + W * part
-  const uint32_t l = (SPLIT && role == 3u) ? (lane & 31u) : lane;   // (the merged iq + disc wave: its iq half; its disc half maps lanes anew)
+  const uint32_t l = role == 6u ? lane % W : (SPLIT && role == 3u) ? (lane & 31u) : lane;
   const bool mine = l < W;
   const uint32_t stream = mine ? s0 + l : 0xFFFFFFFFu;
   const PipeCtx C = pipe_ctx(P, S, stream);
@@ -258,9 +272,8 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
   // zeros and such lanes write to `trash` instead, so what P4 and P5 read for them is exactly zero for good: their slicer bits
   // are 0, their polyphase registers and correlator count never move, and they never take their wave off its block path
   // (fsk_blk.hip parks them on zero input rows; here a narrow group has up to 56 of them and they must not ring).
-  for (uint32_t i = threadIdx.x; i < 2u * kB6XT * kB6TileV4; i += 384u) xring[i] = (v4f){0.f, 0.f, 0.f, 0.f};
-  const int tdel_x = C.valid ? 0 : (int)(trash - xring);    // (v4f units, added to the WRITE addresses only)
-  const int tdel_f = C.valid ? 0 : (int)(trash - fring);
+  for (uint32_t i = threadIdx.x; i < 2u * kB6XT * kB6TileV4; i += 64u * kB6Waves) xring[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const bool live = C.valid;                                // (a lane's WRITES to the x and f rings go to the tile if live, else to `trash`)
   if (role == 5u) {
     const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
     const FastMem &M = C.M;
@@ -355,11 +368,11 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
                  "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
 #undef B6_BLOAD4
-  } else if (role == 1u || (SPLIT && role == 2u)) {
+  } else if (role == 1u || role == 2u) {
     // ---------------------------------------------------------------------------------------------- AGC, pre-filter
-    // 64-stream groups: one wave does both.  Narrow groups: the AGC wave (a recurrence of ten dependent instructions per sample,
-    // the longest chain left) writes the scaled samples back IN PLACE into the staging tile, the pre-filter wave takes them
-    // from there.  The two halves are front_agc_bp's instruction sequences (fsk_pipe_dev.h).
+    // The AGC wave (a recurrence of ten dependent instructions per sample, the longest chain left) writes the scaled samples
+    // back IN PLACE into the staging tile, the pre-filter wave takes them from there.  The two halves are front_agc_bp's
+    // instruction sequences (fsk_pipe_dev.h).
     FrontLane F;
     FrontK K;
     front_load<UNI, 0>(F, K, P, S, C);
@@ -415,7 +428,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
       b6_post(&ctr[do_bp ? C6_Y : C6_AGC], hidx + 2u);       // (the pre-filter's post also frees this tile of the staging ring)
       produced = lds_peek4_get(cv, do_agc ? C6_LD : C6_AGC); consumed = lds_peek4_get(cv, C6_CONS);
     }
-    FSK_STAMP_END(do_agc ? 1 : 6)
+    FSK_STAMP_END(do_agc ? 1 : 2)
     {
       const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
       const FastMem &M = C.M;
@@ -424,11 +437,10 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
       if (do_bp) { PIPE_RSTORE(bp_x1, F.bx1); PIPE_RSTORE(bp_x2, F.bx2); PIPE_RSTORE(bp_y1, F.by1); PIPE_RSTORE(bp_y2, F.by2); }
     }
     };
-    if (!SPLIT) front_stage(std::true_type(), std::true_type());
-    else if (role == 1u) front_stage(std::true_type(), std::false_type());
+    if (role == 1u) front_stage(std::true_type(), std::false_type());
     else front_stage(std::false_type(), std::true_type());
-  } else if (!SPLIT && role == 2u) {
-    // ---------------------------------------------------------------------------------------------- mixer, I/Q low-pass, pair sums (64-stream groups)
+  } else if (role == 3u) {
+    // ---------------------------------------------------------------------------------------------- mixer, I/Q low-pass, pair sums
     const bool upper = SPLIT && lane >= 32u;
     LpLane LI, LQ;                                           // SPLIT: LI is this lane's only chain (I in lanes 0..31, Q in 32..63)
     {
@@ -447,15 +459,15 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
     FSK_STAMP_BEGIN
     for (uint32_t t = 0; t < nt; t++) {
       const uint32_t hidx = 2u * t;
-      if (produced < hidx + 2u || hidx + 2u - consumed > kBlkSlots) {
+      if (produced < hidx + 2u || hidx + 2u - consumed > 2u * kB6XT) {
         FSK_STAMP_W0
         while (produced < hidx + 2u) {
           produced = lds_peek(&ctr[C6_Y]);
-          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
+          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
         }
-        while (hidx + 2u - consumed > kBlkSlots) {           // x ring full: wait for the frame wave
+        while (hidx + 2u - consumed > 2u * kB6XT) {          // x ring full: wait for the frame wave
           consumed = lds_peek(&ctr[C6_CONS]);
-          if (hidx + 2u - consumed > kBlkSlots) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
+          if (hidx + 2u - consumed > 2u * kB6XT) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
         }
         FSK_STAMP_W1
       }
@@ -507,7 +519,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
       } else {
         quad(0, false); quad(1, false); quad(2, false); quad(3, false);
       }
-      v4f *xw = xt + tdel_x;
+      v4f *xw = live ? xt : trash;
       xw[xoff + l] = (v4f){si[0], si[1], si[2], si[3]};
       xw[xoff + 64u + l] = (v4f){si[4], si[5], si[6], si[7]};
       if (!SPLIT) {
@@ -517,11 +529,11 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
       b6_post(&ctr[C6_IQ], hidx + 2u);
       produced = lds_peek4_get(cv, C6_Y); consumed = lds_peek4_get(cv, C6_CONS);
     }
-    FSK_STAMP_END(2)
+    FSK_STAMP_END(3)
     if (SPLIT) fin[(upper ? 64u : 0u) + l] = (v4f){LI.x1, LI.x2, LI.y, LI.v};
     else { fin[l] = (v4f){LI.x1, LI.x2, LI.y, LI.v}; fin[64u + l] = (v4f){LQ.x1, LQ.x2, LQ.y, LQ.v}; }
     b6_post(&ctr[C6_IQ], nh + 1u);
-  } else if (!SPLIT && role == 3u) {
+  } else if (role == 6u) {
     // ---------------------------------------------------------------------------------------------- ZIR correction + discriminator
     const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
     const FastMem &M = C.M;
@@ -536,20 +548,26 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
     uint32_t sgn = 0x80000000u;
     asm volatile("" : "+v"(c1), "+v"(c2), "+v"(tiny), "+v"(rel), "+v"(sgn));
     uint64_t qlive = __builtin_amdgcn_ballot_w64(first & ((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f)));
-    uint32_t produced = 0, xt_i = 0;
+    uint32_t produced = 0, consumed = 0, xt_i = 0;
+    uint32_t *ctr2 = ctr + 8;
     FSK_STAMP_BEGIN
     for (uint32_t t = 0; t < nt; t++) {
       const uint32_t hidx = 2u * t;
-      if (produced < hidx + 2u) {
+      if (produced < hidx + 2u || hidx + 2u - consumed > 2u * kB6DT) {
         FSK_STAMP_W0
         while (produced < hidx + 2u) {
           produced = lds_peek(&ctr[C6_IQ]);
           if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
         }
+        while (hidx + 2u - consumed > 2u * kB6DT) {          // a correction posted now is due kHandLag ahead: no further than that
+          consumed = lds_peek(&ctr[C6_CONS]);
+          if (hidx + 2u - consumed > 2u * kB6DT) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+        }
         FSK_STAMP_W1
       }
-      v4u32 cv;
-      lds_peek4_begin(ctr, cv);
+      v4u32 cv, cv0;
+      lds_peek4_begin(ctr2, cv);
+      lds_peek4_begin(ctr, cv0);
       v4f *xt = xring + xt_i * kB6TileV4;
       xt_i = xt_i + 1u == kB6XT ? 0u : xt_i + 1u;
       const uint32_t kq = cmail[l];
@@ -587,7 +605,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
             const bool own = ow + (uint32_t)j < kHandPairs;   // the frame wave evaluates these itself and needs the pair sums
             ph[j] = own ? ui[j] : ph[j]; am[j] = own ? uq[j] : am[j];
           }
-          v4f *xw = xt + tdel_x;
+          v4f *xw = live ? xt : trash;
           xw[l] = (v4f){ph[0], ph[1], ph[2], ph[3]}; xw[64u + l] = (v4f){ph[4], ph[5], ph[6], ph[7]};
           xw[128u + l] = (v4f){am[0], am[1], am[2], am[3]}; xw[192u + l] = (v4f){am[4], am[5], am[6], am[7]};
         }
@@ -615,9 +633,9 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
         }
 #pragma unroll
         for (int j = 0; j < SP; j++) ph[j] = atan2_amp_fma(uq[j], ui[j], am[j], tiny, sgn);
-        float *xfw = xf + 4 * tdel_x;
+        float *xfw = live ? xf : reinterpret_cast<float *>(trash);
         if (SP == 8) {
-          v4f *xw = xt + tdel_x;
+          v4f *xw = live ? xt : trash;
           xw[l] = (v4f){ph[0], ph[1 % SP], ph[2 % SP], ph[3 % SP]}; xw[64u + l] = (v4f){ph[4 % SP], ph[5 % SP], ph[6 % SP], ph[7 % SP]};
           xw[128u + l] = (v4f){am[0], am[1 % SP], am[2 % SP], am[3 % SP]}; xw[192u + l] = (v4f){am[4 % SP], am[5 % SP], am[6 % SP], am[7 % SP]};
         } else if (SP == 4) {
@@ -631,184 +649,10 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
         }
       }
       b6_post(&ctr[C6_X], hidx + 2u);
-      produced = lds_peek4_get(cv, C6_IQ);
+      produced = lds_peek4_get(cv, C6_IQ - 8); consumed = lds_peek4_get(cv0, C6_CONS);
     }
-    FSK_STAMP_END(3)
+    FSK_STAMP_END(6)
     if (first) fin[128u + l] = (v4f){Qz.ai, Qz.aq, Qz.bi, Qz.bq};
-    b6_post(&ctr[C6_X], nh + 1u);
-  } else if (SPLIT && role == 3u) {
-    // ---------------------------------------------------------------------------------------------- narrow groups: mixer + I/Q low-pass + pair sums, THEN correction + discriminator, one wave
-    // (Four stages on the x ring -- iq, disc, post, frame -- cannot all hold a tile: the frame wave's reset feedback allows the
-    // wave that owns the low-pass only 24 decimated samples = three tiles of lead (kZeroLagPairs), so the ring turned once per
-    // SUM of the four stage times / 3.  In a narrow group both of these stages run on half the lanes or less, and one wave does
-    // them back to back: I chain in lanes 0..31, Q chain in lanes 32..63, pair sums through the x ring tile -- LDS answers a wave
-    // in order, no counter -- then 64 / W lanes per stream for the stateless discriminator.)
-    const bool upper = lane >= 32u;
-    LpLane LI;
-    {
-      const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
-      const uint32_t fld = C.fld, row4 = C.row4;
-      const float ix1 = PIPE_RLOAD(li_x1), ix2 = PIPE_RLOAD(li_x2), iy = PIPE_RLOAD(li_y1), iv = PIPE_RLOAD(li_y2);
-      const float qx1 = PIPE_RLOAD(lq_x1), qx2 = PIPE_RLOAD(lq_x2), qy = PIPE_RLOAD(lq_y1), qv = PIPE_RLOAD(lq_y2);
-      LI.x1 = upper ? qx1 : ix1; LI.x2 = upper ? qx2 : ix2; LI.y = upper ? qy : iy; LI.v = upper ? qv : iv;
-    }
-    float lp_a2 = P.f_lp_a2, lp_nd = -P.f_lp_delta;
-    asm volatile("" : "+v"(lp_a2), "+v"(lp_nd));
-    const uint32_t zoff = upper ? 4u : 0u;                   // v4f offset of this lane's phasor row in a zt tile (cos | sin)
-    const uint32_t xoff = upper ? 2u * 64u : 0u;             // ... and of its rows in an x ring tile
-    // the disc half: lane -> (stream l3, part)
-    const uint32_t l3 = lane % W, part = lane / W;
-    const bool first = part == 0u;                           // the lane that carries the stream's correction
-    const PipeCtx C3 = pipe_ctx(P, S, s0 + l3);
-    const int tdel_x3 = C3.valid ? 0 : (int)(trash - xring);
-    QLane Qz = {0.f, 0.f, 0.f, 0.f};
-    {
-      const __amdgpu_buffer_rsrc_t rs_rsrc = C3.rs_rsrc;
-      const FastMem &M = C3.M;
-      const uint32_t fld = C3.fld, row4 = C3.row4;
-      if (first && PIPE_ILOAD(zr_dph) >= kHandPairs) {      // this wave's from the first sample on
-        Qz.ai = PIPE_RLOAD(zq_ai); Qz.aq = PIPE_RLOAD(zq_aq); Qz.bi = PIPE_RLOAD(zq_bi); Qz.bq = PIPE_RLOAD(zq_bq);
-      }
-    }
-    float c1 = P.z_c1, c2 = P.z_c2, tiny = 0x1p-123f, rel = 3.7252902984619141e-09f;
-    uint32_t sgn = 0x80000000u;
-    asm volatile("" : "+v"(c1), "+v"(c2), "+v"(tiny), "+v"(rel), "+v"(sgn));
-    uint64_t qlive = __builtin_amdgcn_ballot_w64(first & ((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f)));
-    uint32_t consumed = 0, produced = 0, yslot_i = 0, xt_i = 0;
-    FSK_STAMP_BEGIN
-    for (uint32_t t = 0; t < nt; t++) {
-      const uint32_t hidx = 2u * t;
-      if (produced < hidx + 2u || hidx + 2u - consumed > kBlkSlots) {
-        FSK_STAMP_W0
-        while (produced < hidx + 2u) {
-          produced = lds_peek(&ctr[C6_Y]);
-          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
-        }
-        while (hidx + 2u - consumed > kBlkSlots) {           // x ring full: wait for the frame wave
-          consumed = lds_peek(&ctr[C6_CONS]);
-          if (hidx + 2u - consumed > kBlkSlots) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
-        }
-        FSK_STAMP_W1
-      }
-      v4u32 cv;
-      lds_peek4_begin(ctr, cv);
-      const v4f *ztile = zt + (t & ZTM) * 8u;
-      const uint32_t zj = zmail[l];
-      const uint32_t kq = cmail[l3];
-      const uint32_t ow = 4u * hidx - cmail[320u + l3];      // decimated samples since the frame wave's own span began
-      v4f y4[4], zz[4];
-      {
-        const v4f *ys0 = yring + yslot_i * 2u * 64u;
-        yslot_i = yslot_i + 1u == NY ? 0u : yslot_i + 1u;
-        const v4f *ys1 = yring + yslot_i * 2u * 64u;
-        yslot_i = yslot_i + 1u == NY ? 0u : yslot_i + 1u;
-        y4[0] = ys0[l]; y4[1] = ys0[64u + l]; y4[2] = ys1[l]; y4[3] = ys1[64u + l];
-#pragma unroll
-        for (int i = 0; i < 4; i++) zz[i] = ztile[zoff + (uint32_t)i];
-      }
-      v4f *xt = xring + xt_i * kB6TileV4;
-      xt_i = xt_i + 1u == kB6XT ? 0u : xt_i + 1u;
-      // ---- iq half
-      float si[8];
-      auto quad = [&](const uint32_t c, const bool zeroing) {
-        const float y[4] = {y4[c].x, y4[c].y, y4[c].z, y4[c].w};
-        const float za[4] = {zz[c].x, zz[c].y, zz[c].z, zz[c].w};
-        const uint32_t pb = 8u * t + 2u * c;
-        float oi[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (zeroing && !(j & 1)) {
-            if (zj == pb + (uint32_t)(j >> 1)) LI.x1 = LI.x2 = LI.y = LI.v = 0.f;
-          }
-          oi[j] = lp_step(LI, lp_a2, lp_nd, y[j], za[j]);
-        }
-        si[2 * c] = oi[0] + oi[1]; si[2 * c + 1] = oi[2] + oi[3];
-      };
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(zj - 8u * t < 8u) != 0ull, 0)) {
-        asm volatile("s_nop 0");
-        quad(0, true); quad(1, true); quad(2, true); quad(3, true);
-      } else {
-        quad(0, false); quad(1, false); quad(2, false); quad(3, false);
-      }
-      {
-        v4f *xw = xt + tdel_x;
-        xw[xoff + l] = (v4f){si[0], si[1], si[2], si[3]};
-        xw[xoff + 64u + l] = (v4f){si[4], si[5], si[6], si[7]};
-      }
-      asm volatile("" ::: "memory");                          // (the pair sums are in LDS before anything below reads them: same wave, in order)
-      // ---- disc half
-      if (__builtin_expect((__builtin_amdgcn_ballot_w64((kq - 4u * hidx < 8u) | (ow < kHandPairs)) | qlive) != 0ull, 0)) {
-        // a hand-over due in this tile, a lane inside the frame wave's own span, a live correction: the stream's first lane
-        // takes the whole tile, in order (fsk_blk.hip's discriminator wave, op for op)
-        if (first) {
-          const v4f ua = xt[l3], ub = xt[64u + l3], uc = xt[128u + l3], ud = xt[192u + l3];
-          const float ui[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w}, uq[8] = {uc.x, uc.y, uc.z, uc.w, ud.x, ud.y, ud.z, ud.w};
-          float ph[8], am[8];
-          QLane H = {0.f, 0.f, 0.f, 0.f};
-          if (kq - 4u * hidx < 8u) {
-            H.ai = __builtin_bit_cast(float, cmail[64u + l3]); H.aq = __builtin_bit_cast(float, cmail[128u + l3]);
-            H.bi = __builtin_bit_cast(float, cmail[192u + l3]); H.bq = __builtin_bit_cast(float, cmail[256u + l3]);
-            const uint32_t steps = kq > kHandLag ? kHandLag : 0u;   // (posted inside this launch: kHandLag steps before its sample)
-            for (uint32_t g = 0; g < steps; g++) {
-              const float ni = __builtin_fmaf(c1, H.bi, -(c2 * H.ai)), nq = __builtin_fmaf(c1, H.bq, -(c2 * H.aq));
-              H.ai = H.bi; H.aq = H.bq; H.bi = ni; H.bq = nq;
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 8; j++) {
-            if (kq == 4u * hidx + (uint32_t)j) Qz = H;        // the frame wave's correction becomes this wave's here
-            const float wi = ui[j] - Qz.ai, wq = uq[j] - Qz.aq;
-            {
-              const float ni = __builtin_fmaf(c1, Qz.bi, -(c2 * Qz.ai)), nq = __builtin_fmaf(c1, Qz.bq, -(c2 * Qz.aq));
-              Qz.ai = Qz.bi; Qz.aq = Qz.bq; Qz.bi = ni; Qz.bq = nq;
-            }
-            ph[j] = atan2_amp_fma(wq, wi, am[j], tiny, sgn);
-            const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(Qz.ai), __builtin_fabsf(Qz.aq)),
-                                              __builtin_fmaxf(__builtin_fabsf(Qz.bi), __builtin_fabsf(Qz.bq)));
-            if (!(big > am[j] * rel)) { Qz.ai = 0.f; Qz.aq = 0.f; Qz.bi = 0.f; Qz.bq = 0.f; }
-            const bool own = ow + (uint32_t)j < kHandPairs;   // the frame wave evaluates these itself and needs the pair sums
-            ph[j] = own ? ui[j] : ph[j]; am[j] = own ? uq[j] : am[j];
-          }
-          v4f *xw = xt + tdel_x3;
-          xw[l3] = (v4f){ph[0], ph[1], ph[2], ph[3]}; xw[64u + l3] = (v4f){ph[4], ph[5], ph[6], ph[7]};
-          xw[128u + l3] = (v4f){am[0], am[1], am[2], am[3]}; xw[192u + l3] = (v4f){am[4], am[5], am[6], am[7]};
-        }
-        qlive = __builtin_amdgcn_ballot_w64(first & ((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f)));
-      } else {
-        // the plain discriminator is stateless: SP decimated samples per lane, PARTS lanes per stream
-        float *xf = reinterpret_cast<float *>(xt);
-        const uint32_t fi = ((part * (uint32_t)SP) >> 2) * 256u + l3 * 4u + ((part * (uint32_t)SP) & 3u);   // float index of this lane's first I value
-        float ui[SP], uq[SP], ph[SP], am[SP];
-        if (SP == 4) {
-          const v4f ua = *reinterpret_cast<const v4f *>(xf + fi), uc = *reinterpret_cast<const v4f *>(xf + fi + 512u);
-          const float ti[4] = {ua.x, ua.y, ua.z, ua.w}, tq[4] = {uc.x, uc.y, uc.z, uc.w};
-#pragma unroll
-          for (int j = 0; j < SP; j++) { ui[j] = ti[j & 3]; uq[j] = tq[j & 3]; }
-        } else if (SP == 2) {
-          const f2 ua = *reinterpret_cast<const f2 *>(xf + fi), uc = *reinterpret_cast<const f2 *>(xf + fi + 512u);
-          ui[0] = ua.x; ui[SP - 1] = ua.y; uq[0] = uc.x; uq[SP - 1] = uc.y;
-        } else {
-          ui[0] = xf[fi]; uq[0] = xf[fi + 512u];
-        }
-#pragma unroll
-        for (int j = 0; j < SP; j++) ph[j] = atan2_amp_fma(uq[j], ui[j], am[j], tiny, sgn);
-        float *xfw = xf + 4 * tdel_x3;
-        if (SP == 4) {
-          *reinterpret_cast<v4f *>(xfw + fi) = (v4f){ph[0], ph[1 % SP], ph[2 % SP], ph[3 % SP]};
-          *reinterpret_cast<v4f *>(xfw + fi + 512u) = (v4f){am[0], am[1 % SP], am[2 % SP], am[3 % SP]};
-        } else if (SP == 2) {
-          *reinterpret_cast<f2 *>(xfw + fi) = (f2){ph[0], ph[SP - 1]};
-          *reinterpret_cast<f2 *>(xfw + fi + 512u) = (f2){am[0], am[SP - 1]};
-        } else {
-          xfw[fi] = ph[0]; xfw[fi + 512u] = am[0];
-        }
-      }
-      b6_post(&ctr[C6_X], hidx + 2u);
-      produced = lds_peek4_get(cv, C6_Y); consumed = lds_peek4_get(cv, C6_CONS);
-    }
-    FSK_STAMP_END(3)
-    fin[(upper ? 64u : 0u) + l] = (v4f){LI.x1, LI.x2, LI.y, LI.v};
-    if (first) fin[128u + l3] = (v4f){Qz.ai, Qz.aq, Qz.bi, Qz.bq};
     b6_post(&ctr[C6_X], nh + 1u);
   } else if (role == 4u) {
     // ---------------------------------------------------------------------------------------------- discriminator tail, post filter, slicer -- ahead of the frame logic
@@ -825,7 +669,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
     auto tile = [&](const v4f (&cur)[4], v4f (&nxt)[4]) -> bool {
       v4u32 cv;
       lds_peek4_begin(ctr1, cv);
-      v4f *ft = fring + xt_i * kB6TileV4 + tdel_f;
+      v4f *ft = live ? fring + xt_i * kB6TileV4 : trash;
       v4f *ht = hist + xt_i * 2u * 64u;
       xt_i = xt_i + 1u == kB6XT ? 0u : xt_i + 1u;
       {
@@ -1204,7 +1048,7 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
     }
     // the other waves' final states
     while (lds_peek(&ctr[C6_X]) <= nh) __builtin_amdgcn_s_sleep(1);
-    if (!SPLIT) { while (lds_peek(&ctr[C6_IQ]) <= nh) __builtin_amdgcn_s_sleep(1); }
+    while (lds_peek(&ctr[C6_IQ]) <= nh) __builtin_amdgcn_s_sleep(1);
     if (!own_post) {
       // (P4 has run the last tile in this generation -- this wave consumed it -- and leaves its state behind it)
       for (;;) {
@@ -1251,18 +1095,18 @@ __global__ __launch_bounds__(384, 1) void demod_blk6_kernel(
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 size_t demod_blk6_lds_bytes(const DemodParams &P, uint32_t y_slots) {
-  return sizeof(float4) * (kB6Stage * 4 * kSlotStride + y_slots * 2 * 64 + 3 * kB6XT * kB6TileV4 + kB6XT * 2 * 64 + 2 * 64 + 5 * 64 +
+  return sizeof(float4) * (kB6Stage * 4 * kSlotStride + y_slots * 2 * 64 + (2 * kB6XT + 1) * kB6TileV4 + kB6XT * 2 * 64 + 2 * 64 + 5 * 64 +
                            blk6_zt_tiles(y_slots) * 8) +
          sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 16u + 64u + 6u * 64u);
 }
 // the y ring as deep as the LDS of a compute unit this workgroup has to itself allows
 uint32_t demod_blk6_y_slots(const DemodParams &P) {
   uint32_t y = kB6YMax;
-  while (y > kBlkSlots && demod_blk6_lds_bytes(P, y) > 150u * 1024u) y -= 2u;
+  while (y > kB6YMin && demod_blk6_lds_bytes(P, y) > 150u * 1024u) y -= 2u;
   return y;
 }
 bool demod_blk6_applicable(const DemodParams &P) {
-  return P.d >= 8u && (P.d & 3u) == 0u && !P.wide && !P.frac && P.uni_cfg != 0u && demod_blk6_lds_bytes(P, kBlkSlots) <= 150u * 1024u;
+  return P.d >= 8u && (P.d & 3u) == 0u && !P.wide && !P.frac && P.uni_cfg != 0u && demod_blk6_lds_bytes(P, kB6YMin) <= 150u * 1024u;
 }
 // half-tile counters carry a generation in their top byte
 size_t demod_blk6_max_samples() { return ((size_t)1 << 23) * 16u - 16u; }
@@ -1280,15 +1124,14 @@ hipError_t set_blk6_lds_limit(const DemodParams &P) {
   return e;
 }
 
-// default part of each wave: waves w and w + 4 of a workgroup share a SIMD (its six waves go round the CU's four): the two
-// heaviest instruction streams -- frame logic, AGC + pre-filter -- get a SIMD each, loader + post and iq + disc share
-// 64-stream groups (parts 0 loader, 1 AGC + pre-filter, 2 iq, 3 disc, 4 post, 5 frame): frame and AGC + pre-filter get a SIMD each,
-// loader + post and iq + disc share.  Narrow groups (0 loader, 1 AGC, 2 pre-filter, 3 iq + disc, 4 post, 5 frame): frame and
-// iq + disc alone, loader + post and AGC + pre-filter share.
+// default part of each wave (parts: 0 loader, 1 AGC, 2 pre-filter, 3 iq, 4 post, 5 frame, 6 disc).  Waves w and w + 4 of a
+// workgroup share a SIMD (its seven waves go round the CU's four): the frame logic -- the longest instruction stream and the one
+// every rare path runs on -- has a SIMD to itself, loader + post, AGC + pre-filter and iq + disc share.
 uint32_t demod_blk6_default_rolemap(uint32_t lanes) {
-  const uint32_t wide[6] = {0u, 2u, 5u, 1u, 4u, 3u}, narrow[6] = {0u, 1u, 5u, 3u, 4u, 2u};
+  (void)lanes;
+  const uint32_t part[kB6Waves] = {0u, 1u, 3u, 5u, 6u, 2u, 4u};
   uint32_t m = 0;
-  for (uint32_t w = 0; w < 6; w++) m |= (lanes == 64u ? wide[w] : narrow[w]) << (3u * w);
+  for (uint32_t w = 0; w < kB6Waves; w++) m |= part[w] << (3u * w);
   return m;
 }
 
@@ -1298,12 +1141,12 @@ hipError_t launch_demod_blk6(bool writeback, bool append, const DemodParams &P, 
   lanes = (lanes == 8u || lanes == 16u || lanes == 32u) ? lanes : 64u;
   const uint32_t blocks = (P.n_streams + lanes - 1u) / lanes;
   const uint32_t ymax = demod_blk6_y_slots(P);
-  y_slots = y_slots < kBlkSlots ? kBlkSlots : y_slots > ymax ? ymax : y_slots;
+  y_slots = y_slots < kB6YMin ? kB6YMin : y_slots > ymax ? ymax : y_slots;
   y_slots &= ~1u;
   const size_t lds = demod_blk6_lds_bytes(P, y_slots);
   Blk6Z Z = {y_slots, blk6_zt_tiles(y_slots), rolemap ? rolemap : demod_blk6_default_rolemap(lanes)};
 #define FSK_LAUNCH_B6(WBV, LWV)                                                                                      \
-  hipLaunchKernelGGL((demod_blk6_kernel<WBV, LWV>), dim3(blocks), dim3(384), lds, stream, P, S, samples, n, pitch, \
+  hipLaunchKernelGGL((demod_blk6_kernel<WBV, LWV>), dim3(blocks), dim3(64 * kB6Waves), lds, stream, P, S, samples, n, pitch, \
                      append ? 1 : 0, out, out_pitch, out_counts, eod_counts, Z)
   if (writeback) {
     if (lanes == 64u) FSK_LAUNCH_B6(true, 64); else if (lanes == 32u) FSK_LAUNCH_B6(true, 32);

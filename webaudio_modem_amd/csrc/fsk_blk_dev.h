@@ -1,5 +1,5 @@
 // fsk_blk_dev.h -- device code shared by the block-batched whole-tile kernels: the four-wave kernels of fsk_blk.hip and the
-// six-wave small-batch kernel of fsk_blk6.hip.  Ring geometry, the bit clock of one block (blk_clock), the fast path of one
+// seven-wave small-batch kernel of fsk_blk6.hip.  Ring geometry, the bit clock of one block (blk_clock), the fast path of one
 // block (blk_fast), the byte queue flush, the discriminator wave's correction lane.  See fsk_blk.hip for the design.
 #pragma once
 #include <hip/hip_runtime.h>

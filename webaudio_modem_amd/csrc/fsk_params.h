@@ -188,20 +188,29 @@ struct ProcState {
 };
 
 // fp32 free-running frame (fsk_pipe.hip): the front end zeroes a stream's I/Q low-pass kZeroLagPairs decimated samples
-// after a resetState() -- far enough for the wave that owns the low-pass (at most six half tiles = 24 decimated samples
-// ahead of the back wave in fsk_blk.hip, four in fsk_pipe.hip) to learn of the reset in time -- and a direct instance
-// covers those plus two more.
+// after a resetState() -- far enough for the wave that owns the low-pass to learn of the reset in time, however far it runs
+// ahead of the wave with the frame logic (at most six half tiles = 24 decimated samples in fsk_blk.hip, four half tiles in
+// fsk_pipe.hip, kZeroLagPairs / 8 tiles in fsk_blk6.hip) -- and a direct instance covers those plus two more.
+// Round 5: 24 -> 48.  The small-batch kernel (fsk_blk6.hip) has four stages on the ring this lag bounds; at 24 they shared
+// three tiles and ran in turn rather than side by side.  What it costs the others is the longer span the frame logic works
+// itself after a reset (98 instead of 50 decimated samples): config #3 - 1 %, an idle bank - 2 %, a batch whose streams'
+// frames do not line up (a reset in some lane every few tiles) - 12 % (profiles/r05_lag.txt).  One value for every kernel: the
+// fp32 results after a reset depend on it, and the kernels must stay interchangeable call by call.
 #ifndef FSK_ZLAG
-#define FSK_ZLAG 24
+#define FSK_ZLAG 48
 #endif
 static constexpr uint32_t kZeroLagPairs = FSK_ZLAG;
 static constexpr uint32_t kDirectPairs = kZeroLagPairs + 2;
 // The zero-input response left by a reset is carried un-retired for another kHandLag decimated samples (zr_dph counts on
-// to kHandPairs).  That fixed span is what lets the four-wave kernel (fsk_blk.hip) move the correction from its back wave
-// to the discriminator wave running up to 23 decimated samples AHEAD of the tile the back wave is in: the values at the
-// hand-over sample follow from the two start values by the recurrence alone, so the back wave can post them 24 samples
-// early -- and the discriminator wave, whatever its lead, has not reached the hand-over sample when they are posted.
-static constexpr uint32_t kHandLag = 24;
+// to kHandPairs).  That fixed span is what lets the multi-wave kernels move the correction from the wave with the frame logic
+// to the discriminator wave running up to kHandLag - 1 decimated samples AHEAD of it (23 in fsk_blk.hip, kHandLag / 8 tiles
+// in fsk_blk6.hip): the values at the hand-over sample follow from the two start values by the recurrence alone, so they can
+// be posted kHandLag samples early -- and the discriminator wave, whatever its lead, has not reached the hand-over sample
+// when they are posted.
+#ifndef FSK_HLAG
+#define FSK_HLAG 48
+#endif
+static constexpr uint32_t kHandLag = FSK_HLAG;
 static constexpr uint32_t kHandPairs = kDirectPairs + kHandLag;
 static constexpr uint32_t kBigWait = 0x40000000u;  // bit_wait while !started (12 h of decimated samples)
 #ifndef FSK_TILE
