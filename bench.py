@@ -102,6 +102,9 @@ def build_parser():
                     help="also launch the read-pattern probe kernel this many times (FETCH_SIZE calibration)")
     ap.add_argument("--pitch-pad", type=int, default=0, help="extra floats of row pitch (experiments)")
     ap.add_argument("--snr-db", type=float, default=None, help="add AWGN at this SNR (overrides the workload's)")
+    ap.add_argument("--lead-max", type=int, default=None,
+                    help="every stream's first frame starts at a random offset below this many samples (default: ten bit cells, so "
+                         "that the streams' frames -- and their resets -- nearly line up; a frame length = streams that do not)")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="skip the shader-clock probe and its extra steps (profiler passes: their kernel statistics then hold the timed launches only)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -526,7 +529,7 @@ def worker(args):
                 x[:, c0:n0] *= (cols[None, :] < d_end[:, None])
             eng.add_awgn_device(x.data_ptr(), N, pitch, wl["idle_db"] - 10.0 * math.log10(N / float(frame_len)), seed ^ 0xA36, stream)
         else:
-            eng.synth_device(x.data_ptr(), N, pitch, wl["payload"], seed, 10 * spb, 0.1, 1.0, stream)
+            eng.synth_device(x.data_ptr(), N, pitch, wl["payload"], seed, args.lead_max if args.lead_max is not None else 10 * spb, 0.1, 1.0, stream)
             if snr is not None:
                 eng.add_awgn_device(x.data_ptr(), N, pitch, snr, seed ^ 0xA36, stream)
         torch.cuda.synchronize()
@@ -847,6 +850,7 @@ def worker(args):
                                 wl["num"], total_streams if strong_only else S,
                                 " in total" if strong_only else "/GPU", N, N / sr, wl["desc"], wl["payload"],
                                 "" if wl.get("roundtrip") else ", random lead-in and amplitude"),
+                "lead_max_samples": args.lead_max if args.lead_max is not None else 10 * spb,
                 "streams_per_gpu": S, "total_streams": total_streams if strong_only else streams_all,
                 "ranks_reported": ranks_reported, "samples_per_stream": N, "row_pitch_floats": pitch,
                 "resident_input_GB_per_gpu": round(S * pitch * 4 / 1e9, 2),

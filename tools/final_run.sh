@@ -19,6 +19,9 @@ timeout 600 python bench.py --streams 2048 --no-side > $F/bench_2048.txt 2>&1
 timeout 600 python bench.py --workload c1x --no-side > $F/bench_c1x.txt 2>&1
 timeout 600 python bench.py --precision f64 --steps 2 --warmup 1 --no-side --cpu-seconds 6 > $F/bench_f64.txt 2>&1
 timeout 600 python bench.py --streams 8192 --no-side > $F/bench_8192.txt 2>&1
+timeout 600 python bench.py --streams 4096 --no-side > $F/bench_4096.txt 2>&1
+timeout 600 python bench.py --streams 16384 --no-side > $F/bench_16384.txt 2>&1
+timeout 600 python bench.py --lead-max 40000 --no-side > $F/bench_staggered.txt 2>&1
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$F/stats -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-side --no-clock-probe > $R/$F/stats.log 2>&1

@@ -40,7 +40,7 @@ for name in ("pmc_insts.txt", "pmc_fetch.txt", "pmc_write.txt", "pmc_clock.txt",
     src = os.path.join(F, name)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, "%s_final_%s" % (rnd, name)))
-for name in ("bench", "bench_c2", "bench_c4", "bench_c5", "bench_idle", "bench_idle4", "bench_mod", "bench_mod_f64", "bench_c1x", "bench_f64", "bench_8192", "bench_2048"):
+for name in ("bench", "bench_c2", "bench_c4", "bench_c5", "bench_idle", "bench_idle4", "bench_mod", "bench_mod_f64", "bench_c1x", "bench_f64", "bench_8192", "bench_2048", "bench_4096", "bench_16384", "bench_staggered"):
     src = os.path.join(F, name + ".txt")
     if os.path.exists(src):
         lines = [l for l in open(src) if l.startswith("{")]
