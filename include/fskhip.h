@@ -283,7 +283,7 @@ int fskhip_timing_end(fskhip_engine *e, uint32_t *n_launches, double *total_ms);
  *                    to 64 x compute units streams (every workgroup a compute unit to itself) on calls of at least
  *                    "stage_min_tiles" tiles, four waves (demod_blk_kernel / _r / _rp) otherwise wherever they apply;
  *                    auto-r04: never seven ("six-wave" was this kernel's name before it had seven)
- *   "stage_min_tiles" n             calls with fewer whole tiles stay off the seven-wave kernel (default 64)
+ *   "stage_min_tiles" n             calls with fewer whole tiles stay off the seven-wave kernel (default 8: one 128-sample quantum)
  *   "stage_y_slots"  6 .. 24        depth of the seven-wave kernel's y ring (default: what the LDS of a compute unit allows; at least 2 + the
  *                                   half tiles its iq wave may lead the frame wave by)
  *   "stage_roles"    auto | seven digits, a permutation of 0..6: the part each of a workgroup's seven waves plays (measurements)

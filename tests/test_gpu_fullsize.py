@@ -892,7 +892,7 @@ def test_seven_wave_is_the_default_for_small_uniform_batches():
     import webaudio_modem_amd as wm
     N = 48000
     for S, cfg, n, want in ((2048, BELL, N, "demod_blk6_kernel"), (8192, BELL, N, "demod_blk6_kernel"), (16384, BELL, N, "demod_blk6_kernel"),
-                            (32768, BELL, N, "demod_blk_kernel<"), (2048, BELL, 512, "demod_blk_kernel<"),
+                            (32768, BELL, N, "demod_blk_kernel<"), (2048, BELL, 64, "demod_blk_kernel<"),
                             (2048, [dict(BELL, markFrequency=1200 + s % 7) for s in range(2048)], N, "demod_blk_kernel<")):
         eng = wm.FSKEngine(S, cfg, precision=wm.PRECISION_F32)
         d_x = eng.device_malloc(S * N * 4)

@@ -214,7 +214,7 @@ struct fskhip_engine {
   // compute unit of its own (uniform configurations, calls of at least six_min_tiles tiles): 0 never, 1 wherever it applies
   // ("kernel" = seven-wave), 2 auto
   uint32_t use_six = 2;
-  uint32_t six_min_tiles = 64;   // shorter calls stay on the four-wave kernel: seven stages take longer to fill and drain
+  uint32_t six_min_tiles = 8;    // shorter calls stay on the four-wave kernel (one 128-sample quantum is already 1.13 x faster on seven waves, profiles/r05_lag.txt)
   uint32_t six_y_slots = 0;      // 0 = as deep as the LDS allows
   uint32_t six_rolemap = 0;      // 0 = the default placement of the seven parts on a workgroup's waves
   int cus = 0;
