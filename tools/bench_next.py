@@ -109,6 +109,19 @@ def main():
                           "algorithmic_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000, 4)}))
         f.close()
     del xin, yout
+    # (a lane per stream: 16 384 streams are one wave per compute unit; a full device)
+    Sb = 65536
+    xb = torch.randn((Sb, Nf), dtype=torch.float32, device="cuda")
+    yb = torch.empty_like(xb)
+    for prec, name in ((wm.PRECISION_F64, "f64"), (wm.PRECISION_F32, "f32")):
+        f = wm.IIRFilterBatch(bw["b"], bw["a"], Sb, precision=prec)
+        ms = timed(lambda: f.process_device(xb.data_ptr(), Nf, Nf, yb.data_ptr(), Nf, sh), 10)
+        gbs = 8.0 * Sb * Nf / ms / 1e6
+        print(json.dumps({"row": "f3' IIRFilter.processBuffer, order 2", "dtype": name, "streams": Sb, "samples": Nf,
+                          "ms": round(ms, 3), "Msamples_per_s": round(Sb * Nf / ms / 1e3, 1),
+                          "algorithmic_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000, 4)}))
+        f.close()
+    del xb, yb
 
     # ---- XModem scan / CRC ------------------------------------------------------------------------------
     Sx = args.streams
