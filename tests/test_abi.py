@@ -189,3 +189,17 @@ def test_time_sliced_launches_hand_every_field_on_with_device_scope_policy():
     # the helpers that reach state through other helpers pass it down
     for inner in ("ist_store<COH>", "ist_load<COH>", "back_reset<UNI, COH>"):
         assert inner in dev, inner
+
+
+def test_no_bit_cast_of_a_vector_element_expression():
+    """hipcc 7.2 compiles `__builtin_bit_cast(uint32_t, v.y)` on an ext_vector element EXPRESSION to a read of element 0
+    (fsk_blk6.hip met it twice: decoded bytes wrong, no diagnostic).  The sources copy the elements into floats first; this keeps it so."""
+    import glob
+    import re
+    pat = re.compile(r"__builtin_bit_cast\(\s*(?:uint32_t|int|int32_t|unsigned)\s*,\s*[A-Za-z_][\w\.\[\]]*\.[xyzw]\s*\)")
+    bad = []
+    for f in glob.glob(os.path.join(ROOT, "webaudio_modem_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "tools", "*.hip")):
+        for i, line in enumerate(open(f), 1):
+            if pat.search(line):
+                bad.append("%s:%d: %s" % (os.path.relpath(f, ROOT), i, line.strip()))
+    assert not bad, "\n".join(bad)
