@@ -170,7 +170,7 @@ __device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &
       r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
       thf_j = (float)r;
     }
-    med_sample(Bn, K, j, e0, e1, y0, y1, z, thf_j, h ? rp2.y : rp2.x, kvj, matched_min, matched, thr_cur, ls, w, hard, E, am[j]);
+    med_sample(Bn, K, j, e0, e1, y0, y1, z, thf_j, h ? rp2.y : rp2.x, kvj, matched_min, kOwnPairs4, matched, thr_cur, ls, w, hard, E, am[j]);
     }
   }
   hard |= med_finish(Bn, K, Q, kv0, matched, thr_cur, ls, w, bq, nq, E);
@@ -396,28 +396,28 @@ __device__ __forceinline__ void demod_blk_body(
     zmail[lane] = zmail_init(PIPE_ILOAD(zr_dph));
   }
   if (wave == 3) {
-    // a correction still on its un-retired span when the launch starts: the back wave keeps it until zr_dph reaches
-    // kHandPairs, the discriminator wave takes it from decimated sample kHandPairs - zr_dph on
+    // a correction still on the back wave's part of its un-retired span when the launch starts: the back wave keeps it until
+    // zr_dph reaches kOwnPairs4, the discriminator wave takes it from decimated sample kOwnPairs4 - zr_dph on (fsk_params.h)
     const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
     const FastMem &M = C.M;
     const uint32_t fld = C.fld, row4 = C.row4;
     const uint32_t dph = PIPE_ILOAD(zr_dph);
     uint32_t kq = 0xFFFFFFFFu;
     float ai = 0.f, aq = 0.f, bi = 0.f, bq = 0.f;
-    if (dph >= kDirectPairs && dph < kHandPairs) {            // (the steps that are left run here, once per launch: kq <= kHandLag
+    if (dph >= kDirectPairs && dph < kOwnPairs4) {            // (the steps that are left run here, once per launch: kq <= kOwnLag4
                                                               // tells the taker that the values are final -- see zir_step)
       ai = PIPE_RLOAD(zq_ai); aq = PIPE_RLOAD(zq_aq); bi = PIPE_RLOAD(zq_bi); bq = PIPE_RLOAD(zq_bq);
       const float c1 = P.z_c1, c2 = P.z_c2;
-      for (uint32_t g = dph; g < kHandPairs; g++) {
+      for (uint32_t g = dph; g < kOwnPairs4; g++) {
         const float ni = __builtin_fmaf(c1, bi, -(c2 * ai)), nq = __builtin_fmaf(c1, bq, -(c2 * aq));
         ai = bi; aq = bq; bi = ni; bq = nq;
       }
-      kq = kHandPairs - dph;
+      kq = kOwnPairs4 - dph;
     }
     cmail[64u + lane] = __builtin_bit_cast(uint32_t, ai); cmail[128u + lane] = __builtin_bit_cast(uint32_t, aq);
     cmail[192u + lane] = __builtin_bit_cast(uint32_t, bi); cmail[256u + lane] = __builtin_bit_cast(uint32_t, bq);
     cmail[lane] = kq;
-    cmail[320u + lane] = 0u - dph;                          // (dph >= kHandPairs: the span is over)
+    cmail[320u + lane] = 0u - dph;                          // (the decimated sample of this launch at which the stream was last reset, as a signed number)
   }
   __syncthreads();
 
@@ -639,9 +639,13 @@ __device__ __forceinline__ void demod_blk_body(
     const FastMem &M = C.M;
     const uint32_t fld = C.fld, row4 = C.row4;
     QLane Qz = {0.f, 0.f, 0.f, 0.f};
-    if (PIPE_ILOAD(zr_dph) >= kHandPairs) {                   // this wave's from the first sample on
+    const uint32_t dph_s = PIPE_ILOAD(zr_dph);
+    if (dph_s >= kOwnPairs4) {                                // this wave's from the first sample on
       Qz.ai = PIPE_RLOAD(zq_ai); Qz.aq = PIPE_RLOAD(zq_aq); Qz.bi = PIPE_RLOAD(zq_bi); Qz.bq = PIPE_RLOAD(zq_bq);
     }
+    // the decimated sample of this launch (signed) at which the correction became this wave's: zr_dph was kOwnPairs4 there, and
+    // the correction retires no earlier than kHandLag - kOwnLag4 samples later, where zr_dph reaches kHandPairs (fsk_params.h)
+    int32_t kq_last = (int32_t)kOwnPairs4 - (int32_t)dph_s;
     float c1 = P.z_c1, c2 = P.z_c2, tiny = 0x1p-123f, rel = 3.7252902984619141e-09f;
     uint32_t sgn = 0x80000000u;
     asm volatile("" : "+v"(c1), "+v"(c2), "+v"(tiny), "+v"(rel), "+v"(sgn));
@@ -679,14 +683,14 @@ __device__ __forceinline__ void demod_blk_body(
         float ph[8], am[8];
         // one test for everything that is not the plain discriminator: a hand-over due in this tile, a lane inside the
         // back wave's own span, a live correction
-        if (__builtin_expect((__builtin_amdgcn_ballot_w64((kq - 4u * hidx < 8u) | (ow < kHandPairs)) | qlive) != 0ull, 0)) {
+        if (__builtin_expect((__builtin_amdgcn_ballot_w64((kq - 4u * hidx < 8u) | (ow < kOwnPairs4)) | qlive) != 0ull, 0)) {
           // a hand-over due in this tile: the posted start values, advanced by the posted number of steps of the
           // recurrence (all of the tile's lanes at once)
           QLane H = {0.f, 0.f, 0.f, 0.f};
           if (kq - 4u * hidx < 8u) {
             H.ai = __builtin_bit_cast(float, cmail[64u + lane]); H.aq = __builtin_bit_cast(float, cmail[128u + lane]);
             H.bi = __builtin_bit_cast(float, cmail[192u + lane]); H.bq = __builtin_bit_cast(float, cmail[256u + lane]);
-            const uint32_t steps = kq > kHandLag ? kHandLag : 0u;   // (posted inside this launch: kHandLag steps before its sample)
+            const uint32_t steps = kq > kOwnLag4 ? kOwnLag4 : 0u;   // (posted inside this launch: kOwnLag4 steps before its sample)
             for (uint32_t g = 0; g < steps; g++) {
               const float ni = __builtin_fmaf(c1, H.bi, -(c2 * H.ai)), nq = __builtin_fmaf(c1, H.bq, -(c2 * H.aq));
               H.ai = H.bi; H.aq = H.bq; H.bi = ni; H.bq = nq;
@@ -696,6 +700,7 @@ __device__ __forceinline__ void demod_blk_body(
           for (int j = 0; j < 8; j++) {
             if (kq == 4u * hidx + (uint32_t)j) {              // the back wave's correction becomes this wave's here
               Qz = H;
+              kq_last = (int32_t)kq;
             }
             const float wi = ui[j] - Qz.ai, wq = uq[j] - Qz.aq;
             {
@@ -705,10 +710,11 @@ __device__ __forceinline__ void demod_blk_body(
             ph[j] = atan2_amp_fma(wq, wi, am[j], tiny, sgn);
             const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(Qz.ai), __builtin_fabsf(Qz.aq)),
                                               __builtin_fmaxf(__builtin_fabsf(Qz.bi), __builtin_fabsf(Qz.bq)));
-            if (!(big > am[j] * rel)) { Qz.ai = 0.f; Qz.aq = 0.f; Qz.bi = 0.f; Qz.bq = 0.f; }
+            const bool steady = (int32_t)(4u * hidx + (uint32_t)j) - kq_last >= (int32_t)(kHandLag - kOwnLag4);   // zr_dph >= kHandPairs (zir_step's `steady`)
+            if (steady & !(big > am[j] * rel)) { Qz.ai = 0.f; Qz.aq = 0.f; Qz.bi = 0.f; Qz.bq = 0.f; }
             // lanes inside the back wave's own span (direct instance, then its own correction): it evaluates their
             // discriminator itself and needs the pair sums for that, so they stay
-            const bool own = ow + (uint32_t)j < kHandPairs;
+            const bool own = ow + (uint32_t)j < kOwnPairs4;
             ph[j] = own ? ui[j] : ph[j]; am[j] = own ? uq[j] : am[j];
           }
           qlive = __builtin_amdgcn_ballot_w64((Qz.ai != 0.f) | (Qz.aq != 0.f) | (Qz.bi != 0.f) | (Qz.bq != 0.f));
@@ -739,7 +745,7 @@ __device__ __forceinline__ void demod_blk_body(
     back_load<UNI, COH>(B, Kp, P, S, C, stream, out_counts, eod_counts, append);
     BackK Ks;                                                 // the constants as scalars, for the paths that are not the fast block loop
     back_consts(Ks, P);
-    if (B.dph >= kHandPairs) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }   // the discriminator wave's
+    if (B.dph >= kOwnPairs4) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; B.dph = kOwnPairs4; }   // the discriminator wave's (zr_dph is re-formed at the end)
     BlkK Qs;
     Qs.stop_m1 = (1u << P.stop_pos) - 1u; Qs.sh9 = P.stop_pos - 9u; Qs.ff = 0xFFu;
     BlkK Qp = Qs;
@@ -757,9 +763,10 @@ __device__ __forceinline__ void demod_blk_body(
       }
     }
     BackU X;
+    X.own_pairs = kOwnPairs4; X.hand_lag = kOwnLag4;
     X.k = 0; X.kv = 0; X.free0 = free0; X.zmail = zmail; X.cmail = cmail; X.phase = 0;
     X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) ? kDirectPairs : 0u;
-    X.zlive = __builtin_amdgcn_ballot_w64(B.dph < kHandPairs) ? 1u : 0u;
+    X.zlive = __builtin_amdgcn_ballot_w64(B.dph < kOwnPairs4) ? 1u : 0u;
     asm volatile("" : "+v"(X.kv));
     const uint32_t amp_pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)PIPE_ILOAD(amp_pos));
     const uint32_t amp_quad_bytes = P.n_streams * 16u;
@@ -968,7 +975,7 @@ __device__ __forceinline__ void demod_blk_body(
             if (E.jc != 0u) {                                  // (zir_step: the correction's start values, for the discriminator wave)
               cmail[64u + lane] = __builtin_bit_cast(uint32_t, E.cai); cmail[128u + lane] = __builtin_bit_cast(uint32_t, E.caq);
               cmail[192u + lane] = __builtin_bit_cast(uint32_t, E.cbi); cmail[256u + lane] = __builtin_bit_cast(uint32_t, E.cbq);
-              cmail[lane] = k0 + E.jc + kHandLag;
+              cmail[lane] = k0 + E.jc + kOwnLag4;
             }
             if (E.jr != 0u) {                                  // (back_pair's 'eod' + back_reset)
               const uint32_t kr = k0 + E.jr;
@@ -984,7 +991,7 @@ __device__ __forceinline__ void demod_blk_body(
               B.rho = kr % P.cadence;
             }
           }
-          X.zlive = __builtin_amdgcn_ballot_w64(B.dph < kHandPairs) != 0ull ? 1u : 0u;
+          X.zlive = __builtin_amdgcn_ballot_w64(B.dph < kOwnPairs4) != 0ull ? 1u : 0u;
           X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) != 0ull ? kDirectPairs : 0u;
           lds_post(&ctr[3], t);
           rare_exit = false;
@@ -1060,7 +1067,7 @@ __device__ __forceinline__ void demod_blk_body(
       F.qx1 = fq.x; F.qx2 = fq.y; F.qy = fq.z; F.qv = fq.w;
       F.g = F.bx1 = F.bx2 = F.by1 = F.by2 = 0.f;
     }
-    if (B.dph >= kHandPairs) {                                // the correction as the discriminator wave left it
+    if (B.dph >= kOwnPairs4) {                                // the correction as the discriminator wave left it
       const v4f qz = fin[128u + lane];
       B.qai = qz.x; B.qaq = qz.y; B.qbi = qz.z; B.qbq = qz.w;
       // ... unless the hand-over sample is the FIRST of the next launch (or time slice): this wave has let go of the
@@ -1070,12 +1077,16 @@ __device__ __forceinline__ void demod_blk_body(
       if (cmail[lane] == X.k) {
         B.qai = __builtin_bit_cast(float, cmail[64u + lane]); B.qaq = __builtin_bit_cast(float, cmail[128u + lane]);
         B.qbi = __builtin_bit_cast(float, cmail[192u + lane]); B.qbq = __builtin_bit_cast(float, cmail[256u + lane]);
-        const uint32_t steps = X.k > kHandLag ? kHandLag : 0u;   // (what the discriminator wave would have run on taking them)
+        const uint32_t steps = X.k > kOwnLag4 ? kOwnLag4 : 0u;   // (what the discriminator wave would have run on taking them)
         for (uint32_t g = 0; g < steps; g++) {
           const float ni = __builtin_fmaf(Ks.c1, B.qbi, -(Ks.c2 * B.qai)), nq = __builtin_fmaf(Ks.c1, B.qbq, -(Ks.c2 * B.qaq));
           B.qai = B.qbi; B.qaq = B.qbq; B.qbi = ni; B.qbq = nq;
         }
       }
+      // zr_dph as every kernel understands it: decimated samples since the reset, saturating at kHandPairs (this wave stopped
+      // counting at kOwnPairs4; the mailbox has the sample of this launch the stream was last reset at, as a signed number)
+      const uint32_t since = X.k - cmail[320u + lane];
+      B.dph = since < kHandPairs ? since : kHandPairs;
     }
     {
       uint32_t ph = phase0;

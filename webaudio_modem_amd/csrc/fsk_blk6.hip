@@ -148,7 +148,7 @@ __device__ inline uint32_t blk6_medium(BackLane &Bn, const BackK &K, const BlkK 
 #pragma unroll
   for (int j = 0; j < kBlk; j++) {
     const v4f z = (v4f){cv[2 * j], sv[2 * j], cv[2 * j + 1], sv[2 * j + 1]};
-    med_sample(Bn, K, j, e0v[j], e1v[j], yv[2 * j], yv[2 * j + 1], z, thf8[j], ro[j], kv0 + (uint32_t)(j + 1), matched_min, matched, thr_cur, ls,
+    med_sample(Bn, K, j, e0v[j], e1v[j], yv[2 * j], yv[2 * j + 1], z, thf8[j], ro[j], kv0 + (uint32_t)(j + 1), matched_min, kHandPairs, matched, thr_cur, ls,
                w, hard, E, am[j]);
   }
   hard |= med_finish(Bn, K, Q, kv0, matched, thr_cur, ls, w, bq, nq, E);
@@ -758,6 +758,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
       }
     }
     BackU X;
+    X.own_pairs = kHandPairs; X.hand_lag = kHandLag;          // (this wave keeps the correction for the whole un-retired span)
     X.k = 0; X.kv = 0; X.free0 = free0; X.zmail = zmail; X.cmail = cmail; X.phase = 0;
     X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) ? kDirectPairs : 0u;
     X.zlive = __builtin_amdgcn_ballot_w64(B.dph < kHandPairs) ? 1u : 0u;

@@ -17,7 +17,7 @@ namespace fsk {
 static constexpr uint32_t kBlkSlots = FSK_BLK_SLOTS;   // half tiles in the rings
 static_assert((kBlkSlots & 1u) == 0u, "blocks are two half tiles on an even slot");
 static_assert(4u * kBlkSlots <= kZeroLagPairs, "the wave that owns the I/Q low-pass must learn of a reset before it has passed the zeroing point");
-static_assert(4u * kBlkSlots <= kHandLag, "the discriminator wave (up to 4 * kBlkSlots - 1 samples beyond the start of the back wave's tile) must not have reached the hand-over sample when it is posted");
+static_assert(4u * kBlkSlots <= kOwnLag4, "the discriminator wave (up to 4 * kBlkSlots - 1 samples beyond the start of the back wave's tile) must not have reached the hand-over sample when it is posted");
 static constexpr uint32_t kBlkSlotV4 = 2 * 64;     // v4f per x-ring slot: four pair sums (I, Q) -- in place -> four (phase, magnitude)
 static constexpr uint32_t kFlushBlocks = 16;       // byte queues are flushed every this many blocks
 // The y ring (wave 0 -> wave 1) may be deeper than the x ring.  With six slots everywhere the four waves hold exactly
@@ -165,7 +165,7 @@ __device__ inline uint32_t eq_mask(uint32_t v, uint32_t c) { return neg_mask((v 
 // outputs, z = (c0, s0, c1, s1) their NCO phasors, thf_j lastPhase after a reset at this sample, rold the sample's polyphase
 // register.  ONE function for both kernels: the same instruction sequence per decimated sample whichever runs it.
 __device__ __forceinline__ void med_sample(BackLane &Bn, const BackK &K, const int j, const float e0, const float e1, const float y0, const float y1,
-                                           const v4f z, const float thf_j, const uint32_t rold, const uint32_t kvj, const uint32_t matched_min,
+                                           const v4f z, const float thf_j, const uint32_t rold, const uint32_t kvj, const uint32_t matched_min, const uint32_t own_pairs,
                                            uint32_t &matched, uint32_t &thr_cur, uint32_t &ls, uint32_t &w, uint32_t &hard, MedEv &E, float &am_j) {
     // ---- zir_step<UNI, HAND = true>, flat
     const uint32_t dph0 = Bn.dph;
@@ -213,10 +213,10 @@ __device__ __forceinline__ void med_sample(BackLane &Bn, const BackK &K, const i
       // branch that posts them, behind sixteen scratch round trips)
       asm volatile("" : "+v"(E.cai), "+v"(E.caq), "+v"(E.cbi), "+v"(E.cbq), "+v"(E.jc));
     }
-    const uint32_t m_own = neg_mask(dph0 - kHandPairs);                      // the span is this wave's
-    Bn.dph = dph0 - m_own;                                                   // + 1, saturating at kHandPairs
+    const uint32_t m_own = neg_mask(dph0 - own_pairs);                       // the span is this wave's (own_pairs: kHandPairs, or kOwnPairs4 in fsk_blk.hip)
+    Bn.dph = dph0 - m_own;                                                   // + 1, saturating at own_pairs
     {
-      const uint32_t keep = ~eq_mask(dph0, kHandPairs - 1u);                 // handed over: the discriminator wave's from here on
+      const uint32_t keep = ~eq_mask(dph0, own_pairs - 1u);                 // handed over: the discriminator wave's from here on
       Bn.qai = bzero(keep, Bn.qai); Bn.qaq = bzero(keep, Bn.qaq); Bn.qbi = bzero(keep, Bn.qbi); Bn.qbq = bzero(keep, Bn.qbq);
     }
     float a2;

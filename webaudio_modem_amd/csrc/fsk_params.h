@@ -212,6 +212,14 @@ static constexpr uint32_t kDirectPairs = kZeroLagPairs + 2;
 #endif
 static constexpr uint32_t kHandLag = FSK_HLAG;
 static constexpr uint32_t kHandPairs = kDirectPairs + kHandLag;
+// What every kernel shares is the span the correction stays un-retired (zr_dph < kHandPairs) -- not who applies it.  The
+// four-wave kernel's discriminator wave is never more than 23 decimated samples ahead, so its back wave lets go of the
+// correction after kOwnLag4 = 24 samples as in round 4 (its own span: kOwnPairs4 = 74 decimated samples, not 98) and the
+// discriminator wave applies it WITHOUT the retirement test for the rest of the span; the seven-wave kernel's frame wave
+// keeps it for all of kHandLag.  Sample for sample the same operations on the same values either way.
+static constexpr uint32_t kOwnLag4 = 24;
+static constexpr uint32_t kOwnPairs4 = kDirectPairs + kOwnLag4;
+static_assert(kOwnLag4 <= kHandLag, "the back wave cannot keep the correction longer than it stays un-retired");
 static constexpr uint32_t kBigWait = 0x40000000u;  // bit_wait while !started (12 h of decimated samples)
 #ifndef FSK_TILE
 #define FSK_TILE 32

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
     const uint32_t fld = C.fld, row4 = C.row4;
     for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
     BackU X;
+    X.own_pairs = kHandPairs; X.hand_lag = kHandLag;   // (no hand-over in this kernel: HAND = false)
     X.k = 0; X.kv = 0; X.free0 = free0; X.zmail = zmail; X.cmail = nullptr;
     X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) ? kDirectPairs : 0u;
     X.zlive = __builtin_amdgcn_ballot_w64((B.dph < kHandPairs) | (B.qai != 0.f) | (B.qaq != 0.f) | (B.qbi != 0.f) | (B.qbq != 0.f)) ? 1u : 0u;
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(64, 3) void demod_fused_kernel(
   }
   for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
   BackU X;
+  X.own_pairs = kHandPairs; X.hand_lag = kHandLag;   // (no hand-over in this kernel: HAND = false)
   X.k = 0; X.kv = 0; X.free0 = free0; X.zmail = zmail; X.cmail = nullptr;
   zmail[lane] = zmail_init(B.dph);
   X.direct = __builtin_amdgcn_ballot_w64(B.dph < kDirectPairs) ? kDirectPairs : 0u;
@@ -525,6 +527,7 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
   back_load<UNI>(B, BK, P, S, C, stream, out_counts, eod_counts, append);
   for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
   BackU X;
+  X.own_pairs = kHandPairs; X.hand_lag = kHandLag;   // (no hand-over in this kernel: HAND = false)
   X.k = 0; X.kv = 0; X.zmail = zmail; X.cmail = nullptr;
   zmail[lane] = zmail_init(B.dph);
   X.free0 = free0 - (parity0 ? inc : 0ull);             // decimated sample 0 of this launch starts one sample early then

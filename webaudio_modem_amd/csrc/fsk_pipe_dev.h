@@ -216,6 +216,8 @@ struct BackU {                   // wave-uniform context of one decimated sample
   uint32_t amp_soff;             // amplitude ring: byte offset of the push slot (quad row + slot within the quad, fsk_dev.h)
   uint32_t direct;               // decimated samples for which some lane still runs the direct instance (after a reset)
   uint32_t zlive;                // some lane carries a non-zero correction (or runs the direct instance)
+  uint32_t own_pairs, hand_lag;  // HAND kernels: zr_dph up to which the correction is this wave's own, and the lag of the hand-over (kHandPairs, kHandLag
+                                 // in fsk_blk6.hip; kOwnPairs4, kOwnLag4 in fsk_blk.hip)
   uint32_t *zmail;               // LDS [64]: decimated-sample index of this launch before which the front zeroes the lane's filters
   uint32_t *cmail;               // LDS [6][64] or null (fsk_blk.hip): hand-over of the ZIR correction to the discriminator wave
                                  // ([0] from which sample, [1..4] its value kHandLag steps of the recurrence before that sample,
@@ -363,26 +365,26 @@ __device__ inline void zir_step(BackLane &B, const BackK &K, BackU &X, float Ui,
           // steps run there, once) at sample kHandLag at the latest -- which is how the taker tells them apart.
           X.cmail[64u + lane] = __builtin_bit_cast(uint32_t, B.qai); X.cmail[128u + lane] = __builtin_bit_cast(uint32_t, B.qaq);
           X.cmail[192u + lane] = __builtin_bit_cast(uint32_t, B.qbi); X.cmail[256u + lane] = __builtin_bit_cast(uint32_t, B.qbq);
-          X.cmail[lane] = X.k + kHandLag;
+          X.cmail[lane] = X.k + X.hand_lag;
         }
       }
       B.dph += 1u;
     }
   }
-  if (dph0 >= kDirectPairs && dph0 < kHandPairs) {          // the un-retired span after the direct instance
+  if (dph0 >= kDirectPairs && dph0 < (HAND ? X.own_pairs : kHandPairs)) {   // the un-retired span after the direct instance (HAND: this wave's part of it)
     B.dph = dph0 + 1u;
-    if (HAND && B.dph == kHandPairs) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }   // handed over
+    if (HAND && B.dph == X.own_pairs) { B.qai = 0.f; B.qaq = 0.f; B.qbi = 0.f; B.qbq = 0.f; }   // handed over
   }
   if (HAND) {
     // lanes whose correction (or direct instance) is this wave's own evaluate the discriminator here; the others keep
     // the discriminator wave's result, which already carries their correction
-    const bool own = dph0 < kHandPairs;
+    const bool own = dph0 < X.own_pairs;
     if (__builtin_amdgcn_ballot_w64(own)) {
       float a2;
       const float p2 = atan2_amp_fma(wq, wi, a2, K.tiny, K.sgn);
       ph = own ? p2 : ph; amp = own ? a2 : amp;
     }
-    X.zlive = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(B.dph < kHandPairs) != 0));
+    X.zlive = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(B.dph < X.own_pairs) != 0));
   } else {
     const uint32_t changed = (__builtin_bit_cast(uint32_t, wi) ^ __builtin_bit_cast(uint32_t, Ui)) |
                              (__builtin_bit_cast(uint32_t, wq) ^ __builtin_bit_cast(uint32_t, Uq));
