@@ -33,10 +33,11 @@
 //     bytes go to a four-byte queue per lane that is flushed every sixteen blocks (at most two bytes per lane can
 //     complete in between: a byte takes 10 x dsSPB >= 80 decimated samples).
 // Who owns the ZIR correction.  After a reset the back wave runs the direct instance (kDirectPairs samples) and then keeps
-// the correction for kHandLag more samples, un-retired (fsk_params.h); its values at the hand-over sample follow from the
-// recurrence alone, so it posts them (cmail) to wave 2 -- which may be up to 24 decimated samples ahead -- when the direct
-// instance ends.  From the hand-over on wave 2 subtracts the correction before the discriminator and retires it by the
-// common rule, and the back wave's block path needs no discriminator of its own.  While a lane is inside the back wave's
+// the correction for kOwnLag4 = 24 more samples (fsk_params.h); its values at the hand-over sample follow from the
+// recurrence alone, so it posts them (cmail) to wave 2 -- which may be up to 23 decimated samples ahead -- when the direct
+// instance ends.  From the hand-over on wave 2 subtracts the correction before the discriminator -- un-retired until zr_dph
+// has reached kHandPairs (the span every kernel keeps it un-retired for; wave 2 counts from the hand-over sample), then
+// retiring it by the common rule -- and the back wave's block path needs no discriminator of its own.  While a lane is inside the back wave's
 // span, wave 2 leaves its pair sums in the x ring instead of (phase, magnitude) (cmail[5] = where the span began).
 // Bytes, counters and state are those of the per-sample kernels by construction: same float instruction sequence per
 // decimated sample, integer logic restated exactly (tests/test_gpu_parity.py runs every golden through this kernel).

@@ -193,9 +193,10 @@ struct ProcState {
 // fsk_pipe.hip, kZeroLagPairs / 8 tiles in fsk_blk6.hip) -- and a direct instance covers those plus two more.
 // Round 5: 24 -> 48.  The small-batch kernel (fsk_blk6.hip) has four stages on the ring this lag bounds; at 24 they shared
 // three tiles and ran in turn rather than side by side.  What it costs the others is the longer span the frame logic works
-// itself after a reset (98 instead of 50 decimated samples): config #3 - 1 %, an idle bank - 2 %, a batch whose streams'
-// frames do not line up (a reset in some lane every few tiles) - 12 % (profiles/r05_lag.txt).  One value for every kernel: the
-// fp32 results after a reset depend on it, and the kernels must stay interchangeable call by call.
+// itself after a reset (74 decimated samples in the four-wave kernels -- kOwnPairs4 below --, 98 in the seven-wave kernel,
+// instead of 50): config #3 +- 0, config #2 at 65 536 streams - 2 %, a batch whose streams' frames do not line up (a reset in
+// some lane every few tiles) - 6 % (profiles/r05_lag.txt).  One value for every kernel: the fp32 results after a reset depend
+// on it, and the kernels must stay interchangeable call by call.
 #ifndef FSK_ZLAG
 #define FSK_ZLAG 48
 #endif
