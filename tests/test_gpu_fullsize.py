@@ -15,6 +15,7 @@ import zlib
 
 import numpy as np
 import os
+import sys
 import pytest
 
 from conftest import ROOT
@@ -882,6 +883,72 @@ def test_seven_wave_kernel_is_the_four_wave_kernel_bit_for_bit(S, lanes, monkeyp
     for (ra, ia), (rb, ib) in zip(res["four"][2], res["six"][2]):
         assert np.array_equal(np.asarray(ra).view(np.uint64), np.asarray(rb).view(np.uint64))
         assert ia == ib
+    gen.device_free(d_x)
+    gen.close()
+
+
+def test_a_call_may_end_anywhere_in_the_span_after_a_reset():
+    """Round 5: after resetState() the direct instance runs kDirectPairs decimated samples, the correction stays un-retired until
+    zr_dph reaches kHandPairs -- with the back wave of the four-wave kernel for kOwnLag4 samples and with its discriminator wave
+    for the rest, with the frame wave of the seven-wave kernel throughout (fsk_params.h).  One frame per stream, then silence: the
+    'eod' resets every stream once, each at its own sample (random lead-ins).  A call boundary is swept in steps of two input
+    samples over 260 decimated samples around those resets -- so that for some stream it falls on every value of zr_dph from 0 to
+    beyond kHandPairs, on the hand-over sample and on the samples either side of it -- and what the four-wave and the seven-wave
+    kernel carry over it (every state word of every stream) and decode must be what the two-wave kernel, which never hands the
+    correction to another wave, carries and decodes."""
+    import webaudio_modem_amd as wm
+    S, payload = 64, 12
+    gen = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
+    fl = gen.modulated_length(payload)
+    N = (400 + fl + 2400 + 31) // 32 * 32
+    n0 = (400 + fl + 31) // 32 * 32
+    d_x = gen.device_malloc(S * N * 4)
+    gen.synth_device(d_x, n0, N, payload, SEED + 91, 400, 0.3, 1.0)
+    gen.synchronize()
+    row = np.empty(N, np.float32)
+    rng = np.random.RandomState(17)
+    xh = np.zeros((S, N), np.float32)
+    ends = np.zeros(S, np.int64)
+    for s_ in range(S):
+        gen.d2h(row, d_x + s_ * N * 4)
+        lead, _amp = gen.synth_stream_params(SEED + 91, s_, 400, 0.3, 1.0)
+        ends[s_] = lead + fl
+        xh[s_, :ends[s_]] = row[:ends[s_]]                                       # nothing behind a stream's one frame ...
+        p_frame = float(np.mean(row[lead:ends[s_]].astype(np.float64) ** 2))
+        xh[s_] += rng.normal(0.0, np.sqrt(p_frame / 1e4), N).astype(np.float32)  # ... but a floor 40 dB under it
+    gen.h2d(d_x, xh)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from state_fields import REAL, INT
+    import re
+    with open(os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_params.h")) as fh:
+        direct_pairs = int(re.search(r"#define FSK_ZLAG (\d+)", fh.read()).group(1)) + 2              # kDirectPairs
+    i_dph, dead = INT.index("zr_dph"), [REAL.index(n) for n in ("zq_ai", "zq_aq", "zq_bi", "zq_bq")]
+    first = int(ends.min()) + 150
+    cuts = list(range(first, first + 520 + int(ends.max() - ends.min()), 5))                # (both parities of the decimator; 64 lead-ins: every zr_dph many times)
+    ref = {}
+    eod_seen = 0
+    for cut in cuts:
+        res = {}
+        for name, opts in (("two", {"kernel": "two-wave"}), ("four", {"kernel": "four-wave"}), ("seven", {"kernel": "seven-wave"})):
+            eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options=opts)
+            rows1, eod1 = _demod_schedule(eng, d_x, cut, N, [cut])
+            at_cut = [eng.debug_state(s_) for s_ in range(S)]                        # what is carried over the boundary
+            rows2, eod2 = _demod_schedule(eng, d_x + cut * 4, N - cut, N, [N - cut])
+            rows = [bytes(a_) + bytes(b_) for a_, b_ in zip(rows1, rows2)]
+            res[name] = (_digest(rows, eod1 + eod2), at_cut)
+            eod_seen = max(eod_seen, int((eod1 + eod2).min()))
+            eng.close()
+        for name in ("four", "seven"):
+            assert res[name][0] == res["two"][0], (cut, name)
+            for s_, ((ra, ia), (rb, ib)) in enumerate(zip(res["two"][1], res[name][1])):
+                ua, ub = np.asarray(ra).view(np.uint64).copy(), np.asarray(rb).view(np.uint64).copy()
+                if ia[i_dph] < direct_pairs:                 # (while the direct instance runs the correction's four values are dead:
+                    ua[dead] = 0; ub[dead] = 0               # overwritten before their next use; the block kernels park them at zero)
+                assert np.array_equal(ua, ub), (cut, name, s_, [REAL[i] for i in np.nonzero(ua != ub)[0]])
+                assert ia == ib, (cut, name, s_)
+        ref.setdefault("digest", res["two"][0])
+        assert res["two"][0] == ref["digest"], cut                                   # ... and the cut does not matter at all
+    assert eod_seen >= 1                                                             # every stream did fire its 'eod' (and reset)
     gen.device_free(d_x)
     gen.close()
 
