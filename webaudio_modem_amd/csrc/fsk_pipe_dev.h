@@ -707,7 +707,14 @@ __device__ inline void pipe_store(const FrontLane &F, bool store_front, const Ba
   // free-running I/Q low-pass, the correction, lastPhase in the free frame; NCO phase = free phase + frame offset
   PIPE_RSTORE(li_x1, F.ix1); PIPE_RSTORE(li_x2, F.ix2); PIPE_RSTORE(li_y1, F.iy); PIPE_RSTORE(li_y2, F.iv);
   PIPE_RSTORE(lq_x1, F.qx1); PIPE_RSTORE(lq_x2, F.qx2); PIPE_RSTORE(lq_y1, F.qy); PIPE_RSTORE(lq_y2, F.qv);
-  PIPE_RSTORE(zq_ai, B.qai); PIPE_RSTORE(zq_aq, B.qaq); PIPE_RSTORE(zq_bi, B.qbi); PIPE_RSTORE(zq_bq, B.qbq);
+  {
+    // the correction's four values are dead while the direct instance runs (formed from its last two samples, first used at
+    // zr_dph = kDirectPairs): zeros are stored, so that the state arrays do not depend on the kernel (the one- and two-wave
+    // kernels' recurrence runs on over the span, the block kernels park it)
+    const bool dead = B.dph < kDirectPairs;
+    PIPE_RSTORE(zq_ai, dead ? 0.f : B.qai); PIPE_RSTORE(zq_aq, dead ? 0.f : B.qaq);
+    PIPE_RSTORE(zq_bi, dead ? 0.f : B.qbi); PIPE_RSTORE(zq_bq, dead ? 0.f : B.qbq);
+  }
   PIPE_RSTORE(zq_0i, B.q0i); PIPE_RSTORE(zq_0q, B.q0q);
   PIPE_ISTORE(zr_dph, B.dph);
   {
