@@ -385,4 +385,6 @@ async function main() {
   fs.writeFileSync(path.join(OUT, 'manifest.json'), JSON.stringify(manifest));
   console.log('cases', manifest.cases.length, 'arrays', Object.keys(arrays).length);
 }
-main().catch((e) => { console.error(e); process.exit(1); });
+// (round 6) golden_harness_hostile.js re-uses the helpers above: loaded as a module this file only exports them
+if (require.main === module) main().catch((e) => { console.error(e); process.exit(1); });
+else module.exports = { R, OUT, manifest, arrays, saveArray, rng32, gaussian, addGaussian, concat, scaled, str, mkCore, modulate, demodCase };

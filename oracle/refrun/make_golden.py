@@ -8,7 +8,8 @@ TEST INFRASTRUCTURE.  Steps:
      arrays + a manifest into the same temp dir;
   3. this script packs the arrays into tests/golden/golden.npz (compressed) and writes
      tests/golden/manifest.json; golden_harness_next.js does the same for the SURVEY 8(f) rows (CRC-16 /
-     XModem packets, ChunkedModulator, the FSKProcessor quantum loop) -> golden_next.npz + manifest_next.json.
+     XModem packets, ChunkedModulator, the FSKProcessor quantum loop) -> golden_next.npz + manifest_next.json;
+     golden_harness_hostile.js for NaN / Inf / out-of-range / subnormal input (round 6) -> golden_hostile.npz + manifest_hostile.json.
 Only data (inputs, expected outputs, status snapshots, intermediates) reaches the repo.
 
 usage: python oracle/refrun/make_golden.py [--ref /root/reference]
@@ -30,7 +31,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="", help="'golden.npz' or 'golden_next' to regenerate one set")
+    ap.add_argument("--only", default="", help="'golden.npz', 'golden_next' or 'golden_hostile' to regenerate one set")
     ap.add_argument("--keep", action="store_true", help="keep the temp dir (debugging)")
     args = ap.parse_args()
     tmp = tempfile.mkdtemp(prefix="fsk_golden_")
@@ -39,7 +40,8 @@ def main():
         gold = os.path.join(REPO, "tests", "golden")
         os.makedirs(gold, exist_ok=True)
         jobs = [("golden_harness.js", "golden.npz", "manifest.json"),
-                ("golden_harness_next.js", "golden_next.npz", "manifest_next.json")]
+                ("golden_harness_next.js", "golden_next.npz", "manifest_next.json"),
+                ("golden_harness_hostile.js", "golden_hostile.npz", "manifest_hostile.json")]
         for harness, npz, man_name in jobs:
             if args.only and args.only not in npz:
                 continue

@@ -1,7 +1,7 @@
 """FSKHIP_* environment variables -> fskhip_set_option() names (tests/conftest.py and the measurement tools install this as
 webaudio_modem_amd.engine.option_hook; the package and libfskhip.so themselves read no environment variable).
 
-  FSKHIP_SPLIT=0|1|4|6|a|b|c  kernel = one-wave | two-wave | four-wave | seven-wave | auto | auto-r02 | auto-r04
+  FSKHIP_SPLIT=0|1|4|5|6|a|b|c  kernel = one-wave | two-wave | four-wave | five-wave | seven-wave | auto | auto-r02 | auto-r04
   FSKHIP_FORCE_GENERIC=1      force_generic
   FSKHIP_BLK_YSLOTS=<n>       blk_y_slots          FSKHIP_BLK_MIN_TILES=<n>   blk_min_tiles
   FSKHIP_BLK_RESIDENT=<n>     blk_resident         FSKHIP_SLICE_TILES=<n>|off slice_tiles
@@ -10,7 +10,7 @@ webaudio_modem_amd.engine.option_hook; the package and libfskhip.so themselves r
 """
 import os
 
-_KERNEL = {"0": "one-wave", "1": "two-wave", "4": "four-wave", "6": "seven-wave", "a": "auto", "b": "auto-r02", "c": "auto-r04"}
+_KERNEL = {"0": "one-wave", "1": "two-wave", "4": "four-wave", "5": "five-wave", "6": "seven-wave", "a": "auto", "b": "auto-r02", "c": "auto-r04"}
 
 
 def from_env(n_streams=None, precision=None):

@@ -69,9 +69,12 @@ def compile_asm(extra):
         return open(asm).read()
 
 
+FIVE = False     # --five: demod_blk5_kernel (round 6: five waves per group)
+
+
 def mangled(kernel):
     b = [x.strip() == "true" for x in kernel.strip("<> ").split(",")]
-    return "_ZN3fsk16demod_blk_kernelILb%dELb%dELb%dEEE" % tuple(int(x) for x in b)
+    return ("_ZN3fsk17demod_blk5_kernelILb%dELb%dELb%dEEE" if FIVE else "_ZN3fsk16demod_blk_kernelILb%dELb%dELb%dEEE") % tuple(int(x) for x in b)
 
 
 def kernel_body(text, kernel):
@@ -149,7 +152,9 @@ def _is_peek(st):
 def role_of(ins_list):
     text = "\n".join(ins_list)
     if "buffer_load_dwordx4" in text:
-        return "wave 0: loads + AGC + pre-filter + phasors"
+        return "wave 4: loads + AGC (five-wave kernel)" if FIVE else "wave 0: loads + AGC + pre-filter + phasors"
+    if FIVE and "v_cos_f32" in text:
+        return "wave 0: pre-filter + phasors (five-wave kernel)"
     if "v_bcnt_u32_b32" in text:
         return "wave 3: post filter + slicer + correlator + frame FSM (block path)"
     if "v_sqrt_f32" in text:
@@ -174,6 +179,9 @@ def main():
         a = args.pop(0)
         if a == "--kernel":
             kernel = args.pop(0)
+        elif a == "--five":
+            global FIVE
+            FIVE = True
         elif a == "--dump":
             dump = True
         else:
@@ -186,7 +194,7 @@ def main():
             if st.startswith("ds_read_b128") and "ASMSTART" in body[i - 1]:
                 sites.append((n, k))
                 PEEK_REGS.add(st)
-    print("# fsk::demod_blk_kernel%s: hot path of one step (a tile = 16 input samples) per role loop, by issue class" % kernel)
+    print("# fsk::demod_blk%s_kernel%s: hot path of one step (a tile = 16 input samples) per role loop, by issue class" % ("5" if FIVE else "", kernel))
     print("# classes and prices: see this tool's header; per group-sample = per tile / 16")
     tot = {}
     seen_roles = {}
@@ -196,6 +204,8 @@ def main():
         h = histogram(ins)
         # a loop unrolled over several tiles (wave 0: three register sets) passes several counter reads per round
         tiles = max(1, sum(1 for st in ins if st.startswith("ds_read_b128") and _is_peek(st)))
+        if FIVE and "pre-filter + phasors" in role:
+            tiles = max(1, tiles // 2)       # (this part reads both counter quads per tile)
         if tiles > 1:
             h = {c: v / float(tiles) for c, v in h.items()}
         # the compiler clones some loops (the back wave's block loop is peeled): report each site, sum the first per role

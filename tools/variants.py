@@ -56,7 +56,7 @@ if os.environ.get("VAR_STAMPS"):
     six = "blk6" in eng.last_kernel()
     f = L.lib().fskdbg_read_stamps_blk6 if six else L.lib().fskdbg_read_stamps_blk if "blk" in eng.last_kernel() else L.lib().fskdbg_read_stamps
     f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-    a = np.zeros((7 if six else 4, 2048, 8), np.uint64)
+    a = np.zeros((7 if six else 5 if "blk5" in eng.last_kernel() else 4, 2048, 8), np.uint64)
     NW = a.shape[0]
     assert f(a.ctypes.data, a.size) == 0
     g = min(2048, (S + eng.blk_lanes() - 1) // eng.blk_lanes() if eng.blk_lanes() else (S + 63) // 64)
@@ -94,7 +94,7 @@ if os.environ.get("VAR_STAMPS"):
         late = (r0 - r0.min()) / 100.0   # s_memrealtime ticks at 100 MHz -> microseconds
         print("STAMP loop start of wave 0 after the first group's: median %%.0f us, 90 %%%% %%.0f us, max %%.0f us; groups starting more than 1 ms late: %%d of %%d"
               %% (np.median(late), np.percentile(late, 90), late.max(), int((late > 1000).sum()), g))
-    BW = 5 if six else NW - 1
+    BW = 5 if six else 3
     if a[BW, :g, 3].sum():
         c = a[BW, :g, 3:7].astype(np.float64).sum(axis=0)
         print("STAMP back wave blocks: %%.0f per group; per sample because a lane is inside this wave's own span after a reset %%.1f %%%%, (unused) %%.1f %%%%, per sample for a rare event %%.1f %%%%"

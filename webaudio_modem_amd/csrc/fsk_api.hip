@@ -36,14 +36,15 @@ size_t demod_fused_lds_bytes(const DemodParams &P);
 // fsk_blk.hip: four waves per group, block-batched back wave
 size_t demod_blk_lds_bytes(const DemodParams &P);
 size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots);
+size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots, uint32_t waves);
 bool demod_blk_applicable(const DemodParams &P);
 hipError_t set_blk_lds_limit(const DemodParams &P);
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, uint32_t y_slots,
-                             uint32_t lanes, uint32_t medium, bool *sliced_out);
+                             uint32_t lanes, uint32_t medium, bool *sliced_out, uint32_t waves = 4u);
 uint32_t demod_blk_lanes(uint32_t n_streams, int device);
-void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t *y_slots, uint32_t *resident_wgs);
+void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t *y_slots, uint32_t *resident_wgs, uint32_t waves = 4u);
 uint32_t demod_blk_slices(const DemodParams &P, const DemodState &S, size_t n, uint32_t resident_wgs, uint32_t slice_tiles,
                           uint32_t *slice_tiles_out);
 size_t demod_blk_queue_words(uint32_t groups);
@@ -201,6 +202,10 @@ struct fskhip_engine {
   uint32_t blk_resident = 0;     // workgroups of demod_blk_kernel the device holds at once; larger batches run it persistent, in time slices
   uint32_t blk_min_tiles = 0;    // calls with fewer whole tiles than this stay with round 2's kernels
   uint32_t blk_y_slots = 6;      // half tiles in the block kernel's y ring: as deep as the LDS allows at this batch size
+  // five waves per group (demod_blk5_kernel, round 6): the front wave's two halves on a wave each.  0 never, 1 wherever the plain
+  // four-wave kernel would run ("kernel" = five-wave), 2 auto: batches of whole-wave groups that fill the device
+  uint32_t use_five = 0;
+  uint32_t blk5_y_slots = 6, blk5_resident = 0;
   // "blk_resets": which of fsk_blk.hip's two kernels a call launches -- demod_blk_kernel_r, whose block path takes 'eod' resets
   // itself, pays where resets are frequent (an idle receiver bank: +50 %) and costs ~4 % where they are rare.  auto: by the
   // share of tiles the PREVIOUS call's back waves took off their fast loop (the kernels count; the totals come back with an
@@ -660,6 +665,7 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     *e->h_stat = 0ull;
     e->blk_lanes = demod_blk_lanes(n_streams, device);
     demod_blk_plan(P, (n_streams + e->blk_lanes - 1u) / e->blk_lanes, device, &e->blk_y_slots, &e->blk_resident);
+    demod_blk_plan(P, (n_streams + e->blk_lanes - 1u) / e->blk_lanes, device, &e->blk5_y_slots, &e->blk5_resident, 5u);
     if (hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) e->cus = 0;
     if (demod_blk6_applicable(P)) CREATE_TRY(set_blk6_lds_limit(P));
     if (e->blk_resident && e->n_blocks > e->blk_resident) {
@@ -716,15 +722,16 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
   int rc = FSKHIP_OK;
   if (k == "kernel") {          // which whole-tile kernel fp32 lock-step calls use
     const uint32_t n_blocks = e->n_blocks;
-    e->use_six = 0u;
-    if (v == "auto") { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; e->use_six = 2u; }
+    e->use_six = 0u; e->use_five = 0u;
+    if (v == "five-wave") { e->use_blk = true; e->use_split = true; e->split_forced = true; e->use_five = 1u; }
+    else if (v == "auto") { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; e->use_six = 2u; }
     else if (v == "auto-r04") { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; }   // (round 4's choice: never seven waves)
     else if (v == "auto-r02") { e->use_blk = false; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; }
     else if (v == "seven-wave" || v == "six-wave") { e->use_blk = true; e->use_split = true; e->split_forced = true; e->use_six = 1u; }   // (four waves where seven do not apply; "six-wave": its first name)
     else if (v == "four-wave") { e->use_blk = true; e->use_split = true; e->split_forced = true; }
     else if (v == "two-wave") { e->use_blk = false; e->use_split = true; e->split_forced = true; }
     else if (v == "one-wave") { e->use_blk = false; e->use_split = false; e->split_forced = true; }
-    else return fail(FSKHIP_E_INVALID, "fskhip_set_option(kernel): '%s' is none of auto, auto-r04, auto-r02, seven-wave, four-wave, two-wave, one-wave", value);
+    else return fail(FSKHIP_E_INVALID, "fskhip_set_option(kernel): '%s' is none of auto, auto-r04, auto-r02, seven-wave, five-wave, four-wave, two-wave, one-wave", value);
     return FSKHIP_OK;
   }
   if (k == "blk_resets") {      // 1: the four-wave kernel's block path takes resets (default), 0: such blocks go sample by sample
@@ -917,8 +924,11 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
                 "fsk::demod_blk6_kernel<true, 64>", "fsk::demod_blk6_kernel<true, 32>", "fsk::demod_blk6_kernel<true, 16>", "fsk::demod_blk6_kernel<true, 8>"};
             e->last_kernel = names6[(wb ? 4 : 0) + (e->blk_lanes == 64u ? 0 : e->blk_lanes == 32u ? 1 : e->blk_lanes == 16u ? 2 : 3)];
           } else {
+          // five waves per group where the plain four-wave kernel would run (the kernels whose block path takes resets have four)
+          const bool five = e->use_five != 0u && med == 0u && e->blk5_resident != 0u && e->blk_resident == e->blk5_resident;
           HIP_TRY(launch_demod_blk(wb, app, e->P, e->S, d_samples + head, n_fast, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st,
-                                   e->blk_resident, e->blk_slice_tiles, e->blk_y_slots, e->blk_lanes, med, &e->last_sliced));
+                                   e->blk_resident, e->blk_slice_tiles, five ? e->blk5_y_slots : e->blk_y_slots, e->blk_lanes, med, &e->last_sliced,
+                                   five ? 5u : 4u));
           // (the totals are fetched behind every long call, behind every eighth of a run of short ones: the copy is ~3 us of
           // the stream's time, 7 % of a 128-sample call of 65 536 streams)
           if (e->blk_medium == 3u && e->h_stat && e->S.blk_stat) {
@@ -938,7 +948,13 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
               "fsk::demod_blk_kernel_r<true, false>", "fsk::demod_blk_kernel_r<true, true>"};
           static const char *const names_rp[4] = {"fsk::demod_blk_kernel_rp<false, false>", "fsk::demod_blk_kernel_rp<false, true>",
                                                   "fsk::demod_blk_kernel_rp<true, false>", "fsk::demod_blk_kernel_rp<true, true>"};
-          if (med && !e->P.uni_cfg) e->last_kernel = names_rp[(wb ? 2 : 0) + (e->last_sliced ? 1 : 0)];
+          static const char *const names5[8] = {
+              "fsk::demod_blk5_kernel<false, false, false>", "fsk::demod_blk5_kernel<false, false, true>",
+              "fsk::demod_blk5_kernel<false, true, false>", "fsk::demod_blk5_kernel<false, true, true>",
+              "fsk::demod_blk5_kernel<true, false, false>", "fsk::demod_blk5_kernel<true, false, true>",
+              "fsk::demod_blk5_kernel<true, true, false>", "fsk::demod_blk5_kernel<true, true, true>"};
+          if (five) e->last_kernel = names5[(wb ? 4 : 0) + (e->P.uni_cfg ? 2 : 0) + (e->last_sliced ? 1 : 0)];
+          else if (med && !e->P.uni_cfg) e->last_kernel = names_rp[(wb ? 2 : 0) + (e->last_sliced ? 1 : 0)];
           else
           e->last_kernel = med ? names[8 + (wb ? 2 : 0) + (e->last_sliced ? 1 : 0)]                  // <writeback, time-sliced>
                                : names[(wb ? 4 : 0) + (e->P.uni_cfg ? 2 : 0) + (e->last_sliced ? 1 : 0)];   // <writeback, uniform, time-sliced>

@@ -183,6 +183,15 @@ __device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &
 // finish one after the other (185 .. 284 cycles per sample, profiles/r03_blk4_stamps.txt), the last one largely alone
 // and at a single group's latency-bound pace.  Rotating four priority levels over the CU's workgroups every 64 half
 // tiles gives each group every level a quarter of the time.  (s_setprio takes an immediate.)
+#ifndef FSK_BLK_WGS
+#define FSK_BLK_WGS 4
+#endif
+#ifndef FSK_BLK5_WPE
+#define FSK_BLK5_WPE 5           // waves per SIMD the five-wave kernel is compiled for (96 VGPRs)
+#endif
+#ifndef FSK_BLK_LDS_PAD
+#define FSK_BLK_LDS_PAD 0      // (measurement builds: unused bytes at the end of the workgroup's LDS -- where the fourth workgroup of a CU stops fitting)
+#endif
 #ifndef FSK_BLK_PRIO
 #define FSK_BLK_PRIO 1
 #endif
@@ -284,13 +293,22 @@ struct BlkSched {
 // straight-line path needs nearly the whole 128-register budget, and merely compiled in beside the other two it costs
 // them ~4 % where resets are rare (constants pushed out of registers, spills around it: profiles/r04_block_resets.txt).
 // The host launches demod_blk_kernel_r when the previous call's share of tiles off the fast path says it pays.
-template <bool WB, bool UNI, bool SL, bool MED>
+// NW = 5 (round 6, demod_blk5_kernel): the front wave's two halves on a wave each -- part 4: tile loads, transposition, AGC, IN PLACE into
+// one of two staging tiles (and the AGC write-back); part 0: pre-filter + the tile's NCO phasors from there -> y ring.  Five
+// instruction streams per SIMD at four workgroups per CU (every part's per-tile loop fits 96 VGPRs as it stands); the AGC's
+// ten-instruction dependent chain -- 32 of the front wave's 44.8 class-priced cycles per sample -- no longer shares a wave with
+// the loads and the pre-filter.  Same instruction sequence per sample (front_agc + front_bp are front_agc_bp's two halves).
+template <bool WB, bool UNI, bool SL, bool MED, int NW = 4>
 __device__ __forceinline__ void demod_blk_body(
     const DemodParams &P, const DemodState &S, float *__restrict__ samples, size_t n_call, size_t pitch, int append_call,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
     uint32_t *__restrict__ eod_counts, const BlkSched &Z) {
   FSK_ABL_INIT
   FSK_STAMP_DECL
+#ifdef FSK_SCRATCH_PAD       // (measurement builds: private memory nobody touches -- does a larger scratch frame cost resident waves?)
+  volatile uint32_t scratch_pad[FSK_SCRATCH_PAD / 4];
+  if (n_call == 0xDEADBEEFull) { for (int i = 0; i < FSK_SCRATCH_PAD / 4; i++) scratch_pad[i] = (uint32_t)i; out_counts[0] = scratch_pad[threadIdx.x & 15]; }
+#endif
   constexpr int COH = SL ? kCohSc1 : 0;           // cache policy of what a time slice hands to the next (fsk_dev.h)
   extern __shared__ float4 lds[];
   const uint32_t PS = blk_poly_stride(P.d);
@@ -298,12 +316,14 @@ __device__ __forceinline__ void demod_blk_body(
   v4f *stage = reinterpret_cast<v4f *>(lds);
   v4f *fin = stage;                                       // [0..1] wave 1's final I/Q low-pass state, [2] wave 2's final correction
                                                           // (over the staging tile: wave 0 is done with it when they are written)
-  v4f *yring = stage + 4 * kSlotStride;                   // wave 0 -> wave 1 (and the back wave after a reset): pre-filter outputs
+  v4f *yring = stage + (NW == 5 ? 8 : 4) * kSlotStride;   // wave 0 -> wave 1 (and the back wave after a reset): pre-filter outputs
+                                                          // (NW = 5: two staging tiles, part 4 -> part 0)
   v4f *ring = yring + NY * 2 * 64;                        // wave 1: pair sums U -> wave 2: (phase, magnitude) IN PLACE -> wave 3
   v4f *zt = ring + kBlkSlots * kBlkSlotV4;
   const uint32_t ZTM = Z.zt_tiles - 1u;
   uint32_t *poly = reinterpret_cast<uint32_t *>(zt + Z.zt_tiles * 8);   // [lane][PS], index 0 = the phase of the launch's first push
   uint32_t *ctr = poly + 64u * PS;                        // produced by wave 0, 1, 2 | consumed by wave 3 | [4] CU arrival | [5] item
+                                                          // NW = 5: [6] tiles part 4 has staged, [7] staging tiles part 0 has released
   uint32_t *zmail = ctr + 8;                              // back -> wave 1: where to zero a lane's I/Q low-pass
   uint32_t *cmail = zmail + 64;                           // back -> wave 2: [0] from which decimated sample, [1..4] the correction kHandLag
                                                           // steps of its recurrence before that (or there, if [0] <= kHandLag), [5] since
@@ -330,10 +350,30 @@ __device__ __forceinline__ void demod_blk_body(
   // its counter forever).  Every wave posts its wish, then all four evaluate the same rule on the same four words: in wave
   // order, a wave takes its wish if no earlier wave has it, else the lowest part still free.  One LDS write and one
   // barrier per kernel; with the usual one-wave-per-SIMD placement every wave gets its wish.
-  if (lane == 0) ctr[8 + wave] = (simd + ctr[4]) & 3u;      // (ctr[8..11]: the first words of zmail, initialised after this)
+  if (lane == 0) ctr[8 + wave] = NW == 5 ? simd : (simd + ctr[4]) & 3u;      // (ctr[8..12]: the first words of zmail, initialised after this)
   __syncthreads();
   uint32_t role = 0;
-  {
+  if (NW == 5) {
+    // Five parts on four SIMDs: a workgroup's five waves sit on the SIMDs in cyclic order, so one SIMD -- qd -- hosts two of
+    // them, and with four workgroups per CU (config #3's size) every SIMD is some workgroup's qd.  Rows and columns 0..3 of the
+    // cyclic 5 x 5 Latin square: the first wave on SIMD q plays part (qd + q) mod 5, the second wave on qd plays (qd + 4) mod 5 --
+    // every part once per workgroup, and where the four workgroups of a CU have different qd (the usual placement) every SIMD
+    // hosts one wave of each part.  Any other placement: the part is the wave index (every part still played exactly once).
+    uint32_t sd[5], packed = 0;
+    for (uint32_t w = 0; w < 5u; w++) {
+      sd[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctr[8 + w]) & 3u;
+      packed += 1u << (8u * sd[w]);
+    }
+    uint32_t qd = 4u;
+    for (uint32_t q = 0; q < 4u; q++)
+      if (packed == 0x01010101u + (1u << (8u * q))) qd = q;
+    role = wave;
+    if (qd < 4u) {
+      bool first = true;
+      for (uint32_t w = 0; w < wave; w++) first = first && sd[w] != simd;
+      role = first ? (qd + simd) % 5u : (qd + 4u) % 5u;
+    }
+  } else {
     uint32_t taken = 0;
     for (uint32_t w = 0; w <= wave; w++) {
       uint32_t want = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctr[8 + w]) & 3u;
@@ -390,7 +430,7 @@ __device__ __forceinline__ void demod_blk_body(
   const uint64_t inc = UNI ? (((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo) : S.nco_inc[C.row4 >> 2];
   const uint64_t free0 = pipe_free0<UNI, COH>(C);
 
-  if (threadIdx.x == 0) { ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; }
+  if (threadIdx.x == 0) { ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; if (NW == 5) { ctr[6] = 0; ctr[7] = 0; } }
   if (wave == 1) {
     const FastMem &M = C.M;
     const uint32_t fld = C.fld, row4 = C.row4;
@@ -422,7 +462,159 @@ __device__ __forceinline__ void demod_blk_body(
   }
   __syncthreads();
 
-  if (role == 0) {
+  if (NW == 5 && role == 4) {
+    // ------------------------------------------------------------------------------ NW = 5, part 4: loads, AGC (in place in a staging tile)
+    FrontLane F;
+    FrontK K;
+    front_load<UNI, COH>(F, K, P, S, C);
+    const uint32_t sub_row = lane >> 2, chunk = lane & 3;
+    const uint32_t rows_here = P.n_streams - s0 < W ? P.n_streams - s0 : W;
+    v4i in_rsrc;
+    {
+      const uint64_t base = reinterpret_cast<uint64_t>(samples + (size_t)s0 * pitch);
+      in_rsrc.x = (int)(uint32_t)base;
+      in_rsrc.y = (int)(uint32_t)(base >> 32);
+      in_rsrc.z = (int)(uint32_t)(rows_here * pitch * 4u);
+      in_rsrc.w = 0x00020000;
+    }
+    const uint32_t in_voff = (uint32_t)((sub_row * pitch + 4u * chunk) * 4u);
+    const uint32_t in_row16 = (uint32_t)(16u * pitch * 4u);
+    const uint32_t st_slot = chunk * kSlotStride + sub_row;
+#define BLK_BLOAD4(dst, rows16, soff)                                                                       \
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(in_voff + (rows16) * in_row16), \
+               "s"(in_rsrc), "s"(soff) : "memory")
+    auto load_tile = [&](size_t t, v4f &a, v4f &b, v4f &c, v4f &d) {
+      const uint32_t tn = (uint32_t)((t_begin + (t < n_tiles ? t : n_tiles - 1)) * kFastTile * 4u);
+      BLK_BLOAD4(a, 0u, tn); BLK_BLOAD4(b, 1u, tn); BLK_BLOAD4(c, 2u, tn); BLK_BLOAD4(d, 3u, tn);
+    };
+    v4f a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the state loads above are complete, the count starts clean
+    load_tile(0, a0, a1, a2, a3);
+    load_tile(1, b0, b1, b2, b3);
+    load_tile(2, c0, c1, c2, c3);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+                 "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
+    uint32_t released = 0;                                  // staging tiles part 0 is done with
+    auto do_tile = [&](uint32_t t, v4f &r0, v4f &r1, v4f &r2, v4f &r3) {
+      if (WB) asm volatile("s_waitcnt vmcnt(16)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+      if (t >= released + 2u) {                             // both staging tiles in use: part 0 has not released tile t - 2
+        FSK_STAMP_W0
+        while (t >= released + 2u) {
+          released = lds_peek(&ctr[7]);
+          if (t >= released + 2u) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_A);
+        }
+        FSK_STAMP_W1
+      }
+      v4f *stg = stage + (t & 1u) * 4u * kSlotStride;
+      stg[st_slot] = r0; stg[st_slot + 16] = r1; stg[st_slot + 32] = r2; stg[st_slot + 48] = r3;
+      load_tile((size_t)t + 3, r0, r1, r2, r3);
+      v4u32 cw;
+      lds_peek4_begin(ctr + 4, cw);
+      v4f x4[4];
+#pragma unroll
+      for (uint32_t c = 0; c < 4; c++) x4[c] = stg[c * kSlotStride + lane];
+#pragma unroll
+      for (uint32_t c = 0; c < 4; c++) {
+        const float xin[4] = {x4[c].x, x4[c].y, x4[c].z, x4[c].w};
+        float xs[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) xs[j] = FSK_ABL(4) ? xin[j] : front_agc(F, K, xin[j]);
+        stg[c * kSlotStride + lane] = (v4f){xs[0], xs[1], xs[2], xs[3]};
+        if (WB) {
+          if (C.valid)
+            *reinterpret_cast<v4f *>(samples + (size_t)(C.row4 >> 2) * pitch + (size_t)(t_begin + t) * kFastTile + 4u * c) = (v4f){xs[0], xs[1], xs[2], xs[3]};
+        }
+      }
+      lds_post(&ctr[6], t + 1u);
+      released = lds_peek4_get(cw, 3);
+    };
+    const uint32_t nt = (uint32_t)n_tiles;
+    FSK_STAMP_BEGIN
+    for (uint32_t t0 = 0; t0 < nt; t0 += 96u) {             // (a multiple of three tiles and of 64 half tiles)
+      blk_prio<MED>(2u * t0, wgj, 0u);
+      const uint32_t te = t0 + 96u < nt ? t0 + 96u : nt;
+      for (uint32_t t = t0; t < te; t += 3) {
+        do_tile(t, a0, a1, a2, a3);
+        if (t + 1 < te) do_tile(t + 1, b0, b1, b2, b3);
+        if (t + 2 < te) do_tile(t + 2, c0, c1, c2, c3);
+      }
+    }
+    FSK_STAMP_END(4)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+                 "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
+#undef BLK_BLOAD4
+    {
+      const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
+      const FastMem &M = C.M;
+      const uint32_t fld = C.fld;
+      PIPE_RSTORE(agc_gain, F.g);
+    }
+  } else if (NW == 5 && role == 0) {
+    // ------------------------------------------------------------------------------ NW = 5, part 0: pre-filter, phasors
+    FrontLane F;
+    FrontK K;
+    front_load<UNI, COH>(F, K, P, S, C);
+    uint32_t consumed = 0, slot_i = 0, staged = 0;
+    uint64_t zacc = free0 + inc * (uint64_t)(lane & 15u);
+    const uint64_t inc16 = inc * 16u;
+    const uint32_t nt = (uint32_t)n_tiles;
+    FSK_STAMP_BEGIN
+    for (uint32_t t = 0; t < nt; t++) {
+      if ((t & 31u) == 0u) blk_prio<MED>(2u * t, wgj, 0u);
+      const uint32_t hidx = 2u * t;
+      v4u32 cv, cw;
+      lds_peek4_begin(ctr, cv);                             // (read now, looked at after the tile: see lds_peek4_begin)
+      lds_peek4_begin(ctr + 4, cw);
+      if (staged <= t || hidx + 1u - consumed >= NY) {
+        FSK_STAMP_W0
+        while (staged <= t) {                               // part 4's tile
+          staged = lds_peek(&ctr[6]);
+          if (staged <= t) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_A);
+        }
+        while (hidx + 1u - consumed >= NY) {                // ring full: the back wave (which may still need the slots'
+          consumed = lds_peek(&ctr[3]);                     // pre-filter outputs after a reset) has not released them
+          if (hidx + 1u - consumed >= NY) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_A);
+        }
+        FSK_STAMP_W1
+      }
+      const v4f *stg = stage + (t & 1u) * 4u * kSlotStride;
+      v4f x4[4];
+#pragma unroll
+      for (uint32_t c = 0; c < 4; c++) x4[c] = stg[c * kSlotStride + lane];
+      lds_post(&ctr[7], t + 1u);                            // (waits for the four reads: the staging tile is part 4's again)
+      if (UNI) {
+        float pc, ps;
+        nco_phasor(zacc, pc, ps);
+        reinterpret_cast<f2 *>(zt + (t & ZTM) * 8u)[lane & 15u] = (f2){pc, ps};
+        zacc += inc16;
+      }
+#pragma unroll
+      for (uint32_t hf = 0; hf < 2; hf++) {
+        v4f *slot = yring + slot_i * 2u * 64u;
+        slot_i = slot_i + 1u == NY ? 0u : slot_i + 1u;
+#pragma unroll
+        for (uint32_t cc = 0; cc < 2; cc++) {
+          const uint32_t c = 2u * hf + cc;
+          const float xv[4] = {x4[c].x, x4[c].y, x4[c].z, x4[c].w};
+          float y[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) y[j] = FSK_ABL(0) ? xv[j] : front_bp(F, K, xv[j]);
+          slot[cc * 64u + lane] = (v4f){y[0], y[1], y[2], y[3]};
+        }
+      }
+      lds_post(&ctr[0], hidx + 2u);
+      consumed = lds_peek4_get(cv, 3);
+      staged = lds_peek4_get(cw, 2);
+    }
+    FSK_STAMP_END(0)
+    {
+      const __amdgpu_buffer_rsrc_t rs_rsrc = C.rs_rsrc;
+      const FastMem &M = C.M;
+      const uint32_t fld = C.fld;
+      PIPE_RSTORE(bp_x1, F.bx1); PIPE_RSTORE(bp_x2, F.bx2); PIPE_RSTORE(bp_y1, F.by1); PIPE_RSTORE(bp_y2, F.by2);
+    }
+  } else if (role == 0) {
     // ------------------------------------------------------------------------------ loads, AGC, pre-filter
     FrontLane F;
     FrontK K;
@@ -1111,7 +1303,7 @@ __device__ __forceinline__ void demod_blk_body(
 }
 
 template <bool WB, bool UNI, bool SL>
-__global__ __launch_bounds__(256, 4) void demod_blk_kernel(
+__global__ __launch_bounds__(256, FSK_BLK_WGS) void demod_blk_kernel(
     DemodParams P, DemodState S, float *__restrict__ samples, size_t n_call, size_t pitch, int append_call,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
     uint32_t *__restrict__ eod_counts, BlkSched Z) {
@@ -1134,11 +1326,21 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel_rp(
   demod_blk_body<WB, false, SL, true>(P, S, samples, n_call, pitch, append_call, out, out_pitch, out_counts, eod_counts, Z);
 }
 
-// ---- host side ---------------------------------------------------------------------------------------------------
-size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots) {
-  return sizeof(float4) * (4 * kSlotStride + y_slots * 2 * 64 + kBlkSlots * kBlkSlotV4 + blk_zt_tiles(y_slots) * 8) +
-         sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 8u + 64u + 6u * 64u);
+// ... and with five waves per group (round 6): the front wave's two halves on a wave each (see demod_blk_body, NW = 5)
+template <bool WB, bool UNI, bool SL>
+__global__ __launch_bounds__(320, FSK_BLK5_WPE) void demod_blk5_kernel(
+    DemodParams P, DemodState S, float *__restrict__ samples, size_t n_call, size_t pitch, int append_call,
+    uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
+    uint32_t *__restrict__ eod_counts, BlkSched Z) {
+  demod_blk_body<WB, UNI, SL, false, 5>(P, S, samples, n_call, pitch, append_call, out, out_pitch, out_counts, eod_counts, Z);
 }
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots, uint32_t waves) {
+  return sizeof(float4) * ((waves == 5u ? 8 : 4) * kSlotStride + y_slots * 2 * 64 + kBlkSlots * kBlkSlotV4 + blk_zt_tiles(y_slots) * 8) +
+         sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 8u + 64u + 6u * 64u) + FSK_BLK_LDS_PAD;
+}
+size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots) { return demod_blk_lds_bytes(P, y_slots, 4u); }
 size_t demod_blk_lds_bytes(const DemodParams &P) { return demod_blk_lds_bytes(P, kBlkSlots); }
 // the block path needs whole blocks of polyphase registers (dsSPB a multiple of 4) and at most one bit decision per block
 // (in practice dsSPB = 20, 40, 80: the whole-tile kernels only see configurations whose sync-ring capacity, (bits + 32) *
@@ -1148,11 +1350,14 @@ bool demod_blk_applicable(const DemodParams &P) { return P.d >= 8u && (P.d & 3u)
 hipError_t set_blk_lds_limit(const DemodParams &P) {
   hipError_t e = hipSuccess;
   if (demod_blk_lds_bytes(P) > 160 * 1024) return hipSuccess;
-  size_t bytes = demod_blk_lds_bytes(P, kBlkYMax);
+  size_t bytes = demod_blk_lds_bytes(P, kBlkYMax, 5u);
   bytes = bytes > 160 * 1024 ? 160 * 1024 : bytes;
 #define FSK_ATTR(WBV, UNIV, SLV)                                                                                 \
   if (e == hipSuccess)                                                                                           \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk_kernel<WBV, UNIV, SLV>),                  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                            \
+  if (e == hipSuccess)                                                                                           \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk5_kernel<WBV, UNIV, SLV>),                 \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   FSK_ATTR(false, false, false) FSK_ATTR(false, true, false) FSK_ATTR(true, false, false) FSK_ATTR(true, true, false)
   FSK_ATTR(false, false, true) FSK_ATTR(false, true, true) FSK_ATTR(true, false, true) FSK_ATTR(true, true, true)
@@ -1175,14 +1380,18 @@ hipError_t set_blk_lds_limit(const DemodParams &P) {
 // How to launch a batch of `groups` on `device`: the y ring as deep as the LDS allows while every CU still holds its
 // share of the groups (at most four workgroups: the register file's limit), and how many workgroups the device then
 // holds at once (one round; larger batches are run persistently, in time slices).  Zeros if it cannot tell.
-void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t *y_slots, uint32_t *resident_wgs) {
+void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t *y_slots, uint32_t *resident_wgs, uint32_t waves) {
   *y_slots = kBlkSlots; *resident_wgs = 0;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return;
   auto held = [&](uint32_t y) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&demod_blk_kernel<false, true, true>), 256,
-                                                     demod_blk_lds_bytes(P, y)) != hipSuccess) return 0u;
+    const hipError_t oe = waves == 5u
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&demod_blk5_kernel<false, true, true>), 320,
+                                                       demod_blk_lds_bytes(P, y, 5u))
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&demod_blk_kernel<false, true, true>), 256,
+                                                       demod_blk_lds_bytes(P, y));
+    if (oe != hipSuccess) return 0u;
     return per_cu > 0 ? (uint32_t)per_cu : 0u;
   };
   const uint32_t most = held(kBlkSlots);                       // (four)
@@ -1193,7 +1402,7 @@ void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t 
   // (the occupancy query, and 512-byte granules, let a third workgroup "fit" beside 2 x 54 112 bytes; the hardware did not
   // place it and 49 152 streams ran in two rounds.  1 280 = 160 KB / 128 and 2 048 both explain what was measured.)
   auto fits = [&](uint32_t yy) {
-    const size_t b = demod_blk_lds_bytes(P, yy);
+    const size_t b = demod_blk_lds_bytes(P, yy, waves);
     return (size_t)want * ((b + 1279u) / 1280u * 1280u) <= 160u * 1024u && (size_t)want * ((b + 2047u) & ~(size_t)2047u) <= 160u * 1024u;
   };
   while (y + 2u <= kBlkYMax && fits(y + 2u) && held(y + 2u) >= want) y += 2u;
@@ -1238,11 +1447,12 @@ uint32_t demod_blk_lanes(uint32_t n_streams, int device) {
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, uint32_t y_slots,
-                             uint32_t lanes, uint32_t medium, bool *sliced_out) {
+                             uint32_t lanes, uint32_t medium, bool *sliced_out, uint32_t waves) {
   lanes = (lanes == 8u || lanes == 16u || lanes == 32u) ? lanes : 64u;
+  if (medium != 0u) waves = 4u;                               // (the kernels whose block path takes resets have four waves)
   const uint32_t blocks = (P.n_streams + lanes - 1u) / lanes;
   y_slots = y_slots < kBlkSlots ? kBlkSlots : y_slots > kBlkYMax ? kBlkYMax : y_slots;
-  const size_t lds = demod_blk_lds_bytes(P, y_slots);
+  const size_t lds = demod_blk_lds_bytes(P, y_slots, waves);
   set_ablate_blk();
   BlkSched Z = {nullptr, blocks, 1u, 0u, 0u, y_slots, blk_zt_tiles(y_slots), lanes, medium};
   uint32_t st = 0;
@@ -1279,6 +1489,20 @@ hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, c
     return hipGetLastError();
   }
 #undef FSK_LAUNCH_BLKRP
+#define FSK_LAUNCH_BLK5(WBV, UNIV, SLV)                                                                         \
+  hipLaunchKernelGGL((demod_blk5_kernel<WBV, UNIV, SLV>), dim3(grid), dim3(320), lds, stream, P, S, samples, n, pitch, \
+                     append ? 1 : 0, out, out_pitch, out_counts, eod_counts, Z)
+  if (waves == 5u) {
+    if (sliced) {
+      if (writeback) { if (uni) FSK_LAUNCH_BLK5(true, true, true); else FSK_LAUNCH_BLK5(true, false, true); }
+      else { if (uni) FSK_LAUNCH_BLK5(false, true, true); else FSK_LAUNCH_BLK5(false, false, true); }
+    } else {
+      if (writeback) { if (uni) FSK_LAUNCH_BLK5(true, true, false); else FSK_LAUNCH_BLK5(true, false, false); }
+      else { if (uni) FSK_LAUNCH_BLK5(false, true, false); else FSK_LAUNCH_BLK5(false, false, false); }
+    }
+    return hipGetLastError();
+  }
+#undef FSK_LAUNCH_BLK5
   if (sliced) {
     if (writeback) { if (uni) FSK_LAUNCH_BLK(true, true, true); else FSK_LAUNCH_BLK(true, false, true); }
     else { if (uni) FSK_LAUNCH_BLK(false, true, true); else FSK_LAUNCH_BLK(false, false, true); }

@@ -167,28 +167,7 @@ __device__ __forceinline__ float lp_step(LpLane &L, float a2, float nd, float v,
   return L.y;
 }
 
-// front_agc_bp (fsk_pipe_dev.h) as its two halves, instruction for instruction: the AGC (fsk.ts:52-76) ...
-__device__ __forceinline__ float front_agc(FrontLane &F, const FrontK &K, float xin) {
-  const float xv = xin * F.g;
-  const float level = __builtin_fabsf(xv);
-  const float t = __builtin_fmaf(0.5f, __builtin_amdgcn_rcpf(level), -F.g);
-  float st;
-  asm("v_fma_f32 %0, |%1|, %2, %3 clamp" : "=v"(st) : "v"(xv), "v"(K.step_k), "v"(K.step_b));
-  const float rate = __builtin_fmaf(st, K.att_m_rel, K.rel);
-  float gn = __builtin_fmaf(t, rate, F.g);
-  gn = level > 0.0f ? gn : F.g;
-  F.g = __builtin_amdgcn_fmed3f(gn, K.g_lo, K.g_hi);
-  return xv;
-}
-// ... and the pre-filter (filters.ts:47-87), b1 = 0, b2 = -b0
-__device__ __forceinline__ float front_bp(FrontLane &F, const FrontK &K, float xv) {
-  float v = K.bp_b0 * (xv - F.bx2);
-  v = __builtin_fmaf(K.bp_na2, F.by2, v);
-  v = __builtin_fmaf(K.bp_na1, F.by1, v);
-  F.bx2 = F.bx1; F.bx1 = xv;
-  F.by2 = F.by1; F.by1 = v;
-  return v;
-}
+// (front_agc / front_bp -- front_agc_bp as its two halves -- live in fsk_pipe_dev.h since round 6: fsk_blk.hip's five-wave kernel uses them too)
 
 #ifndef FSK_B6_SLEEP
 #define FSK_B6_SLEEP 1

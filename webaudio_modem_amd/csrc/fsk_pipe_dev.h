@@ -107,6 +107,29 @@ __device__ inline void front_agc_bp(FrontLane &F, const FrontK &K, float xin, fl
   F.by2 = F.by1; F.by1 = v;
   y = v;
 }
+// front_agc_bp as its two halves (the seven-wave kernel of fsk_blk6.hip and the five-wave kernel of fsk_blk.hip give them to different waves), instruction for instruction: the AGC (fsk.ts:52-76) ...
+__device__ __forceinline__ float front_agc(FrontLane &F, const FrontK &K, float xin) {
+  const float xv = xin * F.g;
+  const float level = __builtin_fabsf(xv);
+  const float t = __builtin_fmaf(0.5f, __builtin_amdgcn_rcpf(level), -F.g);
+  float st;
+  asm("v_fma_f32 %0, |%1|, %2, %3 clamp" : "=v"(st) : "v"(xv), "v"(K.step_k), "v"(K.step_b));
+  const float rate = __builtin_fmaf(st, K.att_m_rel, K.rel);
+  float gn = __builtin_fmaf(t, rate, F.g);
+  gn = level > 0.0f ? gn : F.g;
+  F.g = __builtin_amdgcn_fmed3f(gn, K.g_lo, K.g_hi);
+  return xv;
+}
+// ... and the pre-filter (filters.ts:47-87), b1 = 0, b2 = -b0
+__device__ __forceinline__ float front_bp(FrontLane &F, const FrontK &K, float xv) {
+  float v = K.bp_b0 * (xv - F.bx2);
+  v = __builtin_fmaf(K.bp_na2, F.by2, v);
+  v = __builtin_fmaf(K.bp_na1, F.by1, v);
+  F.bx2 = F.bx1; F.bx1 = xv;
+  F.by2 = F.by1; F.by1 = v;
+  return v;
+}
+
 // second half: mix with the free-running NCO + I/Q low-pass (fsk.ts:229-238), velocity form, gain already on y
 __device__ inline void front_mix_lp(FrontLane &F, const FrontK &K, float v, float c, float s, float &oi, float &oq) {
   const float mi = v * c, mq = v * s;
