@@ -25,8 +25,8 @@ extern "C" {
  * fskhip_demodulate_host, fskhip_enable_signal_quality / fskhip_get_signal_quality.  4: fskhip_set_option (the library reads no
  * environment variable any more), fskhip_clock_probe_begin / _end, fskhip_debug_state.  5: fskhip_blk_lanes, option
  * "blk_lanes" (additions only).  6: kernel = seven-wave / auto-r04, options "stage_min_tiles" / "stage_y_slots" / "stage_roles"; the batched
- * IIRFilter of fskhip_next.h (additions only). */
-#define FSKHIP_ABI_VERSION 6
+ * IIRFilter of fskhip_next.h (additions only).  7: fskhip_get_faults (additions only). */
+#define FSKHIP_ABI_VERSION 7
 #define FSKHIP_MAX_PATTERN_BYTES 16
 
 enum {
@@ -178,6 +178,26 @@ int fskhip_modulate_device(fskhip_engine *e, const uint8_t *d_payloads, const ui
 int fskhip_reset(fskhip_engine *e, int64_t stream);
 /* getStatus() (fsk.ts:481-493). Synchronises with outstanding work of the engine. */
 int fskhip_get_status(fskhip_engine *e, uint32_t stream, fskhip_status *st);
+
+/*
+ * Streams whose filter state has left the finite range (ABI 7).  out[s] = 1 for such a stream (n_streams bytes, or NULL),
+ * *n_faulty = how many (or NULL).  What puts a stream there, and what the engines then do (tests/test_gpu_hostile.py against
+ * tests/golden/golden_hostile.npz, the REAL reference on the same samples):
+ *   - a NaN or +-Inf sample.  The reference's pre-filter is never reset (fsk.ts:175-188, filters.ts:47-76), so its instance
+ *     is dead from that sample on: every sliced bit is 0 (`NaN > 0`, fsk.ts:264), the amplitude is never below the silence
+ *     threshold (`NaN < t`, fsk.ts:285) -- no further bytes, no further 'eod', until it is configured again.  BOTH precisions
+ *     do exactly that, bit for bit: same bytes, same 'eod' count, same status as the reference; the flag tells the host why a
+ *     stream went quiet.  Other streams of the batch are not affected.
+ *   - FSKHIP_PRECISION_F32 only: a finite sample so large that the fp32 I/Q branch (which runs 2^60 times larger than the
+ *     reference's values) overflows: |x * agcGain| beyond ~1e19, where the reference's doubles go on decoding.  From that call
+ *     on the stream's output is NOT the reference's (it stays quiet, like a poisoned one) and this flag is how the host learns
+ *     of it; FSKHIP_PRECISION_F64 engines follow the reference through the whole float range.
+ * Subnormal samples need no flag: both precisions follow the reference down to the last subnormal bit -- with one exception, the
+ * per-sample generic fp32 kernel (streams out of lock step, > 31 pattern bits, fractional ring capacities, "force_generic"),
+ * whose I/Q branch is not scaled: a frame below ~1e-38 of full scale is a handful of subnormal bits there, and whether it
+ * syncs on one (for the reference itself a marginal decision) can differ from the reference.
+ */
+int fskhip_get_faults(fskhip_engine *e, uint8_t *out, uint32_t *n_faulty);
 
 /*
  * Synthetic multi-stream workload generator (measurement tooling): stream s

@@ -49,6 +49,8 @@ export class FSKBatch {
   modulateData(payloads: Uint8Array[]): Float32Array[];
   reset(stream?: number): void;
   getStatus(stream?: number): FSKStatus;
+  /** 1 = the stream absorbed a NaN / Inf sample (dead from there on, like the reference's instance) or, fp32 engines, a sample beyond their range */
+  getFaults(): Uint8Array;
   enableSignalQualityEstimates(on?: boolean): void;
   getSignalQualityEstimates(stream?: number): SignalQualityEstimates;
   close(): void;

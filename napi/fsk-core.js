@@ -164,6 +164,9 @@ class FSKBatch {
   }
   reset(stream) { addon.reset(this.handle, stream === undefined ? -1 : stream); }
   getStatus(stream) { return addon.getStatus(this.handle, stream || 0); }
+  // Uint8Array[nStreams]: 1 = the stream absorbed a NaN / Inf sample (the reference's instance is dead from there on too, and the engine
+  // does what it does, bit for bit) or, fp32 engines only, a sample beyond their range (include/fskhip.h, fskhip_get_faults)
+  getFaults() { return addon.getFaults(this.handle, this.nStreams); }
   enableSignalQualityEstimates(on) { addon.enableSignalQuality(this.handle, on === undefined ? true : !!on); }
   getSignalQualityEstimates(stream) { return addon.getSignalQualityEstimates(this.handle, stream || 0); }
   close() { if (this.handle) { addon.destroy(this.handle); this.handle = null; } }

@@ -466,6 +466,24 @@ static napi_value GetStatus(napi_env env, napi_callback_info info) {
   return o;
 }
 
+// getFaults(handle) -> Uint8Array[nStreams]: 1 = the stream's filter state is no longer finite (include/fskhip.h, fskhip_get_faults)
+static napi_value GetFaults(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  fskhip_engine *e = get_engine(env, argv[0]);
+  if (!e) return nullptr;
+  uint32_t n = 0;
+  napi_get_value_uint32(env, argv[1], &n);
+  void *data = nullptr;
+  napi_value ab, arr;
+  NAPI_OK(napi_create_arraybuffer(env, n, &data, &ab));
+  int rc = fskhip_get_faults(e, n ? static_cast<uint8_t *>(data) : nullptr, nullptr);
+  if (rc != FSKHIP_OK) return throw_fsk(env, rc);
+  NAPI_OK(napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &arr));
+  return arr;
+}
+
 static napi_value DemodSupported(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
@@ -498,6 +516,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"enableSignalQuality", nullptr, EnableSignalQuality, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"getSignalQualityEstimates", nullptr, GetSignalQualityEstimates, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"getStatus", nullptr, GetStatus, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"getFaults", nullptr, GetFaults, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"demodSupported", nullptr, DemodSupported, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},
   };

@@ -53,8 +53,58 @@ class GoldenNext:
         return [bytes(data[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
 
 
+class GoldenHostile:
+    """tests/golden/golden_hostile.npz (round 6): what the REAL reference does with NaN / Inf / out-of-range / subnormal samples
+    (oracle/refrun/golden_harness_hostile.js).  status_vector: the status numbers as doubles (JSON has no NaN): frameStarted,
+    globalSampleCounter, receivedBitsLength, byteBufferLength, demodulationCalls, syncDetections, silenceThreshold,
+    totalSamplesProcessed, AGC gain."""
+
+    def __init__(self):
+        with open(os.path.join(GOLDEN_DIR, "manifest_hostile.json")) as fh:
+            self.manifest = json.load(fh)
+        self.arrays = np.load(os.path.join(GOLDEN_DIR, "golden_hostile.npz"))
+        self.cases = {c["name"]: c for c in self.manifest["cases"]}
+
+    def array(self, name):
+        return self.arrays[name]
+
+    def case_input(self, case):
+        return self.arrays[case["input"]]
+
+    def clean_input(self, case):
+        """the same two frames without the bad sample / scaling (h_<cfg>_clean)"""
+        return self.arrays[self.cases["_".join(case["name"].split("_")[:2]) + "_clean"]["input"]]
+
+
+HOSTILE_STATUS_KEYS = ["frameStarted", "globalSampleCounter", "receivedBitsLength", "byteBufferLength", "demodulationCalls",
+                       "syncDetections", "silenceThreshold", "totalSamplesProcessed", "agcGain"]
+
+
+def hostile_status_matches(st, vec, rel):
+    """st: an engine's / the oracle's status dict; vec: the reference's status_vector.  Counters exact, the two reals within rel."""
+    for i, k in enumerate(HOSTILE_STATUS_KEYS):
+        if k == "byteBufferLength":
+            continue
+        a, b = float(st[k]), float(vec[i])
+        if k in ("silenceThreshold", "agcGain"):
+            if not ((np.isnan(a) and np.isnan(b)) or a == b or abs(a - b) <= rel * abs(b)):
+                return "%s: %r vs reference %r" % (k, a, b)
+        elif a != b:
+            return "%s: %r vs reference %r" % (k, a, b)
+    return None
+
+
 _GOLDEN = None
 _GOLDEN_NEXT = None
+_GOLDEN_HOSTILE = None
+
+
+def golden_hostile():
+    global _GOLDEN_HOSTILE
+    if _GOLDEN_HOSTILE is None:
+        _GOLDEN_HOSTILE = GoldenHostile()
+    return _GOLDEN_HOSTILE
+
 
 
 def golden_next():

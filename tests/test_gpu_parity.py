@@ -745,3 +745,53 @@ def test_host_calls_after_an_odd_length_call_stay_on_whole_tiles():
             assert out[s] == ob and int(eod[s]) == oe, (s, a)
     assert all(g_ == b"Hello" for g_ in got)
     eng.close()
+
+
+def test_fp64_path_is_cut_invariant_bit_for_bit():
+    """Round 6: the exact path must be exact under ANY cut of a stream into calls, like the reference
+    (fsk-demodulation.node.test.ts:668-753 chunk sweeps) -- not only its bytes: every carried state word and every traced
+    intermediate.  Rounds 1-5 re-evaluated the fp64 NCO's phasor every 32 samples counted from the start of each CALL (and did not
+    carry it), so two cuts could differ by ~1e-14 in the I/Q branch; it is now part of the state and re-evaluated where the
+    stream's absolute sample count is a multiple of 32.  One call against ragged schedules (odd lengths, single samples, lengths
+    that put the refresh point at every position of a 16-sample block) on a noisy multi-frame batch."""
+    import webaudio_modem_amd as wm
+    g = golden()
+    base = g.array("d_noise_bell_10dB_0.in")
+    bell = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
+    S = 70
+    x = np.zeros((S, 3 * base.size + 700), np.float32)
+    for s in range(S):
+        for k in range(3):
+            o = 11 * s + k * (base.size + 97)
+            x[s, o:o + base.size] = base[:x.shape[1] - o] * (0.3 + 0.01 * s)
+    N = x.shape[1]
+    schedules = [[N], [1, 31, 17, 128, 5, 1000, 333, 2, 2, 7, 4096], [33] * 3 + [15, 1, 16, 1, 1, 13, 997], [128], [4095, 1]]
+    results = []
+    for sched in schedules:
+        eng = wm.FSKEngine(S, bell, precision=wm.PRECISION_F64)
+        eng.trace_enable(5, N // 2 + 8)
+        rows = [b""] * S
+        eods = np.zeros(S, np.int64)
+        off = ci = 0
+        while off < N:
+            n = min(sched[ci % len(sched)], N - off)
+            ci += 1
+            out, eod = eng.demodulate_data(x[:, off:off + n].copy())
+            for s in range(S):
+                rows[s] += out[s]
+            eods += np.asarray(eod, np.int64)
+            off += n
+        tr = eng.trace_read()
+        state = [eng.debug_state(s) for s in range(S)]
+        results.append((rows, eods, state, tr))
+        eng.close()
+    r0 = results[0]
+    for sched, r in zip(schedules[1:], results[1:]):
+        assert r[0] == r0[0], sched
+        assert np.array_equal(r[1], r0[1]), sched
+        for s in range(S):
+            assert np.array_equal(np.asarray(r[2][s][0]).view(np.uint64), np.asarray(r0[2][s][0]).view(np.uint64)), (sched, s)
+            assert r[2][s][1] == r0[2][s][1], (sched, s)
+        for k in ("amp", "post_out", "pre_out"):
+            assert np.array_equal(r[3][k].view(np.uint64), r0[3][k].view(np.uint64)), (sched, k)
+        assert np.array_equal(r[3]["bit"], r0[3]["bit"]), sched

@@ -182,6 +182,7 @@ def main():
         elif a == "--five":
             global FIVE
             FIVE = True
+            extra.append("-DFSK_BLK_FIVE")     # (the five-wave kernel is a measurement build's: fsk_blk.hip)
         elif a == "--dump":
             dump = True
         else:

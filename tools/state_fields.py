@@ -1,3 +1,28 @@
-"""per-stream state field names in fsk_params.h order (tools/diag_*.py; regenerate when the header changes)"""
-REAL = ['agc_gain', 'bp_x1', 'bp_x2', 'bp_y1', 'bp_y2', 'li_x1', 'li_x2', 'li_y1', 'li_y2', 'lq_x1', 'lq_x2', 'lq_y1', 'lq_y2', 'po_x1', 'po_x2', 'po_y1', 'po_y2', 'acc_i', 'acc_q', 'last_phase', 'nco_phase', 'sil_thr', 'zq_ai', 'zq_aq', 'zq_bi', 'zq_bq', 'zq_0i', 'zq_0q', 'zd_ix1', 'zd_ix2', 'zd_iy', 'zd_iv', 'zd_qx1', 'zd_qx2', 'zd_qy', 'zd_qv', 'q_signal', 'q_floor', 'q_f_sum', 'q_f2_sum', 'q_f0_sum', 'q_eye_sum']
-INT = ['nco_lo', 'nco_hi', 'ds_cnt', 'gsc', 'cad_ctr', 'sil_cnt', 'started', 'bit_acc', 'bit_wait', 'bit_reload', 'byte_cur', 'bit_pos', 'ring_len', 'poly_phase', 'matched', 'amp_pos', 'amp_len', 'sync_det', 'eod_total', 'fr_lo', 'fr_hi', 'zr_dph', 'q_armed', 'q_prev_d0', 'q_frames', 'q_bytes', 'q_minor', 'q_votes', 'q_starts', 'q_ftrans']
+"""per-stream state field names in fsk_params.h order (tools/*diag*.py, tests/test_gpu_fullsize.py) -- read from the header itself"""
+import os
+import re
+
+_HDR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "webaudio_modem_amd", "csrc", "fsk_params.h")
+
+
+def _macro_fields(text, macro):
+    m = re.search(r"#define %s\(X\)(.*?)\n(?!\s*(?:X\(|/\*|\\))" % macro, text, re.S)
+    body = m.group(1)
+    # the definition ends with the first line that does not end in a backslash
+    lines = []
+    for line in ("#define %s(X)" % macro + body).split("\n"):
+        lines.append(line)
+        if not line.rstrip().endswith("\\"):
+            break
+    body = re.sub(r"/\*.*?\*/", "", "\n".join(lines), flags=re.S)
+    return re.findall(r"X\((\w+)\)", body)[0:] if "X(" in body else []
+
+
+def _load():
+    text = open(_HDR).read()
+    real = sum((_macro_fields(text, m) for m in ("FSK_REAL_FIELDS", "FSK_REAL_FIELDS_PIPE", "FSK_REAL_FIELDS_QUALITY")), [])
+    integer = sum((_macro_fields(text, m) for m in ("FSK_INT_FIELDS", "FSK_INT_FIELDS_PIPE", "FSK_INT_FIELDS_QUALITY")), [])
+    return real, integer
+
+
+REAL, INT = _load()

@@ -75,6 +75,7 @@ _SYMBOLS = [
     ("fskhip_modulate_device", C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_size_t, _P, _P]),
     ("fskhip_reset", C.c_int, [_P, C.c_int64]),
     ("fskhip_get_status", C.c_int, [_P, C.c_uint32, C.POINTER(Status)]),
+    ("fskhip_get_faults", C.c_int, [_P, C.c_void_p, C.POINTER(C.c_uint32)]),
     ("fskhip_synth_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint32,
                                       C.c_double, C.c_double, _P]),
     ("fskhip_synth_payload_byte", C.c_uint8, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -38,6 +38,7 @@ size_t demod_blk_lds_bytes(const DemodParams &P);
 size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots);
 size_t demod_blk_lds_bytes(const DemodParams &P, uint32_t y_slots, uint32_t waves);
 bool demod_blk_applicable(const DemodParams &P);
+bool demod_blk5_built();
 hipError_t set_blk_lds_limit(const DemodParams &P);
 hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                              size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
@@ -121,6 +122,23 @@ __global__ void status_kernel(DemodState S, uint32_t n, uint32_t s, StatusRaw *o
   out->ds_cnt = S.is[(size_t)IF_ds_cnt * n + s];
 }
 
+// fskhip_get_faults: a stream whose filter state has left the finite range -- the pre-filter (never reset, fsk.ts:175-188), the
+// I/Q low-pass, the post filter.  Once a NaN is in the pre-filter's recurrence it stays, so the flag is sticky by itself.
+template <typename Real>
+__global__ void faults_kernel(DemodState S, uint32_t n, uint8_t *out, uint32_t *count) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const Real *rs = (const Real *)S.rs;
+  const int fields[] = {RF_bp_y1, RF_bp_y2, RF_bp_x1, RF_li_y1, RF_lq_y1, RF_po_y1, RF_agc_gain};
+  bool bad = false;
+  for (int f : fields) {
+    const Real v = rs[(size_t)f * n + s];
+    bad = bad || !(fabs((double)v) < (sizeof(Real) == 4 ? 1.0e38 : 1.0e300));
+  }
+  out[s] = bad ? 1 : 0;
+  if (bad) atomicAdd(count, 1u);
+}
+
 // configure(): fresh FSKCore state for every stream (fsk.ts:101-131, 175-188; AGC gain 1.0 fsk.ts:46;
 // silence.threshold 0.01 fsk.ts:128).  `matched` starts at its value for an all-zero bit history.
 template <typename Real>
@@ -131,6 +149,7 @@ __global__ void init_kernel(DemodState S, uint32_t n, uint32_t matched_zero) {
   for (int f = 0; f < RF_COUNT; f++) rs[(size_t)f * n + s] = (Real)0;
   for (int f = 0; f < IF_COUNT; f++) S.is[(size_t)f * n + s] = 0u;
   rs[(size_t)RF_agc_gain * n + s] = (Real)1.0;
+  rs[(size_t)RF_nco_c * n + s] = (Real)1.0;       // (the fp64 NCO's phasor at phase 0)
   rs[(size_t)RF_sil_thr * n + s] = (Real)0.01;
   S.is[(size_t)IF_matched * n + s] = matched_zero;
   S.is[(size_t)IF_bit_wait * n + s] = kBigWait;
@@ -148,6 +167,7 @@ __global__ void reset_kernel(DemodState S, uint32_t n, int64_t stream) {
   const int rz[] = {RF_li_x1, RF_li_x2, RF_li_y1, RF_li_y2, RF_lq_x1, RF_lq_x2, RF_lq_y1, RF_lq_y2,
                     RF_po_x1, RF_po_x2, RF_po_y1, RF_po_y2, RF_acc_i,  RF_acc_q,  RF_last_phase, RF_nco_phase};
   for (int f : rz) rs[(size_t)f * n + s] = (Real)0;
+  rs[(size_t)RF_nco_c * n + s] = (Real)1.0; rs[(size_t)RF_nco_s * n + s] = (Real)0;
   const int iz[] = {IF_nco_lo, IF_nco_hi, IF_ds_cnt, IF_gsc, IF_cad_ctr, IF_sil_cnt, IF_started, IF_bit_acc,
                     IF_bit_reload, IF_byte_cur, IF_bit_pos, IF_ring_len, IF_sync_det};
   if (sizeof(Real) == 4) {
@@ -723,7 +743,10 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
   if (k == "kernel") {          // which whole-tile kernel fp32 lock-step calls use
     const uint32_t n_blocks = e->n_blocks;
     e->use_six = 0u; e->use_five = 0u;
-    if (v == "five-wave") { e->use_blk = true; e->use_split = true; e->split_forced = true; e->use_five = 1u; }
+    if (v == "five-wave") {      // (measurement builds only: -DFSK_BLK_FIVE, fsk_blk.hip)
+      if (!demod_blk5_built()) return fail(FSKHIP_E_INVALID, "fskhip_set_option(kernel): five-wave is a measurement build's kernel (-DFSK_BLK_FIVE, profiles/r06_five_wave.txt): not in this library");
+      e->use_blk = true; e->use_split = true; e->split_forced = true; e->use_five = 1u;
+    }
     else if (v == "auto") { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; e->use_six = 2u; }
     else if (v == "auto-r04") { e->use_blk = true; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; }   // (round 4's choice: never seven waves)
     else if (v == "auto-r02") { e->use_blk = false; e->split_forced = false; e->use_split = n_blocks < e->split_cus * 8u; }
@@ -731,7 +754,7 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
     else if (v == "four-wave") { e->use_blk = true; e->use_split = true; e->split_forced = true; }
     else if (v == "two-wave") { e->use_blk = false; e->use_split = true; e->split_forced = true; }
     else if (v == "one-wave") { e->use_blk = false; e->use_split = false; e->split_forced = true; }
-    else return fail(FSKHIP_E_INVALID, "fskhip_set_option(kernel): '%s' is none of auto, auto-r04, auto-r02, seven-wave, five-wave, four-wave, two-wave, one-wave", value);
+    else return fail(FSKHIP_E_INVALID, "fskhip_set_option(kernel): '%s' is none of auto, auto-r04, auto-r02, seven-wave, four-wave, two-wave, one-wave", value);
     return FSKHIP_OK;
   }
   if (k == "blk_resets") {      // 1: the four-wave kernel's block path takes resets (default), 0: such blocks go sample by sample
@@ -974,6 +997,7 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
           HIP_TRY(launch_demod_tail(wb, true, 0, e->P, e->S, d_samples + done, n - done, pitch, d_out, out_pitch, d_out_counts, d_eod_counts, st));
       }
     } else {
+      e->P.nco_anchor = (uint32_t)(e->total_samples & 31u);   // (fp64: where the NCO phasor is re-evaluated; fsk_demod.hip, mix_lp)
       HIP_TRY(launch_demod(e->precision, e->ds_uniform, wb, append_first, e->P, e->S, d_samples, n, pitch, d_out, out_pitch,
                            d_out_counts, d_eod_counts, st));
       e->last_kernel = e->precision == FSKHIP_PRECISION_F64 ? "fsk::demod_kernel<double, ...>" : "fsk::demod_kernel<float, ...>";
@@ -1215,6 +1239,31 @@ int fskhip_get_status(fskhip_engine *e, uint32_t stream, fskhip_status *st) {
   st->totalSamplesProcessed = (double)(e->total_samples - e->base_samples[stream]);
   st->agcGain = e->P.agc_on ? r.agc_gain : std::numeric_limits<double>::quiet_NaN();
   st->eodCount = r.eod_total;
+  return FSKHIP_OK;
+}
+
+// Which streams' filter state is no longer finite (include/fskhip.h).  out: n_streams bytes (host) or null; n_faulty: host or null.
+int fskhip_get_faults(fskhip_engine *e, uint8_t *out, uint32_t *n_faulty) {
+  if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "not configured");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  uint8_t *d_out = nullptr;
+  uint32_t *d_n = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_out, e->n_streams));
+  if (hipMalloc((void **)&d_n, sizeof(uint32_t)) != hipSuccess) { (void)hipFree(d_out); return fail(FSKHIP_E_NOMEM, "fskhip_get_faults"); }
+  hipError_t err = hipMemset(d_n, 0, sizeof(uint32_t));
+  if (err == hipSuccess) {
+    const dim3 g((e->n_streams + 255) / 256), b(256);
+    if (e->precision == FSKHIP_PRECISION_F64) hipLaunchKernelGGL(faults_kernel<double>, g, b, 0, 0, e->S, e->n_streams, d_out, d_n);
+    else hipLaunchKernelGGL(faults_kernel<float>, g, b, 0, 0, e->S, e->n_streams, d_out, d_n);
+    err = hipGetLastError();
+  }
+  uint32_t n = 0;
+  if (err == hipSuccess) err = hipMemcpy(&n, d_n, sizeof(n), hipMemcpyDeviceToHost);
+  if (err == hipSuccess && out) err = hipMemcpy(out, d_out, e->n_streams, hipMemcpyDeviceToHost);
+  (void)hipFree(d_out); (void)hipFree(d_n);
+  if (err != hipSuccess) return fail(FSKHIP_E_HIP, "fskhip_get_faults: %s", hipGetErrorString(err));
+  if (n_faulty) *n_faulty = n;
   return FSKHIP_OK;
 }
 

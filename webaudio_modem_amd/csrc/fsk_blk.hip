@@ -1326,13 +1326,25 @@ __global__ __launch_bounds__(256, 4) void demod_blk_kernel_rp(
   demod_blk_body<WB, false, SL, true>(P, S, samples, n_call, pitch, append_call, out, out_pitch, out_counts, eod_counts, Z);
 }
 
-// ... and with five waves per group (round 6): the front wave's two halves on a wave each (see demod_blk_body, NW = 5)
+// ... and with five waves per group (round 6): the front wave's two halves on a wave each (see demod_blk_body, NW = 5).
+// MEASUREMENT BUILDS ONLY (-DFSK_BLK_FIVE, tools/build_variant.sh): bit-exact with the four-wave kernel but 16-19 % slower at
+// equal residency, and only three of its 320-thread workgroups are resident per CU at 96 VGPRs (profiles/r06_five_wave.txt);
+// the shipped library does not contain it and refuses kernel = five-wave.
+#ifdef FSK_BLK_FIVE
 template <bool WB, bool UNI, bool SL>
 __global__ __launch_bounds__(320, FSK_BLK5_WPE) void demod_blk5_kernel(
     DemodParams P, DemodState S, float *__restrict__ samples, size_t n_call, size_t pitch, int append_call,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
     uint32_t *__restrict__ eod_counts, BlkSched Z) {
   demod_blk_body<WB, UNI, SL, false, 5>(P, S, samples, n_call, pitch, append_call, out, out_pitch, out_counts, eod_counts, Z);
+}
+#endif
+bool demod_blk5_built() {
+#ifdef FSK_BLK_FIVE
+  return true;
+#else
+  return false;
+#endif
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -1355,13 +1367,19 @@ hipError_t set_blk_lds_limit(const DemodParams &P) {
 #define FSK_ATTR(WBV, UNIV, SLV)                                                                                 \
   if (e == hipSuccess)                                                                                           \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk_kernel<WBV, UNIV, SLV>),                  \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                            \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  FSK_ATTR(false, false, false) FSK_ATTR(false, true, false) FSK_ATTR(true, false, false) FSK_ATTR(true, true, false)
+  FSK_ATTR(false, false, true) FSK_ATTR(false, true, true) FSK_ATTR(true, false, true) FSK_ATTR(true, true, true)
+#undef FSK_ATTR
+#ifdef FSK_BLK_FIVE
+#define FSK_ATTR(WBV, UNIV, SLV)                                                                                 \
   if (e == hipSuccess)                                                                                           \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk5_kernel<WBV, UNIV, SLV>),                 \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   FSK_ATTR(false, false, false) FSK_ATTR(false, true, false) FSK_ATTR(true, false, false) FSK_ATTR(true, true, false)
   FSK_ATTR(false, false, true) FSK_ATTR(false, true, true) FSK_ATTR(true, false, true) FSK_ATTR(true, true, true)
 #undef FSK_ATTR
+#endif
 #define FSK_ATTR(WBV, SLV)                                                                                       \
   if (e == hipSuccess)                                                                                           \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk_kernel_r<WBV, SLV>),                      \
@@ -1386,11 +1404,17 @@ void demod_blk_plan(const DemodParams &P, uint32_t groups, int device, uint32_t 
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return;
   auto held = [&](uint32_t y) {
     int per_cu = 0;
+#ifdef FSK_BLK_FIVE
     const hipError_t oe = waves == 5u
         ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&demod_blk5_kernel<false, true, true>), 320,
                                                        demod_blk_lds_bytes(P, y, 5u))
         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&demod_blk_kernel<false, true, true>), 256,
                                                        demod_blk_lds_bytes(P, y));
+#else
+    if (waves == 5u) return 0u;
+    const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&demod_blk_kernel<false, true, true>), 256,
+                                                                       demod_blk_lds_bytes(P, y));
+#endif
     if (oe != hipSuccess) return 0u;
     return per_cu > 0 ? (uint32_t)per_cu : 0u;
   };
@@ -1449,7 +1473,7 @@ hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, c
                              uint32_t *eod_counts, hipStream_t stream, uint32_t resident_wgs, uint32_t slice_tiles, uint32_t y_slots,
                              uint32_t lanes, uint32_t medium, bool *sliced_out, uint32_t waves) {
   lanes = (lanes == 8u || lanes == 16u || lanes == 32u) ? lanes : 64u;
-  if (medium != 0u) waves = 4u;                               // (the kernels whose block path takes resets have four waves)
+  if (medium != 0u || !demod_blk5_built()) waves = 4u;        // (the kernels whose block path takes resets have four waves)
   const uint32_t blocks = (P.n_streams + lanes - 1u) / lanes;
   y_slots = y_slots < kBlkSlots ? kBlkSlots : y_slots > kBlkYMax ? kBlkYMax : y_slots;
   const size_t lds = demod_blk_lds_bytes(P, y_slots, waves);
@@ -1489,6 +1513,7 @@ hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, c
     return hipGetLastError();
   }
 #undef FSK_LAUNCH_BLKRP
+#ifdef FSK_BLK_FIVE
 #define FSK_LAUNCH_BLK5(WBV, UNIV, SLV)                                                                         \
   hipLaunchKernelGGL((demod_blk5_kernel<WBV, UNIV, SLV>), dim3(grid), dim3(320), lds, stream, P, S, samples, n, pitch, \
                      append ? 1 : 0, out, out_pitch, out_counts, eod_counts, Z)
@@ -1503,6 +1528,7 @@ hipError_t launch_demod_blk(bool writeback, bool append, const DemodParams &P, c
     return hipGetLastError();
   }
 #undef FSK_LAUNCH_BLK5
+#endif
   if (sliced) {
     if (writeback) { if (uni) FSK_LAUNCH_BLK(true, true, true); else FSK_LAUNCH_BLK(true, false, true); }
     else { if (uni) FSK_LAUNCH_BLK(false, true, true); else FSK_LAUNCH_BLK(false, false, true); }

@@ -663,7 +663,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
 #pragma unroll
       for (int j = 0; j < kBlk; j++) {
         const float f = disc_post(B, K, phs[j], am[j]);                        // fsk.ts:251-261
-        nf[j] = 0.0f - f;                                                      // slicer (fsk.ts:264): the bit is this value's sign
+        nf[j] = slicer_nf(f);                                                   // slicer (fsk.ts:264): the bit is this value's sign
       }
       ft[lane] = (v4f){nf[0], nf[1], nf[2], nf[3]}; ft[64u + lane] = (v4f){nf[4], nf[5], nf[6], nf[7]};
       ft[128u + lane] = (v4f){am[0], am[1], am[2], am[3]}; ft[192u + lane] = (v4f){am[4], am[5], am[6], am[7]};

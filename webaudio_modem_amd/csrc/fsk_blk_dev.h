@@ -104,7 +104,7 @@ __device__ inline uint32_t blk_fast(BackLane &Bn, const BackK &K, const BlkK &Q,
     const float f = disc_post(Bn, K, phs[j], am[j]);                        // fsk.ts:251-261
     // slicer (fsk.ts:264): the bit is the sign of 0 - f (f = +-0 gives +0, bit 0); it is shifted into the registers
     // straight from there (v_alignbit: {hi, lo} >> 31 = hi << 1 | sign of lo) without being extracted first
-    const uint32_t nf = __builtin_bit_cast(uint32_t, 0.0f - f);
+    const uint32_t nf = __builtin_bit_cast(uint32_t, slicer_nf(f));
     const uint32_t rold = rp[j];
     const uint32_t r = __builtin_amdgcn_alignbit(rold, nf, 31);              // syncSamplesBuffer.put(bit)
     rp[j] = r;
@@ -225,8 +225,7 @@ __device__ __forceinline__ void med_sample(BackLane &Bn, const BackK &K, const i
     am_j = bself(m_own, a2, e1);
     // ---- discriminator tail, slicer, correlator, silence run (as blk_fast)
     const float f = disc_post(Bn, K, ph, am_j);
-    const uint32_t nf = __builtin_bit_cast(uint32_t, 0.0f - f);
-    
+    const uint32_t nf = __builtin_bit_cast(uint32_t, slicer_nf(f));
     const uint32_t r = __builtin_amdgcn_alignbit(rold, nf, 31);
     matched += (uint32_t)__builtin_popcount((r ^ K.qn) & K.mask);
     matched -= (uint32_t)__builtin_popcount((rold ^ K.qn) & K.mask);

@@ -116,7 +116,6 @@ struct Lane {
   FSK_INT_FIELDS(X)
 #undef X
   uint32_t thr_eff;  // matched_min while searching, 0xFFFFFFFF while a frame is started (not stored)
-  Real nco_c, nco_s; // fp64: cos / sin of nco_phase, carried by rotation between refreshes (not stored; see mix_lp)
 };
 
 template <typename Real>
@@ -299,8 +298,12 @@ __device__ inline float pre_stage(Lane<double> &L, const Consts<double> &C, bool
 // The NCO.  The reference evaluates Math.cos / Math.sin of localOscPhase and advances it by `(phase + omega) % (2 pi)`
 // every sample.  The phase itself is kept exactly as the reference has it (for 0 <= omega < 2 pi the `%` is one
 // conditional subtraction, exact by Sterbenz' lemma, so nco_phase is bit for bit the reference's at every sample); its
-// cosine and sine are carried as a phasor that is ROTATED by e^{j omega} each sample (four FMAs) and re-evaluated from the
-// exact phase by nco_refresh() at every tile boundary (32 samples) and set to exactly (1, 0) by a reset.  Between two
+// cosine and sine are carried as a phasor that is ROTATED by e^{j omega} each sample (four FMAs), re-evaluated from the
+// exact phase by nco_refresh() wherever the stream's ABSOLUTE sample count (samples since the engine was created: the same
+// for every stream) is a multiple of 32, and set to exactly (1, 0) by a reset.  The phasor is part of the stream's state
+// (nco_c, nco_s: round 6), so its value at any sample is a function of the samples before it alone: cutting a stream into
+// calls anywhere changes no fp64 intermediate, bit for bit (rounds 1-5 refreshed every 32 samples counted from the start of
+// each call and did not store the phasor: intermediates could differ by ~1e-14 between two cuts).  Between two
 // refreshes the phasor drifts from the true cos / sin of nco_phase by at most 32 x (the `+`'s rounding 4.4e-16 + the
 // rotation's 2e-16) = 2e-14, against the 1e-12 the fp64 intermediates are held to; evaluating both functions afresh per
 // sample (the device library's: ~150 instructions and a dozen branches) was 60 % of this kernel's time.
@@ -941,8 +944,12 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
   const bool fast16 = fast && sizeof(Real) == 8 && P.d >= 8 && P.cadence > 0 && !P.quality;
   bool cur_fast = n > 0 && tile_is_fast(0);
   if (cur_fast) load_tile_fast(0);
+  // fp64: the NCO phasor afresh from the exact phase (mix_lp) where the stream's absolute sample count is a multiple of 32 -- sample
+  // nco_r0 of every tile of this call (tiles are 32 samples; P.nco_anchor = samples the engine had taken before the call, mod 32)
+  static_assert(kTile == 32, "the NCO refresh period is a tile");
+  const uint32_t nco_r0 = sizeof(Real) == 8 ? ((32u - (P.nco_anchor & 31u)) & 31u) : 0u;
   for (size_t t0 = 0; t0 < n; t0 += kTile) {
-    nco_refresh(L, C);   // fp64: the NCO phasor afresh from the exact phase (mix_lp)
+    if (nco_r0 == 0u) nco_refresh(L, C);
     __syncthreads();  // single-wave workgroup: orders last tile's LDS reads before the overwrite
     if (cur_fast) {
 #pragma unroll
@@ -961,7 +968,13 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
       float xv[4] = {v4.x, v4.y, v4.z, v4.w};
       float wb[4];
       const uint32_t lim = tile_len - 4u * c < 4u ? tile_len - 4u * c : 4u;
-      if (sizeof(Real) == 8 && !FRAC && fast16 && (c & 3u) == 0u && 4u * c + 16u <= tile_len) {
+      // (a call that does not start on the refresh grid -- earlier calls of lengths that are no multiples of 32 -- has its refresh
+      // point inside the tile: at the start of a block where it can be, else that block goes chunk by chunk / sample by sample)
+      const uint32_t s0 = 4u * c;
+      if (sizeof(Real) == 8 && nco_r0 != 0u && nco_r0 == s0) nco_refresh(L, C);
+      const bool r_in16 = sizeof(Real) == 8 && nco_r0 > s0 && nco_r0 < s0 + 16u;
+      const bool r_in4 = sizeof(Real) == 8 && nco_r0 > s0 && nco_r0 < s0 + 4u;
+      if (sizeof(Real) == 8 && !FRAC && fast16 && (c & 3u) == 0u && 4u * c + 16u <= tile_len && !r_in16) {
         float x16[16], wb16[16];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -984,13 +997,14 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
         c += 3;
         continue;
       }
-      if (fast && lim == 4u) {
+      if (fast && lim == 4u && !r_in4) {
         block4(xv, wb);
       } else {
         const float *xs = reinterpret_cast<const float *>(&stage[c * kSlotStride + lane]);
 #pragma unroll 1
         for (uint32_t k = 0; k < lim; k++) {
           float w;
+          if (r_in4 && s0 + k == nco_r0) nco_refresh(L, C);
           step_generic(xs[k], w);
           if (writeback && valid) samples[(size_t)row * pitch + t0 + 4u * c + k] = w;
         }

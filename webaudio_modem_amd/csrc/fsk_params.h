@@ -19,6 +19,8 @@ namespace fsk {
   X(acc_i) X(acc_q)                     /* downsample.{i,q}Accumulator fsk.ts:105-109 */    \
   X(last_phase)                         /* iqState.lastPhase fsk.ts:102 */                  \
   X(nco_phase)                          /* iqState.localOscPhase (f64 path only) */         \
+  X(nco_c) X(nco_s)                     /* f64 path: cos / sin of nco_phase as the rotated phasor stands (round 6: carried across */ \
+                                        /* calls, re-evaluated where the stream's ABSOLUTE sample count is a multiple of 32) */ \
   X(sil_thr)                            /* silence.threshold fsk.ts:128 */
 // fp32 engines keep the I/Q low-pass in a FREE-RUNNING frame (fsk_pipe.hip): li_*, lq_*, last_phase are that frame's.
 // After a resetState() the next kDirectPairs decimated samples come from a zero-started direct instance zd_* (zr_dph =
@@ -117,6 +119,7 @@ struct DemodParams {
   float f_lp_b0, f_lp_b0h, f_lp_a2, f_lp_delta, f_agc_att, f_agc_rel;
   // uni_cfg = 1: every stream shares one configuration, so what is otherwise a per-stream array entry is a
   // wave-uniform constant (SGPRs instead of VGPRs in the fast kernel)
+  uint32_t nco_anchor;    // fp64 generic kernel: samples the engine had taken before this call, mod 32 (where the NCO phasor is re-evaluated)
   uint32_t uni_cfg;
   float u_bp_b0h;                  // pre-filter b0 with the low-pass gain b0/2 folded in
   float u_bp_na1, u_bp_na2;        // -a1, -a2

@@ -197,6 +197,17 @@ __device__ inline uint32_t neg_mask(uint32_t v) {
   asm("" : "+v"(m));
   return m;
 }
+// The slicer (fsk.ts:264: bitValue = filteredPhaseDiff > 0 ? 1 : 0) as a value whose SIGN BIT is the bit -- what the kernels shift
+// into the polyphase registers (v_alignbit) without extracting it.  Round 6: 0 - clamp(4 f) instead of 0 - f.  clamp(4 f) is in
+// (0, 1] exactly when f > 0 (denormals are kept: a subnormal f gives a subnormal product) and +0 for f <= 0, f = +-0 AND f = NaN
+// (the kernels run with DX10_CLAMP = 1: a clamped result of NaN is 0) -- `NaN > 0` is false in the reference, whereas the sign of
+// 0 - NaN is the NaN's own, flipped: a stream poisoned by a +NaN sample sliced ones where the reference slices zeros
+// (tests/golden/golden_hostile.npz, h_*_qnan_mid).  One more full-rate instruction per decimated sample.
+__device__ inline float slicer_nf(float f) {
+  float r;
+  asm("v_mul_f32 %0, 4.0, %1 clamp" : "=v"(r) : "v"(f));
+  return 0.0f - r;
+}
 __device__ inline uint32_t sign_bit(uint32_t v) {
   uint32_t m = v >> 31;
   asm("" : "+v"(m));
@@ -456,7 +467,7 @@ __device__ inline void back_pair(BackLane &B, const BackK &K, const DemodParams 
   // ---- discriminator (fsk.ts:251-264)
   const float f = disc_post(B, K, ph, amp);
   // slicer (fsk.ts:264): f > 0  <=>  sign bit of 0 - f  (f = +-0 gives +0, i.e. bit 0)
-  const uint32_t bit = sign_bit(__builtin_bit_cast(uint32_t, 0.0f - f));
+  const uint32_t bit = sign_bit(__builtin_bit_cast(uint32_t, slicer_nf(f)));
   if (TRC) {
     if (S.trace_stream != 0xFFFFFFFFu && M.voff == S.trace_stream * 4u) {
       const uint32_t kk = *S.trace_n;

@@ -237,6 +237,19 @@ class FSKEngine:
         _lib.check(self._L.fskhip_get_status(self._h, stream, C.byref(st)))
         return _status_dict(st)
 
+    def faults(self):
+        """uint8[S]: 1 = the stream's filter state is no longer finite (fskhip_get_faults): it absorbed a NaN / Inf sample -- the
+        reference's instance is dead from there on too, and the engine does what it does -- or, fp32 engines only, a sample beyond
+        their range (~1e19)."""
+        out = np.zeros(self.n_streams, np.uint8)
+        n = C.c_uint32(0)
+        _lib.check(self._L.fskhip_get_faults(self._h, out.ctypes.data, C.byref(n)))
+        assert int(out.sum()) == n.value
+        return out
+
+    def fault(self, stream=0):
+        return bool(self.faults()[stream])
+
     # ---- opt-in signal-quality estimates (include/fskhip.h; the reference's getSignalQuality() returns zeros) -------
     def enable_signal_quality(self, on=True):
         _lib.check(self._L.fskhip_enable_signal_quality(self._h, 1 if on else 0))
