@@ -534,6 +534,23 @@ def worker(args):
                 eng.add_awgn_device(x.data_ptr(), N, pitch, snr, seed ^ 0xA36, stream)
         torch.cuda.synchronize()
 
+        def fill_idle(e_, idle_db):
+            # (--workload idle's generator, for the side measurement below: one frame per stream, zeros, a noise floor idle_db under the frame)
+            import math
+            frame_len = e_.modulated_length(wl["payload"])
+            lead_max = 10 * spb
+            n0 = min(N, (lead_max + frame_len + 31) // 32 * 32)
+            x.zero_()
+            e_.synth_device(x.data_ptr(), n0, pitch, wl["payload"], seed, lead_max, 0.1, 1.0, stream)
+            torch.cuda.synchronize()
+            ends = np.array([e_.synth_stream_params(seed, s_, lead_max, 0.1, 1.0)[0] for s_ in range(S)], np.int64) + frame_len
+            c0 = int(ends.min())
+            if c0 < n0:
+                cols = torch.arange(c0, n0, device="cuda")
+                x[:, c0:n0] *= (cols[None, :] < torch.as_tensor(ends, device="cuda")[:, None])
+            e_.add_awgn_device(x.data_ptr(), N, pitch, idle_db - 10.0 * math.log10(N / float(frame_len)), seed ^ 0xA36, stream)
+            torch.cuda.synchronize()
+
         def step():
             eng.demodulate_device(x.data_ptr(), N, pitch, out.data_ptr(), out_pitch, counts.data_ptr(), eod.data_ptr(),
                                   0, stream)
@@ -773,6 +790,83 @@ def worker(args):
             del hp
         except Exception as ex:
             side["pcie_inclusive"] = {"error": str(ex)}
+        # (4) the batched generic IIRFilter (SURVEY 8 row a3 / f3', filters.ts:8-106: fskhip_iir_*): order-2 Butterworth low-pass,
+        # processBuffer semantics (f32 in / out), 8 B per sample against the HBM roofline -- VERDICT r05 #7: a driver-recorded number
+        try:
+            iir = {}
+            co = wm.FilterDesign.butterworthLowpass(1200, 48000)
+            n_i = 48000
+            for s_i in (65536, 16384):
+                xi = torch.randn((s_i, n_i), dtype=torch.float32, device="cuda")
+                yi = torch.empty_like(xi)
+                for pname, pv in (("f32", wm.PRECISION_F32), ("f64", wm.PRECISION_F64)):
+                    flt = wm.IIRFilterBatch(co["b"], co["a"], s_i, precision=pv)
+                    flt.process_device(xi.data_ptr(), n_i, n_i, yi.data_ptr(), n_i, stream)
+                    sync()
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                    for _ in range(5):
+                        flt.process_device(xi.data_ptr(), n_i, n_i, yi.data_ptr(), n_i, stream)
+                    ev1.record()
+                    sync()
+                    ms_i = ev0.elapsed_time(ev1) / 5
+                    r_i = s_i * n_i / (ms_i / 1e3) / 1e6
+                    iir["%d_%s" % (s_i, pname)] = {"Msamples_per_s": round(r_i, 1), "GB_per_s": round(r_i * 8 / 1e3, 1),
+                                                   "frac_of_hbm_peak": round(r_i * 8 / 1e3 / HBM_PEAK_GBS, 4), "avg_kernel_ms": round(ms_i, 4)}
+                    flt.close()
+                del xi, yi
+            iir["note"] = ("fsk::iir_kernel, order 2 (butterworthLowpass(1200, 48000)), %d samples per stream, f32 in / out = 8 algorithmic bytes per sample; "
+                           "torch events on the launch stream (the call's stream argument is torch's current stream)" % n_i)
+            side["iir"] = iir
+        except Exception as ex:
+            side["iir"] = {"error": str(ex)}
+        # (5) the unfavourable shapes of the SAME batch size: the resident buffer regenerated in place, LAST (nothing
+        # above needs the headline's signal any more).  staggered: every stream's frames at a random offset within one frame length
+        # (a reset in some lane of a wave every few tiles; the headline's streams all start within ten bit cells of one another);
+        # idle: ONE frame per stream, then a noise floor 30 dB under it (every stream fires 'eod' on its own schedule).  Each with
+        # the kernel the library chose and its own oracle check of a strided sample of the first pass.
+        for sname in ("staggered", "idle"):
+            try:
+                es = wm.FSKEngine(S, cfg, device=local_rank, precision=prec)
+                frame_len_s = es.modulated_length(wl["payload"])
+                if sname == "staggered":
+                    es.synth_device(x.data_ptr(), N, pitch, wl["payload"], seed, frame_len_s, 0.1, 1.0, stream)
+                    torch.cuda.synchronize()
+                else:
+                    fill_idle(es, 30.0)
+
+                def step_u():
+                    es.demodulate_device(x.data_ptr(), N, pitch, out.data_ptr(), out_pitch, counts.data_ptr(), eod.data_ptr(), 0, stream)
+                step_u()
+                sync()
+                chk = {"streams_checked": 0, "streams_byte_identical": 0}
+                if args.cpu_seconds > 0:
+                    from oracle import pyoracle as po
+                    rows_u = np.unique(np.linspace(0, S - 1, int(max(4, min(S, 0.4 * args.cpu_seconds * 7.0e6 // N)))).astype(np.int64))
+                    idx_u = torch.as_tensor(rows_u, device="cuda")
+                    xs_u = x.index_select(0, idx_u)[:, :N].cpu().numpy()
+                    b_u = out.index_select(0, idx_u).cpu().numpy()
+                    c_u = counts.index_select(0, idx_u).cpu().numpy().astype(np.int64)
+                    e_u = eod.index_select(0, idx_u).cpu().numpy().astype(np.int64)
+                    same_u = 0
+                    for j in range(len(rows_u)):
+                        ob, oe = po.OracleCore(cfg).demodulate(xs_u[j])
+                        same_u += (ob == b_u[j, :c_u[j]].tobytes()) and (oe == int(e_u[j]))
+                    chk = {"streams_checked": int(len(rows_u)), "streams_byte_identical": int(same_u)}
+                    if same_u != len(rows_u):
+                        parity_ok = False
+                for _ in range(2):                       # (the kernel choice by tile statistics settles, as for the headline)
+                    step_u()
+                    sync()
+                nl, ms = timed_steps(sync, es, step_u, k_side)
+                r = S * N * nl / (ms / 1e3) / 1e6
+                side[sname] = {"streams": S, "samples_per_stream": N, "kernel": es.last_kernel(), "Msamples_per_s": round(r, 1),
+                               "frac_of_hbm_peak": round(r * 4 / 1e3 / HBM_PEAK_GBS, 4), "avg_kernel_ms": round(ms / max(1, nl), 4), **chk,
+                               "signal": ("lead_max_samples = %d (one frame length): frames -- and resets -- do not line up across a wave" % frame_len_s) if sname == "staggered"
+                               else "one frame per stream, then a Gaussian floor 30 dB under it: every stream fires 'eod' each samplesForEOD decimated samples on its own schedule"}
+                es.close()
+            except Exception as ex:
+                side[sname] = {"error": str(ex)}
 
     total_samples = float(total_streams) * N * args.steps if strong_only else float(streams_all) * N * args.steps
     value = total_samples / elapsed / 1e6
@@ -783,7 +877,7 @@ def worker(args):
 
     def committed(name):
         """a committed profile of THIS kernel (profiles/<round>_<name>.json): the newest round that has one"""
-        for rnd in ("r05", "r04", "r03", "r02"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02"):
             pth = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
             if os.path.exists(pth):
                 with open(pth) as fh:
@@ -818,7 +912,11 @@ def worker(args):
         valu_per_s = ij["insts_per_group_sample"]["valu"] * groups * N / avg_kernel_s
         peak = SIMDS * clk * 1e9 / 2.0
         issue = {"bound": "valu_issue", "achieved": round(valu_per_s / 1e9, 1), "peak": round(peak / 1e9, 1), "unit": "Ginst/s",
-                 "frac": round(valu_per_s / peak, 4), "clock_ghz_measured": round(clock_ghz, 3) if clock_ghz else None,
+                 "frac": round(valu_per_s / peak, 4),
+                 # (tools/valu_probe has four waves retire a full-rate instruction per 1.74 cycles, not 2.0)
+                 "frac_probe": round(valu_per_s / (SIMDS * clk * 1e9 / 1.74), 4),
+                 "frac_probe_definition": "the same against one wave64 vector instruction per 1.74 cycles per SIMD (tools/valu_probe, four waves per SIMD)",
+                 "clock_ghz_measured": round(clock_ghz, 3) if clock_ghz else None,
                  "clock_note": clk_note,
                  "insts_per_group_sample": ij["insts_per_group_sample"],
                  "measured_ns_per_sample": round(ns, 1),
@@ -832,6 +930,7 @@ def worker(args):
             avail = ns * clk * SIMDS / groups
             priced = {"bound": "valu_class_priced", "achieved": round(pc, 1), "peak": round(avail, 1),
                       "unit": "SIMD cycles per group-sample (priced / available)", "frac": round(pc / avail, 4),
+                      "frac_probe": round(pc * (1.74 / 2.0) / avail, 4),
                       "source": ij.get("class_priced_source", isrc)}
     hbm_frac = achieved / HBM_PEAK_GBS
     fr = {"hbm": hbm_frac, "valu_issue": issue["frac"] if issue else 0.0, "valu_class_priced": priced["frac"] if priced else 0.0}

@@ -304,8 +304,9 @@ int fskhip_timing_end(fskhip_engine *e, uint32_t *n_launches, double *total_ms);
  *                    "stage_min_tiles" tiles, four waves (demod_blk_kernel / _r / _rp) otherwise wherever they apply;
  *                    auto-r04: never seven ("six-wave" was this kernel's name before it had seven)
  *   "stage_min_tiles" n             calls with fewer whole tiles stay off the seven-wave kernel (default 8: one 128-sample quantum)
- *   "stage_y_slots"  6 .. 24        depth of the seven-wave kernel's y ring (default: what the LDS of a compute unit allows; at least 2 + the
- *                                   half tiles its iq wave may lead the frame wave by)
+ *   "stage_y_slots"  14 .. 24, even  depth of the seven-wave kernel's y ring in half tiles (default and upper limit: what the LDS of a compute
+ *                                   unit allows at this dsSPB; lower limit: 2 + the half tiles its iq wave may lead the frame wave by).  Values
+ *                                   outside what the kernel can use are FSKHIP_E_INVALID, as for blk_y_slots (they used to be clamped silently)
  *   "stage_roles"    auto | seven digits, a permutation of 0..6: the part each of a workgroup's seven waves plays (measurements)
  *   "force_generic"  0 | 1          never a whole-tile kernel: the sample-serial kernel only
  *   "blk_y_slots"    6 .. 28        depth of the four-wave kernel's first ring (checked against the LDS it needs)
@@ -339,7 +340,9 @@ int fskhip_clock_probe_end(fskhip_engine *e, double *shader_ghz, double *covered
  * played exactly once: the waves settle their parts among themselves at the start), so the wait ends -- but a lost counter
  * update would be a hung kernel, not an error code.  Hosts that need a bound put one on the stream (hipStreamQuery / an
  * event with a timeout) as they would for any kernel; tools/six_check.py and the soak run every case in a child process under
- * a timeout for that reason.
+ * a timeout for that reason.  Round 6: the seven-wave kernel checks once per launch, in every wave, that its part map is a
+ * permutation (a bad one ends the launch at once, bit 30 of the engine's second statistics word set), and a debug build
+ * (-DFSK_SPIN_CAP=<polls>) bounds every one of its polls: a wave that runs into the cap sets bit 31 of that word and ends.
  */
 const char *fskhip_last_error(void);
 int fskhip_abi_version(void);

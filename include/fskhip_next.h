@@ -154,6 +154,7 @@ int fskhip_sinc_bandpass(double center, double bandwidth, double sampleRate, uin
 int fskhip_fir_create(int device, const double *taps, uint32_t n_taps, uint32_t n_streams, int precision,
                       fskhip_fir **out);
 int fskhip_fir_destroy(fskhip_fir *f);
+uint32_t fskhip_fir_streams(const fskhip_fir *f);   /* the n_streams it was created for (0 for NULL); ABI 7 */
 /* processBuffer(input) (filters.ts:142-148) for every stream: out[s][t] = f32(sum_i c[i] * x_s[t-i]), the delay
  * line carried across calls.  in/out are [n_streams][pitch] float32 and may not alias. */
 int fskhip_fir_process_device(fskhip_fir *f, const float *d_in, size_t n_per_stream, size_t in_pitch, float *d_out,
@@ -176,11 +177,12 @@ typedef struct fskhip_iir fskhip_iir;
  * cannot be zero'); coefficients are normalised by a[0] exactly as filters.ts:30-39 does (b[i] /= a0, a[i] /= a0 for
  * i >= 1).  More than 9 coefficients on either side: FSKHIP_E_UNSUPPORTED (the kernel keeps eight past inputs and outputs
  * in registers).  precision: FSKHIP_PRECISION_F64 evaluates output += b[i] * x[n-i], output -= a[i] * y[n-i] in doubles
- * in the reference's order, every product and sum rounded on its own (bit-identical results), FSKHIP_PRECISION_F32 in
- * floats with FMAs. */
+ * in the reference's order, every product and sum rounded on its own (bit-identical results), FSKHIP_PRECISION_F32 the same
+ * operations in floats (separate multiplies and adds: the library is built with -ffp-contract=off). */
 int fskhip_iir_create(int device, const double *b, uint32_t nb, const double *a, uint32_t na, uint32_t n_streams,
                       int precision, fskhip_iir **out);
 int fskhip_iir_destroy(fskhip_iir *f);
+uint32_t fskhip_iir_streams(const fskhip_iir *f);   /* the n_streams it was created for (0 for NULL); ABI 7 */
 /* getCoefficients() (filters.ts:103-105): the normalised sets; b and a must hold 9 doubles each. */
 int fskhip_iir_get_coefficients(const fskhip_iir *f, double *b, uint32_t *nb, double *a, uint32_t *na);
 /* processBuffer(input) (filters.ts:81-87) for every stream: out[s][t] = f32(process(in[s][t])), the histories carried

@@ -18,6 +18,12 @@ class FilterDesign {
   static sincBandpass(centerFreq, bandwidth, sampleRate, numTaps) { return Array.from(addon.sincBandpass(centerFreq, bandwidth, sampleRate, numTaps)); }
 }
 
+// [nStreams][n] in one typed array: n, or an error for a length that is not a whole number of samples per stream
+function samplesPerStream(input, nStreams) {
+  if (input.length % nStreams !== 0) throw new RangeError('input length ' + input.length + ' is not a multiple of the stream count ' + nStreams);
+  return input.length / nStreams;
+}
+
 class FIRFilterBatch {
   constructor(coefficients, nStreams = 1, options = {}) {
     this.coefficients = [...coefficients];
@@ -27,7 +33,7 @@ class FIRFilterBatch {
   }
   // input: Float32Array [nStreams][n]
   processBuffer(input) {
-    const n = input.length / this.nStreams;
+    const n = samplesPerStream(input, this.nStreams);
     if (n === 0) return new Float32Array(0);
     return addon.firProcess(this.handle, input, n, n, this.nStreams);
   }
@@ -53,13 +59,13 @@ class IIRFilterBatch {                            // filters.ts:8-106, S streams
   }
   // Float32Array [nStreams][n] -> Float32Array (processBuffer, filters.ts:81-87)
   processBuffer(input) {
-    const n = input.length / this.nStreams;
+    const n = samplesPerStream(input, this.nStreams);
     if (n === 0) return new Float32Array(0);
     return addon.iirProcess(this.handle, input, n, n, this.nStreams);
   }
   // Float64Array [nStreams][n] -> Float64Array: what process() returns sample by sample (nothing rounded to float)
   processSamples(input) {
-    const n = input.length / this.nStreams;
+    const n = samplesPerStream(input, this.nStreams);
     if (n === 0) return new Float64Array(0);
     return addon.iirProcess(this.handle, input, n, n, this.nStreams);
   }

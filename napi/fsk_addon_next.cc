@@ -69,6 +69,32 @@ void *external(napi_env env, napi_value v, const char *what) {
   if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_error(env, nullptr, what); return nullptr; }
   return p;
 }
+// FIR / IIR filter handles: the external owns a box, so that close() can empty it (a later call throws instead of touching freed
+// memory) and a filter that is never close()d is destroyed when the garbage collector drops the handle
+struct FilterBox { void *p; bool iir; };
+void filter_box_finalize(napi_env, void *data, void *) {
+  FilterBox *b = (FilterBox *)data;
+  if (b->p) { if (b->iir) fskhip_iir_destroy((fskhip_iir *)b->p); else fskhip_fir_destroy((fskhip_fir *)b->p); }
+  delete b;
+}
+napi_value filter_box_new(napi_env env, void *p, bool iir) {
+  FilterBox *b = new FilterBox{p, iir};
+  napi_value ext;
+  if (napi_create_external(env, b, filter_box_finalize, nullptr, &ext) != napi_ok) { filter_box_finalize(env, b, nullptr); return nullptr; }
+  return ext;
+}
+void *filter_of(napi_env env, napi_value v) {
+  FilterBox *b = (FilterBox *)external(env, v, "filter destroyed");
+  if (!b) return nullptr;
+  if (!b->p) { napi_throw_error(env, nullptr, "filter destroyed"); return nullptr; }
+  return b->p;
+}
+void filter_box_close(napi_env env, napi_value v) {
+  void *q = nullptr;
+  if (napi_get_value_external(env, v, &q) != napi_ok || !q) return;
+  FilterBox *b = (FilterBox *)q;
+  if (b->p) { if (b->iir) fskhip_iir_destroy((fskhip_iir *)b->p); else fskhip_fir_destroy((fskhip_fir *)b->p); b->p = nullptr; }
+}
 void set_u32(napi_env env, napi_value obj, const char *k, uint32_t v) {
   napi_value n;
   napi_create_uint32(env, v, &n);
@@ -295,23 +321,21 @@ napi_value FirCreate(napi_env env, napi_callback_info info) {
   fskhip_fir *f = nullptr;
   int rc = fskhip_fir_create(i32(env, argv[2]), (const double *)taps, (uint32_t)nt, u32(env, argv[1]), i32(env, argv[3]), &f);
   if (rc != FSKHIP_OK) return throw_fsk(env, rc);
-  napi_value ext;
-  NAPI_OK(napi_create_external(env, f, nullptr, nullptr, &ext));
-  return ext;
+  return filter_box_new(env, f, false);
 }
 napi_value FirDestroy(napi_env env, napi_callback_info info) {
   ARGS(1);
-  void *p = nullptr;
-  if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) fskhip_fir_destroy((fskhip_fir *)p);
+  filter_box_close(env, argv[0]);
   return nullptr;
 }
 napi_value FirProcess(napi_env env, napi_callback_info info) {
   ARGS(5);
-  fskhip_fir *f = (fskhip_fir *)external(env, argv[0], "filter destroyed");
+  fskhip_fir *f = (fskhip_fir *)filter_of(env, argv[0]);
   if (!f) return nullptr;
   void *in; size_t ilen;
   if (!typed(env, argv[1], napi_float32_array, &in, &ilen)) return nullptr;
   const uint32_t n = u32(env, argv[2]), pitch = u32(env, argv[3]), S = u32(env, argv[4]);
+  if (S != fskhip_fir_streams(f)) { napi_throw_range_error(env, nullptr, "nStreams is not the filter's stream count"); return nullptr; }
   if (S == 0 || pitch < n || (size_t)pitch * (S - 1) + n > ilen) { napi_throw_range_error(env, nullptr, "input too short"); return nullptr; }
   void *out;
   napi_value out_v = make_typed(env, napi_float32_array, (size_t)n * S, 4, &out);
@@ -321,7 +345,7 @@ napi_value FirProcess(napi_env env, napi_callback_info info) {
 }
 napi_value FirReset(napi_env env, napi_callback_info info) {
   ARGS(2);
-  fskhip_fir *f = (fskhip_fir *)external(env, argv[0], "filter destroyed");
+  fskhip_fir *f = (fskhip_fir *)filter_of(env, argv[0]);
   if (!f) return nullptr;
   int64_t s = -1;
   napi_get_value_int64(env, argv[1], &s);
@@ -338,19 +362,16 @@ napi_value IirCreate(napi_env env, napi_callback_info info) {   // (b: Float64Ar
   fskhip_iir *f = nullptr;
   int rc = fskhip_iir_create(i32(env, argv[3]), (const double *)b, (uint32_t)nb, (const double *)a, (uint32_t)na, u32(env, argv[2]), i32(env, argv[4]), &f);
   if (rc != FSKHIP_OK) return throw_fsk(env, rc);
-  napi_value ext;
-  NAPI_OK(napi_create_external(env, f, nullptr, nullptr, &ext));
-  return ext;
+  return filter_box_new(env, f, true);
 }
 napi_value IirDestroy(napi_env env, napi_callback_info info) {
   ARGS(1);
-  void *p = nullptr;
-  if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) fskhip_iir_destroy((fskhip_iir *)p);
+  filter_box_close(env, argv[0]);
   return nullptr;
 }
 napi_value IirCoefficients(napi_env env, napi_callback_info info) {   // -> Float64Array [nb, na, b..., a...]
   ARGS(1);
-  fskhip_iir *f = (fskhip_iir *)external(env, argv[0], "filter destroyed");
+  fskhip_iir *f = (fskhip_iir *)filter_of(env, argv[0]);
   if (!f) return nullptr;
   double b[9], a[9];
   uint32_t nb = 0, na = 0;
@@ -366,7 +387,7 @@ napi_value IirCoefficients(napi_env env, napi_callback_info info) {   // -> Floa
 }
 napi_value IirProcess(napi_env env, napi_callback_info info) {   // Float32Array in -> Float32Array (processBuffer); Float64Array in -> Float64Array (process)
   ARGS(5);
-  fskhip_iir *f = (fskhip_iir *)external(env, argv[0], "filter destroyed");
+  fskhip_iir *f = (fskhip_iir *)filter_of(env, argv[0]);
   if (!f) return nullptr;
   napi_typedarray_type ty; size_t ilen; void *in; napi_value ab; size_t off;
   if (napi_get_typedarray_info(env, argv[1], &ty, &ilen, &in, &ab, &off) != napi_ok || (ty != napi_float32_array && ty != napi_float64_array)) {
@@ -374,6 +395,7 @@ napi_value IirProcess(napi_env env, napi_callback_info info) {   // Float32Array
     return nullptr;
   }
   const uint32_t n = u32(env, argv[2]), pitch = u32(env, argv[3]), S = u32(env, argv[4]);
+  if (S != fskhip_iir_streams(f)) { napi_throw_range_error(env, nullptr, "nStreams is not the filter's stream count"); return nullptr; }
   if (S == 0 || pitch < n || (size_t)pitch * (S - 1) + n > ilen) { napi_throw_range_error(env, nullptr, "input too short"); return nullptr; }
   void *out;
   int rc;
@@ -390,7 +412,7 @@ napi_value IirProcess(napi_env env, napi_callback_info info) {   // Float32Array
 }
 napi_value IirReset(napi_env env, napi_callback_info info) {
   ARGS(2);
-  fskhip_iir *f = (fskhip_iir *)external(env, argv[0], "filter destroyed");
+  fskhip_iir *f = (fskhip_iir *)filter_of(env, argv[0]);
   if (!f) return nullptr;
   int64_t s = -1;
   napi_get_value_int64(env, argv[1], &s);

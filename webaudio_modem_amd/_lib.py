@@ -132,6 +132,8 @@ _SYMBOLS = [
     ("fskhip_sinc_bandpass", C.c_int, [C.c_double, C.c_double, C.c_double, C.c_uint32, _P]),
     ("fskhip_fir_create", C.c_int, [C.c_int, _P, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P)]),
     ("fskhip_fir_destroy", C.c_int, [_P]),
+    ("fskhip_fir_streams", C.c_uint32, [_P]),
+    ("fskhip_iir_streams", C.c_uint32, [_P]),
     ("fskhip_fir_process_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P]),
     ("fskhip_fir_process_host", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t]),
     ("fskhip_fir_reset", C.c_int, [_P, C.c_int64]),

@@ -52,6 +52,7 @@ size_t demod_blk_queue_words(uint32_t groups);
 // fsk_blk6.hip: seven waves per group, for batches that leave every workgroup a compute unit of its own
 size_t demod_blk6_lds_bytes(const DemodParams &P, uint32_t y_slots);
 uint32_t demod_blk6_y_slots(const DemodParams &P);
+uint32_t demod_blk6_min_y_slots();
 bool demod_blk6_applicable(const DemodParams &P);
 size_t demod_blk6_max_samples();
 hipError_t set_blk6_lds_limit(const DemodParams &P);
@@ -222,6 +223,7 @@ struct fskhip_engine {
   uint32_t blk_resident = 0;     // workgroups of demod_blk_kernel the device holds at once; larger batches run it persistent, in time slices
   uint32_t blk_min_tiles = 0;    // calls with fewer whole tiles than this stay with round 2's kernels
   uint32_t blk_y_slots = 6;      // half tiles in the block kernel's y ring: as deep as the LDS allows at this batch size
+  bool blk_y_pinned = false;     // "blk_y_slots" was set: "blk_lanes" leaves it alone
   // five waves per group (demod_blk5_kernel, round 6): the front wave's two halves on a wave each.  0 never, 1 wherever the plain
   // four-wave kernel would run ("kernel" = five-wave), 2 auto: batches of whole-wave groups that fill the device
   uint32_t use_five = 0;
@@ -768,9 +770,12 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
     e->six_min_tiles = (uint32_t)x;
     return FSKHIP_OK;
   }
-  if (k == "stage_y_slots") {
-    if ((rc = number(6, 24, &x)) != FSKHIP_OK) return rc;
-    e->six_y_slots = (uint32_t)x & ~1u;
+  if (k == "stage_y_slots") {     // (checked against what the kernel can use, as blk_y_slots is -- it used to be clamped silently)
+    if (!(e->demod_ok && e->precision == FSKHIP_PRECISION_F32 && demod_blk6_applicable(e->P))) return FSKHIP_OK;   // (the seven-wave kernel does not apply: nothing to tune)
+    const uint32_t lo = demod_blk6_min_y_slots(), hi = demod_blk6_y_slots(e->P);
+    if ((rc = number(lo, hi, &x)) != FSKHIP_OK) return rc;
+    if (x & 1u) return fail(FSKHIP_E_INVALID, "fskhip_set_option(stage_y_slots): %s is odd (whole tiles: two half tiles each)", value);
+    e->six_y_slots = (uint32_t)x;
     return FSKHIP_OK;
   }
   if (k == "stage_roles") {       // measurements: the part each of the seven waves plays, e.g. 0135426 (every part exactly once)
@@ -804,12 +809,13 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
         return fail(FSKHIP_E_INVALID, "fskhip_set_option(blk_y_slots): %s slots need %zu B of LDS (> 160 KiB) at dsSPB %u", value,
                     demod_blk_lds_bytes(e->P, (uint32_t)x), e->P.d);
       e->blk_y_slots = (uint32_t)x;
+      e->blk_y_pinned = true;                          // (a later "blk_lanes" re-plans the depth only if it was not asked for)
     } else if (k == "blk_lanes") {                    // streams per workgroup: auto (what the device's CU count suggests) | 64 | 32 | 16 | 8
       if (v == "auto") {
         e->blk_lanes = demod_blk_lanes(e->n_streams, e->device);
         uint32_t y = 0, res = 0;
         demod_blk_plan(e->P, (e->n_streams + e->blk_lanes - 1u) / e->blk_lanes, e->device, &y, &res);
-        if (y) e->blk_y_slots = y;
+        if (y && !e->blk_y_pinned) e->blk_y_slots = y;
         return FSKHIP_OK;
       }
       if ((rc = number(8, 64, &x)) != FSKHIP_OK) return rc;
@@ -818,7 +824,7 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
       {   // the ring depth follows the workgroup count the new width gives; a "blk_resident" pinned by a test stays
         uint32_t y = 0, res = 0;
         demod_blk_plan(e->P, (e->n_streams + e->blk_lanes - 1u) / e->blk_lanes, e->device, &y, &res);
-        if (y) e->blk_y_slots = y;
+        if (y && !e->blk_y_pinned) e->blk_y_slots = y;
       }
     } else if (k == "blk_min_tiles") {
       if ((rc = number(0, 1u << 30, &x)) != FSKHIP_OK) return rc;
@@ -1421,12 +1427,9 @@ int fskhip_trace_read_pre(fskhip_engine *e, double *pre, size_t cap, size_t *n) 
   size_t m = cnt[1] < 2u * e->trace_cap ? cnt[1] : 2u * e->trace_cap;
   m = m < cap ? m : cap;
   if (pre && m) HIP_TRY(hipMemcpy(pre, e->S.trace_post + e->trace_cap, sizeof(double) * m, hipMemcpyDeviceToHost));
-  // fp32 lock-step engines carry the pre-filter's output times the low-pass gain b0 / 2 and 2^60 (fsk_pipe_dev.h): back to the
-  // reference's scale here.  (fp64 engines and the generic fp32 kernel record the reference's own value.)
-  if (pre && m && e->precision == FSKHIP_PRECISION_F32 && e->ds_uniform && !e->force_generic && !e->P.wide && !e->P.frac) {
-    const double g = 0.5 * e->P.lp_b0 * 1152921504606846976.0;
-    for (size_t i = 0; i < m; i++) pre[i] /= g;
-  }
+  // (every kernel records the reference's own scale: the per-sample fp32 kernel of lock-step engines, which carries the value times
+  // the low-pass gain b0 / 2 and 2^60, divides where it records -- the host used to, by a predicate that could not tell which
+  // kernel a call had taken: ADVICE r05)
   *n = cnt[1];
   return FSKHIP_OK;
 }

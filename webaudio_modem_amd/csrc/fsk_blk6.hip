@@ -169,6 +169,22 @@ __device__ __forceinline__ float lp_step(LpLane &L, float a2, float nd, float v,
 
 // (front_agc / front_bp -- front_agc_bp as its two halves -- live in fsk_pipe_dev.h since round 6: fsk_blk.hip's five-wave kernel uses them too)
 
+// Every hand-off wait of this kernel is a poll with s_sleep in between (include/fskhip.h, "Hand-off waits").  Debug builds
+// (-DFSK_SPIN_CAP=<polls>, tools/build_variant.sh) bound them: a wave that has polled that often without getting on sets bit 31 of
+// the engine's second statistics word (blk_stat[1]) and ends -- the waves waiting on IT then run into their own cap -- so that a
+// protocol slip shows as a flagged, finished launch instead of a hung GPU.  The shipped library polls unbounded.
+#ifdef FSK_SPIN_CAP
+#define B6_SPIN(arg)                                                                                          \
+  do {                                                                                                        \
+    __builtin_amdgcn_s_sleep(arg);                                                                            \
+    if (++b6_spins > (uint32_t)(FSK_SPIN_CAP)) {                                                              \
+      if (lane == 0 && S.blk_stat) __hip_atomic_fetch_or(&S.blk_stat[1], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+      __builtin_amdgcn_endpgm();                                                                              \
+    }                                                                                                         \
+  } while (0)
+#else
+#define B6_SPIN(arg) __builtin_amdgcn_s_sleep(arg)
+#endif
 #ifndef FSK_B6_SLEEP
 #define FSK_B6_SLEEP 1
 #endif
@@ -229,6 +245,20 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t role = (Z.rolemap >> (3u * wave)) & 7u;
+#ifdef FSK_SPIN_CAP
+  uint32_t b6_spins = 0;
+#endif
+  {
+    // every part played exactly once (the host validates "stage_roles" and builds the default map; a map that is no permutation of
+    // 0..6 would leave some counter without a writer and six waves waiting on it for good): checked here once per launch by every
+    // wave alike -- scalar work -- and a bad map ends the launch at once, flagged in the statistics word
+    uint32_t seen = 0;
+    for (uint32_t w = 0; w < kB6Waves; w++) seen |= 1u << ((Z.rolemap >> (3u * w)) & 7u);
+    if (seen != 0x7Fu) {
+      if (threadIdx.x == 0 && S.blk_stat) __hip_atomic_fetch_or(&S.blk_stat[1], 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
 
   const size_t n_tiles = n_call / kFastTile;
   const size_t n = n_tiles * kFastTile;
@@ -317,7 +347,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
         FSK_STAMP_W0
         while (2u * t + 2u - used > 2u * kB6Stage) {
           used = lds_peek(&ctr[C6_Y]);
-          if (2u * t + 2u - used > 2u * kB6Stage) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
+          if (2u * t + 2u - used > 2u * kB6Stage) B6_SPIN(FSK_B6_SLEEP);
         }
         FSK_STAMP_W1
       }
@@ -367,11 +397,11 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
         FSK_STAMP_W0
         while (produced < hidx + 2u) {
           produced = lds_peek(&ctr[c_in]);
-          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
+          if (produced < hidx + 2u) B6_SPIN(FSK_B6_SLEEP);
         }
         while (do_bp && hidx + 1u - consumed >= NY) {         // y ring full: the frame wave (which may still need the slots'
           consumed = lds_peek(&ctr[C6_CONS]);                 // pre-filter outputs after a reset) has not released them
-          if (hidx + 1u - consumed >= NY) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP);
+          if (hidx + 1u - consumed >= NY) B6_SPIN(FSK_B6_SLEEP);
         }
         FSK_STAMP_W1
       }
@@ -442,11 +472,11 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
         FSK_STAMP_W0
         while (produced < hidx + 2u) {
           produced = lds_peek(&ctr[C6_Y]);
-          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+          if (produced < hidx + 2u) B6_SPIN(FSK_B6_SLEEP_RING);
         }
         while (hidx + 2u - consumed > 2u * kB6XT) {          // x ring full: wait for the frame wave
           consumed = lds_peek(&ctr[C6_CONS]);
-          if (hidx + 2u - consumed > 2u * kB6XT) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+          if (hidx + 2u - consumed > 2u * kB6XT) B6_SPIN(FSK_B6_SLEEP_RING);
         }
         FSK_STAMP_W1
       }
@@ -536,11 +566,11 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
         FSK_STAMP_W0
         while (produced < hidx + 2u) {
           produced = lds_peek(&ctr[C6_IQ]);
-          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+          if (produced < hidx + 2u) B6_SPIN(FSK_B6_SLEEP_RING);
         }
         while (hidx + 2u - consumed > 2u * kB6DT) {          // a correction posted now is due kHandLag ahead: no further than that
           consumed = lds_peek(&ctr[C6_CONS]);
-          if (hidx + 2u - consumed > 2u * kB6DT) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+          if (hidx + 2u - consumed > 2u * kB6DT) B6_SPIN(FSK_B6_SLEEP_RING);
         }
         FSK_STAMP_W1
       }
@@ -691,7 +721,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
             continue;
           }
           if (t < nt && produced >= 2u * t + 2u) break;
-          __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+          B6_SPIN(FSK_B6_SLEEP_RING);
         }
         FSK_STAMP_W1
       }
@@ -787,7 +817,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
           for (;;) {
             pw = lds_peek(&ctr[C6_P4]);
             if ((pw >> 24) == gen && (pw & 0xFFFFFFu) >= t + 2u) break;
-            __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+            B6_SPIN(FSK_B6_SLEEP_RING);
           }
           FSK_STAMP_W1
         }
@@ -846,7 +876,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
             for (;;) {
               const uint32_t pw2 = lds_peek(&ctr[C6_P4]);
               if ((pw2 >> 24) == gen && (pw2 & 0xFFFFFFu) >= t + 2u) { produced = pw2 & 0xFFFFFFu; break; }
-              __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+              B6_SPIN(FSK_B6_SLEEP_RING);
             }
             FSK_STAMP_W1
           }
@@ -885,7 +915,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
             for (;;) {                                         // (P4 has produced this tile: its entry state is in the history)
               const uint32_t pw = lds_peek(&ctr[C6_P4]);
               if ((pw >> 24) == gen && (pw & 0xFFFFFFu) >= t + 2u) break;
-              __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+              B6_SPIN(FSK_B6_SLEEP_RING);
             }
             const v4f *ht = hist + slot_t * 2u * 64u;
             const v4f a = ht[lane], b = ht[64u + lane];
@@ -896,7 +926,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
         {
           uint32_t p3 = 0;
           FSK_STAMP_W0
-          while ((p3 = lds_peek(&ctr[C6_X])) < t + 2u) __builtin_amdgcn_s_sleep(FSK_B6_SLEEP_RING);
+          while ((p3 = lds_peek(&ctr[C6_X])) < t + 2u) B6_SPIN(FSK_B6_SLEEP_RING);
           FSK_STAMP_W1
         }
         if (X.zlive != 0u) { rare_tiles++; FSK_STAMP_COUNT(1) } else { FSK_STAMP_COUNT(3) }
@@ -1027,14 +1057,14 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
       __hip_atomic_fetch_add(&S.blk_stat[1], rare_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // the other waves' final states
-    while (lds_peek(&ctr[C6_X]) <= nh) __builtin_amdgcn_s_sleep(1);
-    while (lds_peek(&ctr[C6_IQ]) <= nh) __builtin_amdgcn_s_sleep(1);
+    while (lds_peek(&ctr[C6_X]) <= nh) B6_SPIN(1);
+    while (lds_peek(&ctr[C6_IQ]) <= nh) B6_SPIN(1);
     if (!own_post) {
       // (P4 has run the last tile in this generation -- this wave consumed it -- and leaves its state behind it)
       for (;;) {
         const uint32_t pw = lds_peek(&ctr[C6_P4]);
         if ((pw >> 24) == gen && (pw & 0xFFFFFFu) > nh) break;
-        __builtin_amdgcn_s_sleep(1);
+        B6_SPIN(1);
       }
       const v4f a = fin[192u + lane], b = fin[256u + lane];
       B.px1 = a.x; B.px2 = a.y; B.py = a.z; B.pv = a.w; B.last_phase = b.x;
@@ -1080,6 +1110,7 @@ size_t demod_blk6_lds_bytes(const DemodParams &P, uint32_t y_slots) {
          sizeof(uint32_t) * (64u * blk_poly_stride(P.d) + 16u + 64u + 6u * 64u);
 }
 // the y ring as deep as the LDS of a compute unit this workgroup has to itself allows
+uint32_t demod_blk6_min_y_slots() { return kB6YMin; }
 uint32_t demod_blk6_y_slots(const DemodParams &P) {
   uint32_t y = kB6YMax;
   while (y > kB6YMin && demod_blk6_lds_bytes(P, y) > 150u * 1024u) y -= 2u;

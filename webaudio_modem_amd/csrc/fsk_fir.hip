@@ -180,6 +180,8 @@ int fskhip_sinc_bandpass(double center, double bandwidth, double sampleRate, uin
   return (int)n_taps;
 }
 
+uint32_t fskhip_fir_streams(const fskhip_fir *f) { return f ? f->S : 0u; }
+
 int fskhip_fir_destroy(fskhip_fir *f) {
   if (!f) return FSKHIP_OK;
   (void)hipSetDevice(f->device);

@@ -68,8 +68,10 @@ __device__ __forceinline__ Real iir_step(const IirCoef &C, Real (&xh)[kIirMax], 
 
 // IO = float: processBuffer() (Float32Array in, Float32Array out); IO = double: process() sample by sample (numbers in, numbers out)
 template <typename Real, typename IO, int NB, int NA>
-__global__ __launch_bounds__(64) void iir_kernel(IirCoef C, const IO *__restrict__ in, size_t n, size_t in_pitch,
-                                                 IO *__restrict__ out, size_t out_pitch, int vec_ok, Real *__restrict__ hx,
+// (in and out are NOT __restrict__: the header allows in == out, and tile t + 1 is loaded before tile t is stored -- different
+// addresses, but an aliasing promise the language would let the compiler build on)
+__global__ __launch_bounds__(64) void iir_kernel(IirCoef C, const IO *in, size_t n, size_t in_pitch,
+                                                 IO *out, size_t out_pitch, int vec_ok, Real *__restrict__ hx,
                                                  Real *__restrict__ hy, uint32_t n_streams) {
   constexpr int VN = 16 / (int)sizeof(IO);               // samples per 16-byte chunk
   constexpr int TILE = kIirChunks * VN;                  // samples per row per tile
@@ -317,6 +319,8 @@ int fskhip_iir_create(int device, const double *b, uint32_t nb, const double *a,
   *out = f;
   return FSKHIP_OK;
 }
+
+uint32_t fskhip_iir_streams(const fskhip_iir *f) { return f ? f->S : 0u; }
 
 int fskhip_iir_get_coefficients(const fskhip_iir *f, double *b, uint32_t *nb, double *a, uint32_t *na) {
   if (!f || !b || !a || !nb || !na) return fail(FSKHIP_E_INVALID, "fskhip_iir_get_coefficients: null argument");

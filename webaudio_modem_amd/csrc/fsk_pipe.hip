@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64, 2) void demod_tail_kernel(
     nco_phasor(free0 + inc * (uint64_t)t, zc, zs);
     if (par == 0) front_zero(F, zmail[lane] == X.k);     // first sample of decimated sample number X.k
     front_sample(F, FK, xin, zc, zs, xs, y, oi, oq);
-    if (S.trace_stream != 0xFFFFFFFFu && C.M.voff == S.trace_stream * 4u) trace_pre_put(S, (double)y);   // (scaled: the host divides, fskhip_trace_read_pre)
+    if (S.trace_stream != 0xFFFFFFFFu && C.M.voff == S.trace_stream * 4u) trace_pre_put(S, (double)y / (0.5 * P.lp_b0 * 1152921504606846976.0));   // (back to the reference's scale HERE -- this kernel carries the value times the low-pass gain b0 / 2 and 2^60 -- so that the buffer holds one scale whichever kernels a traced engine's calls went through: ADVICE r05)
     if (WB) { if (C.valid) xrow[t] = xs; }
     if (par == 0) {
       acc_i = oi; acc_q = oq;
