@@ -1,7 +1,10 @@
 'use strict';
 // CRC16 / XModemPacket / ControlType with the reference's surface (src/utils/crc16.ts, src/transports/xmodem/packet.ts,
 // types.ts), plus the batch forms and scanBursts -- the receive checks of XModemTransport (xmodem.ts:233-320) applied
-// to recorded bursts.  Everything computes in libfskhip.so through the N-API addon; no JavaScript CRC here.
+// to recorded bursts.  Everything that COMPUTES does so in libfskhip.so through the N-API addon (no JavaScript CRC here); the one
+// method that only lays bytes out is XModemPacket.serialize(packet): packet.ts:44-54 writes the fields of the packet OBJECT as
+// they are -- checksum included, whatever it holds (the reference's tests serialise packets with a wrong one) -- so it cannot go
+// through serializeBatch, which computes the CRC.
 const path = require('path');
 const addon = require(path.join(__dirname, 'fsk_addon.node'));
 
