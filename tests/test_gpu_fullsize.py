@@ -848,16 +848,22 @@ def test_agc_write_back_on_dword_aligned_tiles(kernel):
     gen.close()
 
 
+@pytest.mark.parametrize("per_stream", [False, True], ids=["uniform", "per-stream-tones"])
 @pytest.mark.parametrize("S,lanes", [(2048, None), (4096, None), (700, "32"), (150, "64"), (96, "16")])
-def test_seven_wave_kernel_is_the_four_wave_kernel_bit_for_bit(S, lanes, monkeypatch):
+def test_seven_wave_kernel_is_the_four_wave_kernel_bit_for_bit(S, lanes, per_stream, monkeypatch):
     """Round 5: demod_blk6_kernel (fsk_blk6.hip) -- the small-batch kernel whose stages that are not recurrences run on the idle
     lanes of a narrow group and whose post filter runs ahead of the frame logic and is rewound after a reset -- against
     demod_blk_kernel on the same buffers: config #3's signal at 10 dB SNR on top of random lead-ins and levels, a ragged call
     schedule (whole tiles, odd lengths, 128-sample quanta: launches that begin and end inside a reset's own span, a hand-over
     or a frame).  Decoded bytes, per-call byte and 'eod' counts, and EVERY carried state word of every sampled stream must be
-    identical: the float sequence per decimated sample is the same whoever evaluates it."""
+    identical: the float sequence per decimated sample is the same whoever evaluates it.
+    Round 6: the same with per-stream tone pairs (demod_blk6_kernel<., ., false>: per-lane phasor rotation in the iq wave,
+    per-lane phasors and lastPhase in the frame wave's block path with resets) against demod_blk_kernel<., false, .>."""
     import webaudio_modem_amd as wm
     N = 96000
+    BELL = dict(globals()["BELL"])
+    if per_stream:
+        BELL = [dict(BELL, markFrequency=1200 + 7 * (s % 13), spaceFrequency=2200 + 5 * (s % 11)) for s in range(S)]
     gen = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32)
     d_x = gen.device_malloc(S * N * 4)
     gen.synth_device(d_x, N, N, 40, SEED + 77, 400, 0.1, 1.0)
@@ -871,6 +877,8 @@ def test_seven_wave_kernel_is_the_four_wave_kernel_bit_for_bit(S, lanes, monkeyp
         eng = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options=opts)
         rows, eod = _demod_schedule(eng, d_x, N, N, sched)
         want = "demod_blk6_kernel" if name == "six" else "demod_blk_kernel"
+        if per_stream and name == "six":
+            want = ", false>"                                                     # (<write-back, streams per workgroup, uniform = false>)
         state = [eng.debug_state(s) for s in sorted(set(list(range(min(S, 80))) + list(range(0, S, 61)) + [S - 1]))]
         res[name] = (rows, eod, state)
         eng2 = wm.FSKEngine(S, BELL, precision=wm.PRECISION_F32, options=opts)      # one long call: the kernel meant is the one that runs
@@ -955,12 +963,12 @@ def test_a_call_may_end_anywhere_in_the_span_after_a_reset():
 
 def test_seven_wave_is_the_default_for_small_uniform_batches():
     """The engine's own choice: a uniform configuration, every workgroup a compute unit to itself (up to 64 x compute units
-    streams), a long enough call -> seven waves; per-stream tone pairs, bigger batches and short calls stay on four."""
+    streams), a long enough call -> seven waves (round 6: per-stream tone pairs too); bigger batches and short calls stay on four."""
     import webaudio_modem_amd as wm
     N = 48000
     for S, cfg, n, want in ((2048, BELL, N, "demod_blk6_kernel"), (8192, BELL, N, "demod_blk6_kernel"), (16384, BELL, N, "demod_blk6_kernel"),
                             (32768, BELL, N, "demod_blk_kernel<"), (2048, BELL, 64, "demod_blk_kernel<"),
-                            (2048, [dict(BELL, markFrequency=1200 + s % 7) for s in range(2048)], N, "demod_blk_kernel<")):
+                            (2048, [dict(BELL, markFrequency=1200 + s % 7) for s in range(2048)], N, "demod_blk6_kernel<false, 8, false>")):
         eng = wm.FSKEngine(S, cfg, precision=wm.PRECISION_F32)
         d_x = eng.device_malloc(S * N * 4)
         eng.synth_device(d_x, N, N, 12, SEED + 5, 300, 0.1, 1.0)
@@ -1001,21 +1009,24 @@ def test_idle_receiver_bank_with_per_stream_tone_pairs():
     for name, opts, schedule in (("plain", {"kernel": "four-wave", "blk_resets": 0}, [N]), ("resets", {"kernel": "four-wave", "blk_resets": 1}, [N]),
                                  ("resets_quanta", {"kernel": "four-wave", "blk_resets": 1}, [4800, 128, 17, 30000]),
                                  ("resets_redo", {"kernel": "four-wave", "blk_resets": 2}, [N]), ("redo_calls", {"kernel": "four-wave", "blk_resets": 2}, [16000]),
-                                 ("two_wave", {"kernel": "two-wave"}, [N]), ("auto", {}, [24000])):
+                                 ("two_wave", {"kernel": "two-wave"}, [N]), ("auto", {}, [24000]), ("auto_r04", {"kernel": "auto-r04"}, [24000]),
+                                 ("seven", {"kernel": "seven-wave"}, [N]), ("seven_quanta", {"kernel": "seven-wave"}, [4800, 128, 17, 30000])):
         eng = wm.FSKEngine(S, cfgs, precision=wm.PRECISION_F32, options=opts)
         rows, eod = _demod_schedule(eng, d_x, N, N, schedule)
         if name == "resets":
             assert eng.last_kernel().startswith("fsk::demod_blk_kernel_rp<"), eng.last_kernel()
         if name == "plain":
             assert eng.last_kernel().startswith("fsk::demod_blk_kernel<false, false"), eng.last_kernel()
-        if name == "auto":
+        if name == "auto_r04":
             assert eng.last_kernel().startswith("fsk::demod_blk_kernel_rp<"), eng.last_kernel()      # (the statistics of four calls of floor behind it)
+        if name in ("auto", "seven"):
+            assert eng.last_kernel().startswith("fsk::demod_blk6_kernel<false, 8, false>"), eng.last_kernel()   # (round 6: 700 streams = 88 groups of 8: seven waves, per-stream)
         results[name] = (rows, eod, [eng.debug_state(s_) for s_ in range(0, S, 23)])
         eng.close()
     base = _digest(results["plain"][0], results["plain"][1])
     for name, r in results.items():
         assert _digest(r[0], r[1]) == base, name
-    for name in ("resets", "resets_redo", "two_wave"):      # (the same call lengths: the state words must be the same too -- a parked bit clock counts from the call's start)
+    for name in ("resets", "resets_redo", "two_wave", "seven"):      # (the same call lengths: the state words must be the same too -- a parked bit clock counts from the call's start)
         for (ra, ia), (rb, ib) in zip(results["plain"][2], results[name][2]):
             assert np.array_equal(np.asarray(ra).view(np.uint64), np.asarray(rb).view(np.uint64)), name
             assert ia == ib, name

@@ -47,7 +47,10 @@ def _check_status(st, ref, tol, agc_gain):
 # on an 8-lane group; "-64" pins whole-wave groups, whose six parts are cut differently)
 GOLDEN_VARIANTS = PRECISIONS + [("f32-one-wave", 0, 1e-5), ("f32-four-wave", 0, 1e-5), ("f32-four-wave-64", 0, 1e-5),
                                 ("f32-four-wave-resets", 0, 1e-5), ("f32-four-wave-redo", 0, 1e-5),
-                                ("f32-seven-wave", 0, 1e-5), ("f32-seven-wave-64", 0, 1e-5)]
+                                ("f32-seven-wave", 0, 1e-5), ("f32-seven-wave-64", 0, 1e-5),
+                                ("f32-seven-wave-per-stream", 0, 1e-5), ("f32-four-wave-per-stream", 0, 1e-5)]
+# (round 6: "-per-stream": the golden's stream as stream 0 of a TWO-stream engine whose other stream has another tone pair, so that the
+# engine is not uniform and runs the kernels' per-stream instantiations -- demod_blk6_kernel<., ., false>, demod_blk_kernel<., false, .>)
 
 
 @pytest.mark.parametrize("pname,prec,tol", GOLDEN_VARIANTS)
@@ -82,11 +85,21 @@ def test_demod_matches_reference_golden(name, pname, prec, tol, monkeypatch):
         return
     if name in SLOW_F32_ONLY and pname == "f64":
         pytest.skip("covered by the coarser chunkings")
-    eng = _engine(c["config"], prec)
+    per_stream = pname.endswith("-per-stream")
+    if per_stream:
+        monkeypatch.setenv("FSKHIP_SPLIT", "6" if "seven" in pname else "4")
+        merged = dict(wm.engine.DEFAULT_FSK_CONFIG, **c["config"])
+        other = dict(c["config"], markFrequency=merged["markFrequency"] + 30, spaceFrequency=merged["spaceFrequency"] + 30)
+        eng = wm.FSKEngine(2, [c["config"], other], device=0, precision=prec)
+    else:
+        eng = _engine(c["config"], prec)
     x = g.case_input(c)
 
     def call(chunk):
-        out, eod = eng.demodulate_data(chunk.reshape(1, -1))
+        if per_stream:
+            out, eod = eng.demodulate_data(np.stack([chunk, np.zeros_like(chunk)]))
+        else:
+            out, eod = eng.demodulate_data(chunk.reshape(1, -1))
         return out[0], int(eod[0])
 
     out, eod, nonempty, n_calls = run_chunked(call, x, c["chunk"])

@@ -3,7 +3,7 @@
 buffers -- decoded bytes, counts, 'eod' counts and the carried per-stream state words must be IDENTICAL (the same float
 instruction sequence per decimated sample, whoever runs it) -- and their kernel times.
 
-  tools/six_check.py [S:N[:workload[:chunks]] ...]     workload = c3 | c2 | idle | noisy; chunks = call lengths, '+'-separated
+  tools/six_check.py [S:N[:workload[:chunks]] ...]     workload = c3 | c2 | idle | noisy | c4 | p3 (per-stream tone pairs); chunks = call lengths, '+'-separated
 Each case runs in a child process under a timeout (a hand-off bug is a hung kernel, not an error code).  Diagnostic aid."""
 import os
 import subprocess
@@ -18,6 +18,10 @@ import webaudio_modem_amd as wm
 S, N, wl = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 chunks = [int(c) for c in sys.argv[4].split("+")] if sys.argv[4] != "-" else [N]
 cfg = dict(baudRate=300, markFrequency=1070, spaceFrequency=1270) if wl == "c2" else dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
+# per-stream tone pairs (round 6): c4 = BASELINE config #4 (300 baud, mark_s = 1000 + 10 (s mod 100), space_s = mark_s + 200), p3 = config #3's
+# parameters with a tone pair per stream
+if wl == "c4": cfg = [dict(baudRate=300, markFrequency=1000 + 10 * (s % 100), spaceFrequency=1200 + 10 * (s % 100)) for s in range(S)]
+if wl == "p3": cfg = [dict(baudRate=1200, markFrequency=1200 + 7 * (s % 13), spaceFrequency=2200 + 5 * (s % 11)) for s in range(S)]
 st = torch.cuda.current_stream().cuda_stream
 x = torch.zeros((S, N), dtype=torch.float32, device="cuda")
 g = wm.FSKEngine(S, cfg, precision=wm.PRECISION_F32)
@@ -29,7 +33,7 @@ if wl == "idle":
     import math
     g.add_awgn_device(x.data_ptr(), N, N, 30.0 - 10.0 * math.log10(N / float(fl)), 0xF5C0DE ^ 0xA36, st)
 else:
-    g.synth_device(x.data_ptr(), N, N, 32 if wl == "c2" else 100, 0xF5C0DE, 10 * (160 if wl == "c2" else 40), 0.1, 1.0, st)
+    g.synth_device(x.data_ptr(), N, N, 32 if wl in ("c2", "c4") else 100, 0xF5C0DE, 10 * (160 if wl in ("c2", "c4") else 40), 0.1, 1.0, st)
     if wl == "noisy":
         g.add_awgn_device(x.data_ptr(), N, N, 10.0, 0xF5C0DE ^ 0xA36, st)
 torch.cuda.synchronize()

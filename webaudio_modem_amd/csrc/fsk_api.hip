@@ -948,10 +948,13 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
               }
               if (fetch) HIP_TRY(hipMemcpyAsync((void *)e->h_stat, e->S.blk_stat, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             }
-            static const char *const names6[8] = {
+            static const char *const names6[16] = {
                 "fsk::demod_blk6_kernel<false, 64>", "fsk::demod_blk6_kernel<false, 32>", "fsk::demod_blk6_kernel<false, 16>", "fsk::demod_blk6_kernel<false, 8>",
-                "fsk::demod_blk6_kernel<true, 64>", "fsk::demod_blk6_kernel<true, 32>", "fsk::demod_blk6_kernel<true, 16>", "fsk::demod_blk6_kernel<true, 8>"};
-            e->last_kernel = names6[(wb ? 4 : 0) + (e->blk_lanes == 64u ? 0 : e->blk_lanes == 32u ? 1 : e->blk_lanes == 16u ? 2 : 3)];
+                "fsk::demod_blk6_kernel<true, 64>", "fsk::demod_blk6_kernel<true, 32>", "fsk::demod_blk6_kernel<true, 16>", "fsk::demod_blk6_kernel<true, 8>",
+                // (round 6: per-stream tone pairs -- <write-back, streams per workgroup, uniform = false>)
+                "fsk::demod_blk6_kernel<false, 64, false>", "fsk::demod_blk6_kernel<false, 32, false>", "fsk::demod_blk6_kernel<false, 16, false>", "fsk::demod_blk6_kernel<false, 8, false>",
+                "fsk::demod_blk6_kernel<true, 64, false>", "fsk::demod_blk6_kernel<true, 32, false>", "fsk::demod_blk6_kernel<true, 16, false>", "fsk::demod_blk6_kernel<true, 8, false>"};
+            e->last_kernel = names6[(e->P.uni_cfg ? 0 : 8) + (wb ? 4 : 0) + (e->blk_lanes == 64u ? 0 : e->blk_lanes == 32u ? 1 : e->blk_lanes == 16u ? 2 : 3)];
           } else {
           // five waves per group where the plain four-wave kernel would run (the kernels whose block path takes resets have four)
           const bool five = e->use_five != 0u && med == 0u && e->blk5_resident != 0u && e->blk_resident == e->blk5_resident;

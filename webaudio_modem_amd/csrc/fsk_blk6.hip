@@ -131,9 +131,14 @@ __device__ inline uint32_t blk6_fast(BackLane &Bn, const BackK &K, const BlkK &Q
 // registers here) and the entry state kept as a register copy by the caller instead of a stash in memory.  xa = the x ring
 // tile (I or phase 0..3, 4..7; Q or magnitude 0..3, 4..7), ya = its four y ring entries, zc / zs = the tile's cos / sin rows,
 // ro = the eight polyphase registers.
+// UNI = false (round 6: per-stream tone pairs, BASELINE config #4's kind): every lane has its own NCO, so the direct instance's
+// phasors and lastPhase after a reset are evaluated here per lane, as fsk_blk.hip's blk_medium<false> does (nco_phasor of the
+// lane's free-running accumulator; back_reset's expression); k0 = decimated samples of the launch before the tile.
+template <bool UNI>
 __device__ inline uint32_t blk6_medium(BackLane &Bn, const BackK &K, const BlkK &Q, uint32_t matched_min, uint32_t kv0, const v4f (&xa)[4],
                                        const v4f (&ya)[4], const v4f (&zc)[4], const v4f (&zs)[4], const uint32_t (&ro)[kBlk],
-                                       const float (&thf8)[kBlk], float (&am)[kBlk], uint32_t &bq, uint32_t &nq, MedEv &E, uint32_t &w_out) {
+                                       const float (&thf8)[kBlk], float (&am)[kBlk], uint32_t &bq, uint32_t &nq, MedEv &E, uint32_t &w_out,
+                                       uint64_t free0 = 0, uint64_t inc = 0, uint32_t k0 = 0) {
   uint32_t w = 0, hard = 0;
   uint32_t matched = Bn.matched, thr_cur = Bn.thr_eff, ls = Bn.ls;
   E.jr = 0; E.jc = 0; E.cai = E.caq = E.cbi = E.cbq = 0.f;
@@ -147,8 +152,20 @@ __device__ inline uint32_t blk6_medium(BackLane &Bn, const BackK &K, const BlkK 
                               zs[2].x, zs[2].y, zs[2].z, zs[2].w, zs[3].x, zs[3].y, zs[3].z, zs[3].w};
 #pragma unroll
   for (int j = 0; j < kBlk; j++) {
-    const v4f z = (v4f){cv[2 * j], sv[2 * j], cv[2 * j + 1], sv[2 * j + 1]};
-    med_sample(Bn, K, j, e0v[j], e1v[j], yv[2 * j], yv[2 * j + 1], z, thf8[j], ro[j], kv0 + (uint32_t)(j + 1), matched_min, kHandPairs, matched, thr_cur, ls,
+    v4f z = (v4f){cv[2 * j], sv[2 * j], cv[2 * j + 1], sv[2 * j + 1]};
+    float thf_j = thf8[j];
+    if (!UNI) {
+      const uint64_t n0 = (uint64_t)(2u * (k0 + (uint32_t)j));
+      float c0, s0, c1, s1;
+      nco_phasor(free0 + inc * n0, c0, s0);
+      nco_phasor(free0 + inc * (n0 + 1ull), c1, s1);
+      z = (v4f){c0, s0, c1, s1};
+      const uint64_t fr0 = free0 + inc * (uint64_t)(2u * (k0 + (uint32_t)j + 1u));
+      double r = (double)fr0 * 5.42101086242752217e-20 * 6.283185307179586476925;   // 2^-64 turns -> radians (back_reset)
+      r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
+      thf_j = (float)r;
+    }
+    med_sample(Bn, K, j, e0v[j], e1v[j], yv[2 * j], yv[2 * j + 1], z, thf_j, ro[j], kv0 + (uint32_t)(j + 1), matched_min, kHandPairs, matched, thr_cur, ls,
                w, hard, E, am[j]);
   }
   hard |= med_finish(Bn, K, Q, kv0, matched, thr_cur, ls, w, bq, nq, E);
@@ -215,13 +232,17 @@ __device__ inline void b6_post(uint32_t *p, uint32_t v) {
 #define FSK_B6_SLEEP_RING 1
 #endif
 
-template <bool WB, int LW>
+// UNI = false (round 6): per-stream tone pairs.  What changes: the pre-filter wave takes its coefficients per stream
+// (front_load<false>), the iq wave rotates a per-lane phasor -- the tile's first from the exact accumulator, the other fifteen by
+// e^{j w} (fsk_blk.hip's wave 1, op for op; in a narrow group both halves of the wave rotate the same phasor and use its real or
+// imaginary part) -- the loader's phasor table is not written, and the frame wave's block path with resets evaluates the direct
+// instance's phasors and lastPhase per lane (blk6_medium<false>).  Bytes, counters and state words are demod_blk_kernel<., false, .>'s.
+template <bool WB, int LW, bool UNI = true>
 __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
     DemodParams P, DemodState S, float *__restrict__ samples, size_t n_call, size_t pitch, int append,
     uint8_t *__restrict__ out, size_t out_pitch, uint32_t *__restrict__ out_counts,
     uint32_t *__restrict__ eod_counts, Blk6Z Z) {
   FSK_STAMP_DECL
-  constexpr bool UNI = true;
   constexpr bool SPLIT = LW <= 32;                         // P2: I chain in lanes 0..31, Q chain in lanes 32..63
   constexpr int PARTS = 64 / LW;                           // P3: lanes per stream
   constexpr int SP = kBlk / PARTS;                         // ... decimated samples per lane and tile
@@ -271,7 +292,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
   const bool mine = l < W;
   const uint32_t stream = mine ? s0 + l : 0xFFFFFFFFu;
   const PipeCtx C = pipe_ctx(P, S, stream);
-  const uint64_t inc = ((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo;
+  const uint64_t inc = UNI ? (((uint64_t)P.u_inc_hi << 32) | P.u_inc_lo) : S.nco_inc[C.row4 >> 2];
   const uint64_t free0 = pipe_free0<UNI, 0>(C);
   uint32_t *gpoly = (uint32_t *)S.poly + (size_t)(s0 >> 6) * P.d * 64u + (s0 & 63u);
   constexpr int COH = 0;
@@ -357,7 +378,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
       load_tile((size_t)t + 3, r0, r1, r2, r3);
       v4u32 cv;
       lds_peek4_begin(ctr, cv);
-      {
+      if (UNI) {
         float pc, ps;
         nco_phasor(zacc, pc, ps);
         float *ztf = reinterpret_cast<float *>(zt + (t & ZTM) * 8u);
@@ -462,6 +483,14 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
     }
     float lp_a2 = P.f_lp_a2, lp_nd = -P.f_lp_delta;
     asm volatile("" : "+v"(lp_a2), "+v"(lp_nd));
+    float wre = 1.f, wim = 0.f, zr = 1.f, zi = 0.f;          // UNI = false: e^{j w} of this lane's stream, and the running phasor
+    uint64_t tacc = free0;
+    const uint64_t inc16p = inc * 16u;
+    if (!UNI) {
+      const __amdgpu_buffer_rsrc_t cf_rsrc = C.cf_rsrc;
+      const uint32_t fld = C.fld, row4 = C.row4;
+      wre = (float)PIPE_CLOAD(CF_w1_re); wim = (float)PIPE_CLOAD(CF_w1_im);
+    }
     uint32_t consumed = 0, produced = 0, yslot_i = 0, xt_i = 0;
     const uint32_t zoff = upper ? 4u : 0u;                   // v4f offset of this lane's phasor row in a zt tile (cos | sin)
     const uint32_t xoff = upper ? 2u * 64u : 0u;             // ... and of its rows in an x ring tile
@@ -485,13 +514,20 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
       const v4f *ztile = zt + (t & ZTM) * 8u;
       const uint32_t zj = zmail[l];
       v4f y4[4], zz[8];
+      if (!UNI) {                                             // the tile's first phasor from the exact accumulator
+        nco_phasor(tacc, zr, zi);
+        tacc += inc16p;
+      }
       {
         const v4f *ys0 = yring + yslot_i * 2u * 64u;
         yslot_i = yslot_i + 1u == NY ? 0u : yslot_i + 1u;
         const v4f *ys1 = yring + yslot_i * 2u * 64u;
         yslot_i = yslot_i + 1u == NY ? 0u : yslot_i + 1u;
         y4[0] = ys0[l]; y4[1] = ys0[64u + l]; y4[2] = ys1[l]; y4[3] = ys1[64u + l];
-        if (SPLIT) {
+        if (!UNI) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) zz[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+        } else if (SPLIT) {
 #pragma unroll
           for (int i = 0; i < 4; i++) zz[i] = ztile[zoff + (uint32_t)i];
         } else {
@@ -504,8 +540,16 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
       float si[8], sq[8];                                    // pair sums U of the tile's eight decimated samples
       auto quad = [&](const uint32_t c, const bool zeroing) {
         const float y[4] = {y4[c].x, y4[c].y, y4[c].z, y4[c].w};
-        const float za[4] = {zz[c].x, zz[c].y, zz[c].z, zz[c].w};                       // SPLIT: this lane's row; else cos
-        const float zb[4] = {zz[(c + 4u) & 7u].x, zz[(c + 4u) & 7u].y, zz[(c + 4u) & 7u].z, zz[(c + 4u) & 7u].w};   // sin (not SPLIT)
+        float za[4] = {zz[c].x, zz[c].y, zz[c].z, zz[c].w};                             // SPLIT: this lane's row; else cos
+        float zb[4] = {zz[(c + 4u) & 7u].x, zz[(c + 4u) & 7u].y, zz[(c + 4u) & 7u].z, zz[(c + 4u) & 7u].w};   // sin (not SPLIT)
+        if (!UNI) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {                       // (fsk_blk.hip wave 1's rotation, op for op)
+            za[j] = (SPLIT && upper) ? zi : zr; zb[j] = zi;
+            const float nr = __builtin_fmaf(-zi, wim, zr * wre), ni = __builtin_fmaf(zi, wre, zr * wim);
+            zr = nr; zi = ni;
+          }
+        }
         const uint32_t pb = 8u * t + 2u * c;
         float oi[4], oq[4];
 #pragma unroll
@@ -947,8 +991,8 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
           const uint32_t ro[kBlk] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
           // lastPhase after a resetState() at the end of sample j of this tile: the free-running frame's phase there
           // (back_reset's expression; lane j evaluates it, the wave reads it back as a scalar)
-          float thf8[kBlk];
-          {
+          float thf8[kBlk] = {};
+          if (UNI) {
             const uint64_t fr0 = X.free0 + inc * (uint64_t)(2u * (X.k + (lane & 7u) + 1u));
             double r = (double)fr0 * 5.42101086242752217e-20 * 6.283185307179586476925;
             r = r > 3.14159265358979323846 ? r - 6.283185307179586476925 : r;
@@ -960,7 +1004,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
           float am[kBlk];
           uint32_t bqn = bq, nqn = nq, wbits;
           MedEv E;
-          const uint32_t hard = blk6_medium(Bn, K, Q, P.matched_min, X.kv, xa, ya, zc, zs, ro, thf8, am, bqn, nqn, E, wbits);
+          const uint32_t hard = blk6_medium<UNI>(Bn, K, Q, P.matched_min, X.kv, xa, ya, zc, zs, ro, thf8, am, bqn, nqn, E, wbits, X.free0, inc, X.k);
           FSK_STAMP_COUNT(2)
           if (__builtin_amdgcn_ballot_w64((int32_t)hard < 0) == 0ull) {
             B = Bn; bq = bqn; nq = nqn;
@@ -1035,7 +1079,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
             X.kv += 1u;
             const float zph[4] = {zc[2 * j], zs[2 * j], zc[2 * j + 1], zs[2 * j + 1]};
             back_pair<UNI, true, false, true, COH>(B, K, P, S, M, &rn[j], lane, amp_rsrc, out, (uint32_t)out_pitch, eod_counts, X,
-                                                   u0[j], u1[j], &yv[2 * j], ro[j], inc, u0[j], u1[j], zph);
+                                                   u0[j], u1[j], &yv[2 * j], ro[j], inc, u0[j], u1[j], UNI ? zph : nullptr);
             amp_advance(X.amp_soff, amp_quad_bytes, amp_wrap);
           }
           *reinterpret_cast<uint4 *>(prow + pidx) = make_uint4(rn[0], rn[1], rn[2], rn[3]);
@@ -1117,7 +1161,7 @@ uint32_t demod_blk6_y_slots(const DemodParams &P) {
   return y;
 }
 bool demod_blk6_applicable(const DemodParams &P) {
-  return P.d >= 8u && (P.d & 3u) == 0u && !P.wide && !P.frac && P.uni_cfg != 0u && demod_blk6_lds_bytes(P, kB6YMin) <= 150u * 1024u;
+  return P.d >= 8u && (P.d & 3u) == 0u && !P.wide && !P.frac && demod_blk6_lds_bytes(P, kB6YMin) <= 150u * 1024u;   // (round 6: per-stream tone pairs too)
 }
 // half-tile counters carry a generation in their top byte
 size_t demod_blk6_max_samples() { return ((size_t)1 << 23) * 16u - 16u; }
@@ -1127,7 +1171,10 @@ hipError_t set_blk6_lds_limit(const DemodParams &P) {
   const size_t bytes = demod_blk6_lds_bytes(P, demod_blk6_y_slots(P));
 #define FSK_ATTR(WBV, LWV)                                                                                       \
   if (e == hipSuccess)                                                                                           \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk6_kernel<WBV, LWV>),                       \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk6_kernel<WBV, LWV, true>),                 \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                            \
+  if (e == hipSuccess)                                                                                           \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_blk6_kernel<WBV, LWV, false>),                \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   FSK_ATTR(false, 64) FSK_ATTR(false, 32) FSK_ATTR(false, 16) FSK_ATTR(false, 8)
   FSK_ATTR(true, 64) FSK_ATTR(true, 32) FSK_ATTR(true, 16) FSK_ATTR(true, 8)
@@ -1157,8 +1204,14 @@ hipError_t launch_demod_blk6(bool writeback, bool append, const DemodParams &P, 
   const size_t lds = demod_blk6_lds_bytes(P, y_slots);
   Blk6Z Z = {y_slots, blk6_zt_tiles(y_slots), rolemap ? rolemap : demod_blk6_default_rolemap(lanes)};
 #define FSK_LAUNCH_B6(WBV, LWV)                                                                                      \
-  hipLaunchKernelGGL((demod_blk6_kernel<WBV, LWV>), dim3(blocks), dim3(64 * kB6Waves), lds, stream, P, S, samples, n, pitch, \
-                     append ? 1 : 0, out, out_pitch, out_counts, eod_counts, Z)
+  do {                                                                                                               \
+    if (P.uni_cfg != 0u)                                                                                             \
+      hipLaunchKernelGGL((demod_blk6_kernel<WBV, LWV, true>), dim3(blocks), dim3(64 * kB6Waves), lds, stream, P, S, samples, n, pitch, \
+                         append ? 1 : 0, out, out_pitch, out_counts, eod_counts, Z);                                \
+    else                                                                                                             \
+      hipLaunchKernelGGL((demod_blk6_kernel<WBV, LWV, false>), dim3(blocks), dim3(64 * kB6Waves), lds, stream, P, S, samples, n, pitch, \
+                         append ? 1 : 0, out, out_pitch, out_counts, eod_counts, Z);                                \
+  } while (0)
   if (writeback) {
     if (lanes == 64u) FSK_LAUNCH_B6(true, 64); else if (lanes == 32u) FSK_LAUNCH_B6(true, 32);
     else if (lanes == 16u) FSK_LAUNCH_B6(true, 16); else FSK_LAUNCH_B6(true, 8);
