@@ -20,8 +20,8 @@ chunks = [int(c) for c in sys.argv[4].split("+")] if sys.argv[4] != "-" else [N]
 cfg = dict(baudRate=300, markFrequency=1070, spaceFrequency=1270) if wl == "c2" else dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
 # per-stream tone pairs (round 6): c4 = BASELINE config #4 (300 baud, mark_s = 1000 + 10 (s mod 100), space_s = mark_s + 200), p3 = config #3's
 # parameters with a tone pair per stream
-if wl == "c4": cfg = [dict(baudRate=300, markFrequency=1000 + 10 * (s % 100), spaceFrequency=1200 + 10 * (s % 100)) for s in range(S)]
-if wl == "p3": cfg = [dict(baudRate=1200, markFrequency=1200 + 7 * (s % 13), spaceFrequency=2200 + 5 * (s % 11)) for s in range(S)]
+if wl == "c4": cfg = [dict(baudRate=300, markFrequency=1000 + 10 * (s %% 100), spaceFrequency=1200 + 10 * (s %% 100)) for s in range(S)]
+if wl == "p3": cfg = [dict(baudRate=1200, markFrequency=1200 + 7 * (s %% 13), spaceFrequency=2200 + 5 * (s %% 11)) for s in range(S)]
 st = torch.cuda.current_stream().cuda_stream
 x = torch.zeros((S, N), dtype=torch.float32, device="cuda")
 g = wm.FSKEngine(S, cfg, precision=wm.PRECISION_F32)

@@ -20,6 +20,9 @@ envopts.install()
 S, N = int(sys.argv[1]), int(sys.argv[2])
 wl = os.environ.get("VAR_WORKLOAD", "c3")
 cfg = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200) if wl in ("c3", "idle") else dict(baudRate=300, markFrequency=1070, spaceFrequency=1270)
+# per-stream tone pairs (round 6): c4 = BASELINE config #4, p3 = config #3's parameters with a tone pair per stream
+if wl == "c4": cfg = [dict(baudRate=300, markFrequency=1000 + 10 * (s %% 100), spaceFrequency=1200 + 10 * (s %% 100)) for s in range(S)]
+if wl == "p3": cfg = [dict(baudRate=1200, markFrequency=1200 + 7 * (s %% 13), spaceFrequency=2200 + 5 * (s %% 11)) for s in range(S)]
 eng = wm.FSKEngine(S, cfg, precision=wm.PRECISION_F32)
 st = torch.cuda.current_stream().cuda_stream
 x = torch.empty((S, N), dtype=torch.float32, device="cuda")
@@ -38,7 +41,7 @@ if wl == "idle":      # bench.py --workload idle: one frame per stream, then a f
         x[:, c0:n0] *= (torch.arange(c0, n0, device="cuda")[None, :] < torch.as_tensor(ends, device="cuda")[:, None])
     eng.add_awgn_device(x.data_ptr(), N, N, 30.0 - 10.0 * math.log10(N / float(fl)), 0xF5C0DE ^ 0xA36, st)
 else:
-    eng.synth_device(x.data_ptr(), N, N, 100 if wl == "c3" else 32, 0xF5C0DE, int(os.environ.get("VAR_LEAD", "400")), 0.1, 1.0, st)
+    eng.synth_device(x.data_ptr(), N, N, 100 if wl in ("c3", "p3") else 32, 0xF5C0DE, int(os.environ.get("VAR_LEAD", "400")), 0.1, 1.0, st)
 torch.cuda.synchronize()
 def step():
     eng.demodulate_device(x.data_ptr(), N, N, out.data_ptr(), op, cnt.data_ptr(), 0, 0, st)

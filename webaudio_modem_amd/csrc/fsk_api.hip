@@ -56,7 +56,7 @@ uint32_t demod_blk6_min_y_slots();
 bool demod_blk6_applicable(const DemodParams &P);
 size_t demod_blk6_max_samples();
 hipError_t set_blk6_lds_limit(const DemodParams &P);
-uint32_t demod_blk6_default_rolemap(uint32_t lanes);
+uint32_t demod_blk6_default_rolemap(uint32_t lanes, bool uniform);
 hipError_t launch_demod_blk6(bool writeback, bool append, const DemodParams &P, const DemodState &S, float *samples, size_t n,
                               size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts, uint32_t *eod_counts,
                               hipStream_t stream, uint32_t lanes, uint32_t y_slots, uint32_t rolemap);

@@ -1185,9 +1185,13 @@ hipError_t set_blk6_lds_limit(const DemodParams &P) {
 // default part of each wave (parts: 0 loader, 1 AGC, 2 pre-filter, 3 iq, 4 post, 5 frame, 6 disc).  Waves w and w + 4 of a
 // workgroup share a SIMD (its seven waves go round the CU's four): the frame logic -- the longest instruction stream and the one
 // every rare path runs on -- has a SIMD to itself, loader + post, AGC + pre-filter and iq + disc share.
-uint32_t demod_blk6_default_rolemap(uint32_t lanes) {
+uint32_t demod_blk6_default_rolemap(uint32_t lanes, bool uniform) {
   (void)lanes;
-  const uint32_t part[kB6Waves] = {0u, 1u, 3u, 5u, 6u, 2u, 4u};
+  // (per-stream tone pairs: the iq wave rotates a phasor per lane -- 83 instead of 66 busy cycles per sample -- and takes the
+  // pre-filter for a neighbour instead of the post wave: loader + AGC, iq + pre-filter, post + disc share; 89 -> 94 Gsamples/s at
+  // config #4's per-GPU share, profiles/r06_seven_wave_per_stream.txt)
+  const uint32_t part_u[kB6Waves] = {0u, 1u, 3u, 5u, 6u, 2u, 4u}, part_p[kB6Waves] = {0u, 3u, 4u, 5u, 1u, 2u, 6u};
+  const uint32_t *part = uniform ? part_u : part_p;
   uint32_t m = 0;
   for (uint32_t w = 0; w < kB6Waves; w++) m |= part[w] << (3u * w);
   return m;
@@ -1202,7 +1206,7 @@ hipError_t launch_demod_blk6(bool writeback, bool append, const DemodParams &P, 
   y_slots = y_slots < kB6YMin ? kB6YMin : y_slots > ymax ? ymax : y_slots;
   y_slots &= ~1u;
   const size_t lds = demod_blk6_lds_bytes(P, y_slots);
-  Blk6Z Z = {y_slots, blk6_zt_tiles(y_slots), rolemap ? rolemap : demod_blk6_default_rolemap(lanes)};
+  Blk6Z Z = {y_slots, blk6_zt_tiles(y_slots), rolemap ? rolemap : demod_blk6_default_rolemap(lanes, P.uni_cfg != 0u)};
 #define FSK_LAUNCH_B6(WBV, LWV)                                                                                      \
   do {                                                                                                               \
     if (P.uni_cfg != 0u)                                                                                             \
