@@ -820,6 +820,46 @@ def worker(args):
             side["iir"] = iir
         except Exception as ex:
             side["iir"] = {"error": str(ex)}
+        # (4b) one GPU's share of BASELINE config #4 over eight GPUs: 4 096 streams, 300 baud, every stream its own tone pair
+        # (mark_s = 1000 + 10 (s mod 100), space_s = mark_s + 200) -- since round 6 the seven-wave kernel's per-stream instantiation
+        try:
+            s4 = 4096
+            w4 = WORKLOADS["c4"]
+            cfgs4 = [dict(w4["cfg"], markFrequency=1000 + 10 * (s_ % 100), spaceFrequency=1200 + 10 * (s_ % 100)) for s_ in range(s4)]
+            e4 = wm.FSKEngine(s4, cfgs4, device=local_rank, precision=prec)
+            x4 = torch.empty((s4, pitch), dtype=torch.float32, device="cuda")
+            op4 = e4.max_bytes(N)
+            o4 = torch.empty((s4, op4), dtype=torch.uint8, device="cuda")
+            c4 = torch.empty(s4, dtype=torch.int32, device="cuda")
+            e4.synth_device(x4.data_ptr(), N, pitch, w4["payload"], seed, 10 * (sr // 300), 0.1, 1.0, stream)
+            torch.cuda.synchronize()
+
+            def step4():
+                e4.demodulate_device(x4.data_ptr(), N, pitch, o4.data_ptr(), op4, c4.data_ptr(), 0, 0, stream)
+            step4()
+            sync()
+            chk4 = {"streams_checked": 0, "streams_byte_identical": 0}
+            if args.cpu_seconds > 0:
+                from oracle import pyoracle as po
+                rows4 = np.unique(np.linspace(0, s4 - 1, int(max(4, 0.25 * args.cpu_seconds * 7.0e6 // N))).astype(np.int64))
+                i4 = torch.as_tensor(rows4, device="cuda")
+                xs4 = x4.index_select(0, i4)[:, :N].cpu().numpy()
+                b4 = o4.index_select(0, i4).cpu().numpy()
+                n4 = c4.index_select(0, i4).cpu().numpy().astype(np.int64)
+                same4 = sum(1 for j, s_ in enumerate(rows4) if po.OracleCore(cfgs4[int(s_)]).demodulate(xs4[j])[0] == b4[j, :n4[j]].tobytes())
+                chk4 = {"streams_checked": int(len(rows4)), "streams_byte_identical": int(same4)}
+                if same4 != len(rows4):
+                    parity_ok = False
+            nl, ms = timed_steps(sync, e4, step4, k_side)
+            r4 = s4 * N * nl / (ms / 1e3) / 1e6
+            side["c4_per_gpu_share"] = {"streams": s4, "samples_per_stream": N, "kernel": e4.last_kernel(), "streams_per_workgroup": e4.blk_lanes(),
+                                        "Msamples_per_s": round(r4, 1), "frac_of_hbm_peak": round(r4 * 4 / 1e3 / HBM_PEAK_GBS, 4),
+                                        "x8_GPUs_Msamples_per_s": round(8 * r4, 1), **chk4,
+                                        "note": "BASELINE config #4 (32 768 streams with per-stream mark / space, 300 baud) as one of eight GPUs would hold it"}
+            e4.close()
+            del x4, o4, c4
+        except Exception as ex:
+            side["c4_per_gpu_share"] = {"error": str(ex)}
         # (5) the unfavourable shapes of the SAME batch size: the resident buffer regenerated in place, LAST (nothing
         # above needs the headline's signal any more).  staggered: every stream's frames at a random offset within one frame length
         # (a reset in some lane of a wave every few tiles; the headline's streams all start within ten bit cells of one another);

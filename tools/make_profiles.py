@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 F = os.path.join(ROOT, "gpurun_out", "final")
 P = os.path.join(ROOT, "profiles")
 KERNEL = "fsk::demod_blk_kernel<false, true, false>"
@@ -40,7 +40,7 @@ for name in ("pmc_insts.txt", "pmc_fetch.txt", "pmc_write.txt", "pmc_clock.txt",
     src = os.path.join(F, name)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, "%s_final_%s" % (rnd, name)))
-for name in ("bench", "bench_c2", "bench_c4", "bench_c5", "bench_idle", "bench_idle4", "bench_mod", "bench_mod_f64", "bench_c1x", "bench_f64", "bench_8192", "bench_2048", "bench_4096", "bench_16384", "bench_staggered"):
+for name in ("bench", "bench_c2", "bench_c4", "bench_c5", "bench_idle", "bench_idle4", "bench_mod", "bench_mod_f64", "bench_c1x", "bench_f64", "bench_8192", "bench_2048", "bench_4096", "bench_16384", "bench_staggered", "bench_c4_4096"):
     src = os.path.join(F, name + ".txt")
     if os.path.exists(src):
         lines = [l for l in open(src) if l.startswith("{")]
