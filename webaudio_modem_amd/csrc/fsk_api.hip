@@ -18,7 +18,7 @@
 namespace fsk {
 hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, bool append, const DemodParams &P,
                         const DemodState &S, float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch,
-                        uint32_t *out_counts, uint32_t *eod_counts, hipStream_t stream);
+                        uint32_t *out_counts, uint32_t *eod_counts, hipStream_t stream, bool split2 = false);
 bool demod_fast_applicable(int precision, bool uniform_even, const DemodParams &P, const DemodState &S,
                            const float *samples, size_t pitch);
 // fsk_pipe.hip: free-running front / ZIR-corrected back kernels
@@ -31,6 +31,8 @@ hipError_t launch_demod_fused(bool writeback, bool append, const DemodParams &P,
 hipError_t launch_demod_tail(bool writeback, bool append, int parity0, const DemodParams &P, const DemodState &S,
                              float *samples, size_t n, size_t pitch, uint8_t *out, size_t out_pitch, uint32_t *out_counts,
                              uint32_t *eod_counts, hipStream_t stream);
+size_t demod_split2_lds_bytes(const DemodParams &P);
+hipError_t set_demod_split2_lds_limit(size_t lds_bytes);
 size_t demod_pipe_lds_bytes(const DemodParams &P);
 size_t demod_fused_lds_bytes(const DemodParams &P);
 // fsk_blk.hip: four waves per group, block-batched back wave
@@ -227,6 +229,10 @@ struct fskhip_engine {
   // five waves per group (demod_blk5_kernel, round 6): the front wave's two halves on a wave each.  0 never, 1 wherever the plain
   // four-wave kernel would run ("kernel" = five-wave), 2 auto: batches of whole-wave groups that fill the device
   uint32_t use_five = 0;
+  // the exact path (fp64, fsk_demod.hip) on two waves per 64-stream group -- loads + AGC + pre-filter | the rest (SPLIT2): 0 never,
+  // 1 wherever it applies ("exact_waves" = 2), 2 auto: batches of at most one group per SIMD (4 x compute units), where the one-wave
+  // kernel leaves every SIMD a single instruction stream
+  uint32_t exact_split = 2;
   uint32_t blk5_y_slots = 6, blk5_resident = 0;
   // "blk_resets": which of fsk_blk.hip's two kernels a call launches -- demod_blk_kernel_r, whose block path takes 'eod' resets
   // itself, pays where resets are frequent (an idle receiver bank: +50 %) and costs ~4 % where they are rare.  auto: by the
@@ -676,6 +682,9 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
     CREATE_TRY(hipDeviceSynchronize());
   }
   if (e->demod_ok && e->lds_bytes > 48 * 1024) CREATE_TRY(set_demod_lds_limit(e->lds_bytes));
+  if (e->demod_ok && precision == FSKHIP_PRECISION_F64 && !P.wide && !P.frac && demod_split2_lds_bytes(P) > 48 * 1024 && demod_split2_lds_bytes(P) <= 160 * 1024)
+    CREATE_TRY(set_demod_split2_lds_limit(demod_split2_lds_bytes(P)));
+  if (hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) e->cus = 0;
   if (e->demod_ok && !P.wide && !P.frac && precision == FSKHIP_PRECISION_F32 && demod_pipe_lds_bytes(P) <= 160 * 1024)
     CREATE_TRY(set_pipe_lds_limit(demod_pipe_lds_bytes(P)));
   if (e->demod_ok && precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(P)) {
@@ -788,6 +797,12 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
       seen |= 1u << r; m |= r << (3u * w);
     }
     e->six_rolemap = m;
+    return FSKHIP_OK;
+  }
+  if (k == "exact_waves") {       // the fp64 kernel: auto | 1 (one wave per 64-stream group) | 2 (two: loads + AGC + pre-filter | the rest)
+    if (v == "auto") { e->exact_split = 2u; return FSKHIP_OK; }
+    if ((rc = number(1, 2, &x)) != FSKHIP_OK) return rc;
+    e->exact_split = x == 2 ? 1u : 0u;
     return FSKHIP_OK;
   }
   if (k == "force_generic") {
@@ -1007,9 +1022,12 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
       }
     } else {
       e->P.nco_anchor = (uint32_t)(e->total_samples & 31u);   // (fp64: where the NCO phasor is re-evaluated; fsk_demod.hip, mix_lp)
+      const bool split2 = e->precision == FSKHIP_PRECISION_F64 && e->ds_uniform && !e->P.wide && !e->P.frac && e->S.trace_stream == 0xFFFFFFFFu &&
+                          !e->P.quality && demod_split2_lds_bytes(e->P) <= 160 * 1024 &&
+                          (e->exact_split == 1u || (e->exact_split == 2u && e->cus > 0 && e->n_blocks <= 4u * (uint32_t)e->cus && n >= 64));
       HIP_TRY(launch_demod(e->precision, e->ds_uniform, wb, append_first, e->P, e->S, d_samples, n, pitch, d_out, out_pitch,
-                           d_out_counts, d_eod_counts, st));
-      e->last_kernel = e->precision == FSKHIP_PRECISION_F64 ? "fsk::demod_kernel<double, ...>" : "fsk::demod_kernel<float, ...>";
+                           d_out_counts, d_eod_counts, st, split2));
+      e->last_kernel = split2 ? "fsk::demod_kernel<double, ..., two waves>" : e->precision == FSKHIP_PRECISION_F64 ? "fsk::demod_kernel<double, ...>" : "fsk::demod_kernel<float, ...>";
       // the generic kernel keeps an open decimator pair's partial sums in the reference's own frame: stay with it
       // until the pair is closed
       if (n > 0) e->gen_odd = e->precision == FSKHIP_PRECISION_F32 && ((e->ds_parity + (uint32_t)(n & 1)) & 1u) != 0;

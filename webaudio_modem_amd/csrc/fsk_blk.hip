@@ -215,6 +215,10 @@ __device__ inline uint32_t blk_medium(BackLane &Bn, const BackK &K, const BlkK &
 #ifndef FSK_BLK_PRIO_PERIOD
 #define FSK_BLK_PRIO_PERIOD 64
 #endif
+// demod_blk_kernel_r / _rp: fixed priority levels by part (1, see BYROLE below) or the plain kernel's rotation (0: measurement builds)
+#ifndef FSK_BLK_R_BYROLE
+#define FSK_BLK_R_BYROLE 1
+#endif
 // BYROLE (demod_blk_kernel_r): fixed levels by part instead, the back wave highest -- in the calls that kernel is picked for
 // the back wave IS the group's time and the other three mostly wait; measured on the idle bank 291 -> 312 Gsamples/s
 // (and the rotation, which evens out four equally loaded groups of a CU, has nothing to even out there).
@@ -532,7 +536,7 @@ __device__ __forceinline__ void demod_blk_body(
     const uint32_t nt = (uint32_t)n_tiles;
     FSK_STAMP_BEGIN
     for (uint32_t t0 = 0; t0 < nt; t0 += 96u) {             // (a multiple of three tiles and of 64 half tiles)
-      blk_prio<MED>(2u * t0, wgj, 0u);
+      blk_prio<(MED && FSK_BLK_R_BYROLE)>(2u * t0, wgj, 0u);
       const uint32_t te = t0 + 96u < nt ? t0 + 96u : nt;
       for (uint32_t t = t0; t < te; t += 3) {
         do_tile(t, a0, a1, a2, a3);
@@ -561,7 +565,7 @@ __device__ __forceinline__ void demod_blk_body(
     const uint32_t nt = (uint32_t)n_tiles;
     FSK_STAMP_BEGIN
     for (uint32_t t = 0; t < nt; t++) {
-      if ((t & 31u) == 0u) blk_prio<MED>(2u * t, wgj, 0u);
+      if ((t & 31u) == 0u) blk_prio<(MED && FSK_BLK_R_BYROLE)>(2u * t, wgj, 0u);
       const uint32_t hidx = 2u * t;
       v4u32 cv, cw;
       lds_peek4_begin(ctr, cv);                             // (read now, looked at after the tile: see lds_peek4_begin)
@@ -700,7 +704,7 @@ __device__ __forceinline__ void demod_blk_body(
     const uint32_t nt = (uint32_t)n_tiles;
     FSK_STAMP_BEGIN
     for (uint32_t t0 = 0; t0 < nt; t0 += 96u) {             // (a multiple of three tiles and of 64 half tiles)
-      blk_prio<MED>(2u * t0, wgj, 0u);
+      blk_prio<(MED && FSK_BLK_R_BYROLE)>(2u * t0, wgj, 0u);
       const uint32_t te = t0 + 96u < nt ? t0 + 96u : nt;
       for (uint32_t t = t0; t < te; t += 3) {
         do_tile(t, a0, a1, a2, a3);
@@ -737,7 +741,7 @@ __device__ __forceinline__ void demod_blk_body(
     FSK_STAMP_BEGIN
     uint32_t hidx = 0;                                        // half tiles done; this wave works a tile (two of them) at a time
     while (hidx < nh) {
-      if ((hidx & 63u) == 0u) blk_prio<MED>(hidx, wgj, 1u);
+      if ((hidx & 63u) == 0u) blk_prio<(MED && FSK_BLK_R_BYROLE)>(hidx, wgj, 1u);
       if (produced < hidx + 2u || hidx + 2u - consumed > kBlkSlots) {
         FSK_STAMP_W0
         while (produced < hidx + 2u) {                        // wave 0's tile
@@ -847,7 +851,7 @@ __device__ __forceinline__ void demod_blk_body(
     FSK_STAMP_BEGIN
     uint32_t hidx = 0;                                        // half tiles done; a tile (two of them, eight decimated samples) at a time
     while (hidx < nh) {
-      if ((hidx & 63u) == 0u) blk_prio<MED>(hidx, wgj, 2u);
+      if ((hidx & 63u) == 0u) blk_prio<(MED && FSK_BLK_R_BYROLE)>(hidx, wgj, 2u);
       if (produced < hidx + 2u) {
         FSK_STAMP_W0
         while (produced < hidx + 2u) {
@@ -993,7 +997,7 @@ __device__ __forceinline__ void demod_blk_body(
     FSK_STAMP_BEGIN
     uint32_t t = 0;                                           // half tiles consumed (a block = a tile = two of them)
     while (t < nh) {
-      blk_prio<MED>(t & ~15u, wgj, 3u);                            // (t advances in steps of two; the outer loop sees every multiple of 16)
+      blk_prio<(MED && FSK_BLK_R_BYROLE)>(t & ~15u, wgj, 3u);                            // (t advances in steps of two; the outer loop sees every multiple of 16)
       if (produced < t + 2u) {
         FSK_STAMP_W0
         while (produced < t + 2u) {

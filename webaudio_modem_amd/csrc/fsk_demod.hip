@@ -707,8 +707,16 @@ __device__ inline bool block_fsm8(Lane<Real> &L, const DemodParams &P, const Dem
 // ------------------------------------------------------------------------------------------------
 // fp32 kernels are capped at 128 VGPRs (4 waves/SIMD): the chain is VALU-bound and one wave per
 // SIMD issues a VALU op only every 4 cycles (MI355X_MICROARCH.md), so occupancy is throughput.
-template <typename Real, typename PolyT, bool FRAC, bool UNI, bool TRACE>
-__global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1)) void demod_kernel(DemodParams P, DemodState S, float *__restrict__ samples,
+// SPLIT2 (round 6, the exact path at batches of one wave per SIMD): TWO waves per 64-stream group.  Wave 0 is the part of the chain
+// that resetState() never touches (fsk.ts:175-188) -- tile loads, AGC with its correctly rounded division, pre-filter, the
+// Float32Array store of fsk.ts:202 -- and hands the pre-filter's floats to wave 1 through a ring of kPreTiles tiles in LDS; wave 1 is
+// everything from the NCO on, exactly the one-wave kernel's code with those floats for input.  Exact by construction: the hand-over
+// is the reference's own Float32Array, and nothing behind it feeds back into what is in front of it.  What it buys: a double-
+// precision instruction occupies the pipe for 4 cycles while a lone wave issues one instruction per ~5.7 -- two instruction
+// streams per SIMD instead of one.
+static constexpr uint32_t kPreTiles = 3;
+template <typename Real, typename PolyT, bool FRAC, bool UNI, bool TRACE, bool SPLIT2 = false>
+__global__ __launch_bounds__(SPLIT2 ? 128 : 64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : SPLIT2 ? 2 : 1)) void demod_kernel(DemodParams P, DemodState S, float *__restrict__ samples,
                                                    size_t n, size_t pitch, int vec_ok, int writeback, int append,
                                                    uint8_t *__restrict__ out, size_t out_pitch,
                                                    uint32_t *__restrict__ out_counts,
@@ -719,8 +727,12 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
   PolyT *gpoly = (PolyT *)S.poly + (size_t)blockIdx.x * P.d * 64u;   // this wave's registers in HBM
   PolyT *poly_u = poly + (FRAC ? 64u * P.d : 0u);
   PolyT *gpoly_u = (PolyT *)S.poly_u + (size_t)blockIdx.x * P.d * 64u;
+  // SPLIT2: [kPreTiles][kChunks][64] float4 of pre-filter outputs (lane = stream, four consecutive samples), then two counters
+  float4 *pring = reinterpret_cast<float4 *>(reinterpret_cast<char *>(poly) + (((FRAC ? 2u : 1u) * sizeof(PolyT) * 64u * P.d + 15u) & ~(size_t)15u));
+  uint32_t *pctr = reinterpret_cast<uint32_t *>(pring + kPreTiles * kChunks * 64);     // [0] tiles produced, [1] tiles consumed
+  const uint32_t wave2 = SPLIT2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
 
-  const uint32_t lane = threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
   const uint32_t stream = blockIdx.x * 64u + lane;
   const bool valid = stream < P.n_streams;
   const uint32_t row = valid ? stream : P.n_streams - 1;
@@ -733,9 +745,15 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
   L.thr_eff = L.started ? 0xFFFFFFFFu : P.matched_min;
   Consts<Real> C;
   C.init(P, S, row);
-  for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
-  if (FRAC)
-    for (uint32_t p = 0; p < P.d; p++) poly_u[p * 64u + lane] = gpoly_u[p * 64u + lane];
+  if (!SPLIT2 || wave2 == 1u) {
+    for (uint32_t p = 0; p < P.d; p++) poly[p * 64u + lane] = gpoly[p * 64u + lane];
+    if (FRAC)
+      for (uint32_t p = 0; p < P.d; p++) poly_u[p * 64u + lane] = gpoly_u[p * 64u + lane];
+  }
+  if (SPLIT2) {
+    if (threadIdx.x == 0) { pctr[0] = 0u; pctr[1] = 0u; }
+    __syncthreads();
+  }
 
   // ring positions: wave-uniform (SGPR) in UNI launches
   RingPos R;
@@ -802,9 +820,14 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
     }
   };
 
+  // (SPLIT2, wave 1: the input IS the pre-filter's output)
+  auto pre_in = [&](float x, float &wbv) -> float {
+    if (SPLIT2) { wbv = x; return x; }
+    return pre_stage(L, C, agc_on, x, wbv);
+  };
   // generic path: one sample at a time, per-lane decimator phase (fsk.ts:224-276 as written)
   auto step_generic = [&](float x, float &wbv) {
-    float pre_y = pre_stage(L, C, agc_on, x, wbv);
+    float pre_y = pre_in(x, wbv);
     if (TRACE) { if (stream == S.trace_stream) trace_pre_put(S, (double)pre_y); }
     Real fi, fq;
     mix_lp(L, C, pre_y, fi, fq);
@@ -864,7 +887,7 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
 #endif
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      pre_y[k] = pre_stage(L, C, agc_on, x[k], wbv[k]);
+      pre_y[k] = pre_in(x[k], wbv[k]);
       mix_lp<true>(L, C, pre_y[k], fi[k], fq[k]);
     }
     if (TRACE) {
@@ -919,9 +942,9 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       Real fi0, fq0, fi1, fq1;
-      const float y0 = pre_stage(L, C, agc_on, x[2 * j], wbv[2 * j]);
+      const float y0 = pre_in(x[2 * j], wbv[2 * j]);
       mix_lp<true>(L, C, y0, fi0, fq0);
-      const float y1 = pre_stage(L, C, agc_on, x[2 * j + 1], wbv[2 * j + 1]);
+      const float y1 = pre_in(x[2 * j + 1], wbv[2 * j + 1]);
       mix_lp<true>(L, C, y1, fi1, fq1);
       pre16[2 * j] = y0; pre16[2 * j + 1] = y1;
       const bool bit = discriminate(L, C, fi0 + fi1, fq0 + fq1, amp[j], post[j]);
@@ -942,14 +965,75 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
   // the sixteen-sample block: fp64 only (registers: one wave per SIMD), at most one bit decision per eight decimated samples, none
   // of the opt-in estimates (they hook the per-sample state machine)
   const bool fast16 = fast && sizeof(Real) == 8 && P.d >= 8 && P.cadence > 0 && !P.quality;
-  bool cur_fast = n > 0 && tile_is_fast(0);
+  auto ctr_peek = [&](const uint32_t *q) -> uint32_t {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)q) : "memory");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  };
+  auto ctr_post = [&](uint32_t *q, uint32_t v) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" : : "v"((uint32_t)(uintptr_t)q), "v"(v) : "memory");
+  };
+  if (SPLIT2 && wave2 == 0u) {
+    // ---- wave 0: loads, AGC, pre-filter -> the ring (and the AGC write-back)
+    bool cf = n > 0 && tile_is_fast(0);
+    if (cf) load_tile_fast(0);
+    uint32_t consumed = 0, ti = 0;
+    for (size_t t0 = 0; t0 < n; t0 += kTile, ti++) {
+      if (cf) {
+#pragma unroll
+        for (int i = 0; i < kChunks; i++) stage[chunk * kSlotStride + (uint32_t)kRowsPerLoad * i + sub_row] = pre[i];
+      } else {
+        stage_tile_slow(t0);
+      }
+      cf = (t0 + kTile < n) && tile_is_fast(t0 + kTile);
+      if (cf) load_tile_fast(t0 + kTile);
+      while (ti - consumed >= kPreTiles) {                    // ring full: wave 1 has not released the slot
+        consumed = ctr_peek(&pctr[1]);
+        if (ti - consumed >= kPreTiles) __builtin_amdgcn_s_sleep(1);
+      }
+      float4 *dstt = pring + (ti % kPreTiles) * kChunks * 64u;
+      const uint32_t tile_len = (uint32_t)((n - t0) < (size_t)kTile ? (n - t0) : (size_t)kTile);
+      const uint32_t n_chunks = (tile_len + 3u) >> 2;
+      for (uint32_t c = 0; c < n_chunks; c++) {
+        const float4 v4 = stage[c * kSlotStride + lane];
+        const float xv[4] = {v4.x, v4.y, v4.z, v4.w};
+        float y[4], wb[4];
+        const uint32_t lim = tile_len - 4u * c < 4u ? tile_len - 4u * c : 4u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                         // (a ragged last chunk: samples beyond the call's end are not there)
+          y[k] = 0.f; wb[k] = 0.f;
+          if ((uint32_t)k < lim) y[k] = pre_stage(L, C, agc_on, xv[k], wb[k]);
+        }
+        dstt[c * 64u + lane] = make_float4(y[0], y[1], y[2], y[3]);
+        if (writeback && valid) {
+          float *dst = samples + (size_t)row * pitch + t0 + 4u * c;
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if ((uint32_t)k < lim) dst[k] = wb[k];
+        }
+      }
+      ctr_post(&pctr[0], ti + 1u);
+    }
+  } else {
+  bool cur_fast = !SPLIT2 && n > 0 && tile_is_fast(0);
   if (cur_fast) load_tile_fast(0);
+  uint32_t produced2 = 0, ti2 = 0;
   // fp64: the NCO phasor afresh from the exact phase (mix_lp) where the stream's absolute sample count is a multiple of 32 -- sample
   // nco_r0 of every tile of this call (tiles are 32 samples; P.nco_anchor = samples the engine had taken before the call, mod 32)
   static_assert(kTile == 32, "the NCO refresh period is a tile");
   const uint32_t nco_r0 = sizeof(Real) == 8 ? ((32u - (P.nco_anchor & 31u)) & 31u) : 0u;
   for (size_t t0 = 0; t0 < n; t0 += kTile) {
     if (nco_r0 == 0u) nco_refresh(L, C);
+    const float4 *tin = stage;                              // this tile's input: [chunk][tstride] float4, lane = stream
+    uint32_t tstride = kSlotStride;
+    if (SPLIT2) {
+      while (produced2 <= ti2) {                            // wave 0's tile
+        produced2 = ctr_peek(&pctr[0]);
+        if (produced2 <= ti2) __builtin_amdgcn_s_sleep(1);
+      }
+      tin = pring + (ti2 % kPreTiles) * kChunks * 64u;
+      tstride = 64u;
+    } else {
     __syncthreads();  // single-wave workgroup: orders last tile's LDS reads before the overwrite
     if (cur_fast) {
 #pragma unroll
@@ -960,11 +1044,12 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
     __syncthreads();
     cur_fast = (t0 + kTile < n) && tile_is_fast(t0 + kTile);
     if (cur_fast) load_tile_fast(t0 + kTile);
+    }
 
     const uint32_t tile_len = (uint32_t)((n - t0) < (size_t)kTile ? (n - t0) : (size_t)kTile);
     const uint32_t n_chunks = (tile_len + 3u) >> 2;
     for (uint32_t c = 0; c < n_chunks; c++) {
-      float4 v4 = stage[c * kSlotStride + lane];
+      float4 v4 = tin[c * tstride + lane];
       float xv[4] = {v4.x, v4.y, v4.z, v4.w};
       float wb[4];
       const uint32_t lim = tile_len - 4u * c < 4u ? tile_len - 4u * c : 4u;
@@ -978,7 +1063,7 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
         float x16[16], wb16[16];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const float4 u4 = stage[(c + q) * kSlotStride + lane];
+          const float4 u4 = tin[(c + q) * tstride + lane];
           x16[4 * q] = u4.x; x16[4 * q + 1] = u4.y; x16[4 * q + 2] = u4.z; x16[4 * q + 3] = u4.w;
         }
         if (!block16(x16, wb16)) {                               // something rare in these sixteen samples: the per-sample order
@@ -989,7 +1074,7 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
             wb16[4 * q] = wq[0]; wb16[4 * q + 1] = wq[1]; wb16[4 * q + 2] = wq[2]; wb16[4 * q + 3] = wq[3];
           }
         }
-        if (writeback && valid) {
+        if (writeback && valid && !SPLIT2) {
           float *dst = samples + (size_t)row * pitch + t0 + 4u * c;
 #pragma unroll
           for (int k = 0; k < 16; k++) dst[k] = wb16[k];
@@ -1000,24 +1085,26 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
       if (fast && lim == 4u && !r_in4) {
         block4(xv, wb);
       } else {
-        const float *xs = reinterpret_cast<const float *>(&stage[c * kSlotStride + lane]);
+        const float *xs = reinterpret_cast<const float *>(&tin[c * tstride + lane]);
 #pragma unroll 1
         for (uint32_t k = 0; k < lim; k++) {
           float w;
           if (r_in4 && s0 + k == nco_r0) nco_refresh(L, C);
           step_generic(xs[k], w);
-          if (writeback && valid) samples[(size_t)row * pitch + t0 + 4u * c + k] = w;
+          if (writeback && valid && !SPLIT2) samples[(size_t)row * pitch + t0 + 4u * c + k] = w;
         }
         continue;
       }
-      if (writeback && valid) {
+      if (writeback && valid && !SPLIT2) {
         float *dst = samples + (size_t)row * pitch + t0 + 4u * c;
 #pragma unroll
         for (int k = 0; k < 4; k++)
           if ((uint32_t)k < lim) dst[k] = wb[k];
       }
     }
+    if (SPLIT2) { ti2++; ctr_post(&pctr[1], ti2); }        // (the tile's reads are complete: ctr_post waits for them)
   }
+  }   // (wave 1 / the one-wave kernel)
 
   // ring bookkeeping back to per-stream state
   {
@@ -1028,6 +1115,18 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
     L.poly_phase = R.phase;
     L.amp_pos = R.amp_pos;
   }
+  if (SPLIT2 && wave2 == 0u) {
+    // wave 0's share of the state: the AGC gain and the pre-filter's history -- written AFTER wave 1 has stored the lane (its copies
+    // of these five are the launch's start values)
+    __syncthreads();
+    if (valid) {
+      Real *rs = (Real *)S.rs;
+      rs[(size_t)RF_agc_gain * ns + row] = L.agc_gain;
+      rs[(size_t)RF_bp_x1 * ns + row] = L.bp_x1; rs[(size_t)RF_bp_x2 * ns + row] = L.bp_x2;
+      rs[(size_t)RF_bp_y1 * ns + row] = L.bp_y1; rs[(size_t)RF_bp_y2 * ns + row] = L.bp_y2;
+    }
+    return;
+  }
   for (uint32_t p = 0; p < P.d; p++) gpoly[p * 64u + lane] = poly[p * 64u + lane];
   if (FRAC)
     for (uint32_t p = 0; p < P.d; p++) gpoly_u[p * 64u + lane] = poly_u[p * 64u + lane];
@@ -1037,6 +1136,7 @@ __global__ __launch_bounds__(64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : 1
     out_counts[stream] = O.out_cnt;
     if (eod_counts) eod_counts[stream] = O.eod_cnt;
   }
+  if (SPLIT2) __syncthreads();
 }
 
 
@@ -1058,6 +1158,10 @@ size_t demod_lds_bytes(const DemodParams &P) {
   const size_t reg = (P.wide ? sizeof(uint64_t) : sizeof(uint32_t)) * 64u * P.d;
   return sizeof(float4) * kChunks * kSlotStride + reg * (P.frac ? 2u : 1u);
 }
+// ... of the two-wave exact kernel (SPLIT2): the pre-filter ring and its two counters behind the polyphase registers
+size_t demod_split2_lds_bytes(const DemodParams &P) {
+  return ((demod_lds_bytes(P) + 15u) & ~(size_t)15u) + sizeof(float4) * kPreTiles * kChunks * 64u + 16u;
+}
 
 // kernel variants: Real x {u32, u64, u64+frac} x {uniform, per-lane decimator phase} x trace
 #define FSK_FOR_RT(X, R, T, F)                                                                     \
@@ -1072,7 +1176,7 @@ size_t demod_lds_bytes(const DemodParams &P) {
 hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, bool append, const DemodParams &P,
                         const DemodState &S, float *samples, size_t n, size_t pitch, uint8_t *out,
                         size_t out_pitch, uint32_t *out_counts, uint32_t *eod_counts,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool split2) {
   const uint32_t blocks = (P.n_streams + 63u) / 64u;
   const size_t lds_bytes = demod_lds_bytes(P);
   const int vec_ok = (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(samples) & 15u) == 0);
@@ -1082,7 +1186,12 @@ hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, bool app
 #endif
   const bool f64 = precision != 0, wide = P.wide != 0, frac = P.frac != 0;
   const bool trace = S.trace_stream != 0xFFFFFFFFu;
-  dim3 g(blocks), b(64);
+ dim3 g(blocks), b(64);
+  if (split2 && f64 && !wide && !frac && uniform_ds && !trace) {     // the exact path on two waves per group (SPLIT2)
+    hipLaunchKernelGGL((demod_kernel<double, uint32_t, false, true, false, true>), g, dim3(128), demod_split2_lds_bytes(P), stream, P, S, samples, n,
+                       pitch, vec_ok, wb, append ? 1 : 0, out, out_pitch, out_counts, eod_counts);
+    return hipGetLastError();
+  }
 #define FSK_LAUNCH(R, T, F, U, TR)                                                                 \
   if (f64 == (sizeof(R) == 8) && wide == (sizeof(T) == 8) && frac == F && uniform_ds == U &&       \
       trace == TR)                                                                                 \
@@ -1091,6 +1200,11 @@ hipError_t launch_demod(int precision, bool uniform_ds, bool writeback, bool app
   FSK_FOR_ALL_VARIANTS(FSK_LAUNCH)
 #undef FSK_LAUNCH
   return hipGetLastError();
+}
+
+hipError_t set_demod_split2_lds_limit(size_t lds_bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(&demod_kernel<double, uint32_t, false, true, false, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
 hipError_t set_demod_lds_limit(size_t lds_bytes) {
