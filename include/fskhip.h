@@ -308,6 +308,9 @@ int fskhip_timing_end(fskhip_engine *e, uint32_t *n_launches, double *total_ms);
  *                                   unit allows at this dsSPB; lower limit: 2 + the half tiles its iq wave may lead the frame wave by).  Values
  *                                   outside what the kernel can use are FSKHIP_E_INVALID, as for blk_y_slots (they used to be clamped silently)
  *   "stage_roles"    auto | seven digits, a permutation of 0..6: the part each of a workgroup's seven waves plays (measurements)
+ *   "exact_waves"    auto | 1 | 2   the fp64 kernel on one wave per 64-stream group (auto) or on two (loads + AGC + pre-filter | the rest:
+ *                                   exact by construction -- the hand-over is the reference's own Float32Array, fsk.ts:202 -- and bit-identical, but
+ *                                   slower at this register budget; kept for measurements)
  *   "force_generic"  0 | 1          never a whole-tile kernel: the sample-serial kernel only
  *   "blk_y_slots"    6 .. 28        depth of the four-wave kernel's first ring (checked against the LDS it needs)
  *   "blk_min_tiles"  n              calls with fewer whole tiles stay off the four-wave kernel

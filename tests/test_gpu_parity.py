@@ -808,3 +808,44 @@ def test_fp64_path_is_cut_invariant_bit_for_bit():
         for k in ("amp", "post_out", "pre_out"):
             assert np.array_equal(r[3][k].view(np.uint64), r0[3][k].view(np.uint64)), (sched, k)
         assert np.array_equal(r[3]["bit"], r0[3]["bit"]), sched
+
+
+def test_exact_path_on_two_waves_is_the_one_wave_kernel_bit_for_bit():
+    """Round 6 (second half): the fp64 kernel cut in two where resetState() never reaches -- loads + AGC + pre-filter | NCO
+    ... frame logic, the pre-filter's floats handed over through LDS (option exact_waves = 2).  Exact by construction; here: bytes, 'eod'
+    counts, every state word and the AGC write-back identical to the one-wave kernel on a ragged schedule.  (Not the default: at two
+    waves per SIMD the back wave spills, 156 against 180 Gsamples/s -- DESIGN section 4.3.)"""
+    import webaudio_modem_amd as wm
+    g = golden()
+    base = g.array("d_noise_bell_10dB_0.in")
+    bell = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
+    S = 150
+    x = np.zeros((S, 2 * base.size + 500), np.float32)
+    for s in range(S):
+        for k in range(2):
+            o = 7 * s + k * (base.size + 60)
+            x[s, o:o + base.size] = base[:x.shape[1] - o] * (0.2 + 0.005 * s)
+    N = x.shape[1]
+    res = []
+    for waves in (1, 2):
+        eng = wm.FSKEngine(S, bell, precision=wm.PRECISION_F64, options={"exact_waves": waves})
+        rows, eods, wb = [b""] * S, np.zeros(S, np.int64), []
+        off = 0
+        for n in [4096, 33, 1, 128, 5000, 17, 10 ** 9]:
+            n = min(n, N - off)
+            if n <= 0:
+                break
+            chunk = x[:, off:off + n].copy()
+            out, eod = eng.demodulate_data(chunk, writeback_agc=True)
+            wb.append(chunk)
+            rows = [a + b for a, b in zip(rows, out)]
+            eods += np.asarray(eod, np.int64)
+            off += n
+        assert ("two waves" in eng.last_kernel()) == (waves == 2), eng.last_kernel()
+        res.append((rows, eods, [eng.debug_state(s) for s in range(S)], np.concatenate(wb, axis=1)))
+        eng.close()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    assert sum(len(r) for r in res[0][0]) > 10 * S
+    assert np.array_equal(res[0][3], res[1][3])
+    for (ra, ia), (rb, ib) in zip(res[0][2], res[1][2]):
+        assert np.array_equal(np.asarray(ra).view(np.uint64), np.asarray(rb).view(np.uint64)) and ia == ib

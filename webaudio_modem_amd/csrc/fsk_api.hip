@@ -229,10 +229,11 @@ struct fskhip_engine {
   // five waves per group (demod_blk5_kernel, round 6): the front wave's two halves on a wave each.  0 never, 1 wherever the plain
   // four-wave kernel would run ("kernel" = five-wave), 2 auto: batches of whole-wave groups that fill the device
   uint32_t use_five = 0;
-  // the exact path (fp64, fsk_demod.hip) on two waves per 64-stream group -- loads + AGC + pre-filter | the rest (SPLIT2): 0 never,
-  // 1 wherever it applies ("exact_waves" = 2), 2 auto: batches of at most one group per SIMD (4 x compute units), where the one-wave
-  // kernel leaves every SIMD a single instruction stream
-  uint32_t exact_split = 2;
+  // the exact path (fp64, fsk_demod.hip) on two waves per 64-stream group -- loads + AGC + pre-filter | the rest (SPLIT2): 0 never
+  // (the default: measured SLOWER, 156 against 180 Gsamples/s at config #3 -- at two waves per SIMD the back wave has 256 registers and
+  // spills 864 bytes per lane, where the one-wave kernel spreads into the accumulation registers), 1 wherever it applies
+  // ("exact_waves" = 2: bit-identical, tests/test_gpu_parity.py), 2 batches of at most one group per SIMD
+  uint32_t exact_split = 0;
   uint32_t blk5_y_slots = 6, blk5_resident = 0;
   // "blk_resets": which of fsk_blk.hip's two kernels a call launches -- demod_blk_kernel_r, whose block path takes 'eod' resets
   // itself, pays where resets are frequent (an idle receiver bank: +50 %) and costs ~4 % where they are rare.  auto: by the
@@ -800,7 +801,7 @@ int fskhip_set_option(fskhip_engine *e, const char *name, const char *value) {
     return FSKHIP_OK;
   }
   if (k == "exact_waves") {       // the fp64 kernel: auto | 1 (one wave per 64-stream group) | 2 (two: loads + AGC + pre-filter | the rest)
-    if (v == "auto") { e->exact_split = 2u; return FSKHIP_OK; }
+    if (v == "auto") { e->exact_split = 0u; return FSKHIP_OK; }     // (auto = one wave: the two-wave cut does not pay, see exact_split)
     if ((rc = number(1, 2, &x)) != FSKHIP_OK) return rc;
     e->exact_split = x == 2 ? 1u : 0u;
     return FSKHIP_OK;
