@@ -285,8 +285,8 @@ def blk6_resources():
             res[cur][m.group(1)] = int(m.group(2))
     problems = []
     k6 = {k: v for k, v in res.items() if "demod_blk6_kernel" in k}
-    if len(k6) != 8:
-        problems.append(("demod_blk6_kernel", "expected 8 kernel bodies, found %d" % len(k6)))
+    if len(k6) != 16:     # <write-back, streams per workgroup, uniform> (round 6: per-stream tone pairs too)
+        problems.append(("demod_blk6_kernel", "expected 16 kernel bodies, found %d" % len(k6)))
     for k, v in k6.items():
         if v.get("VGPRs", 999) > 256 or v.get("ScratchSize [bytes/lane]", 1) != 0 or v.get("VGPRs Spill", 1) != 0:
             problems.append((k, "resources %s" % v))
