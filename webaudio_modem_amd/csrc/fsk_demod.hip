@@ -615,20 +615,20 @@ __device__ inline bool downsampled_bit(Lane<Real> &L, const DemodParams &P, cons
 // sync.  Returns false, with nothing touched, if the block has to be redone in the per-sample order; otherwise commits:
 // polyphase registers, amplitude ring, counters, at most ONE bit decision (they are dsSPB >= 8 decimated samples apart:
 // the caller checks) at sample jd = bit_wait on entry, a completed byte.
-template <typename Real, typename PolyT, bool TRACE>
-__device__ inline bool block_fsm8(Lane<Real> &L, const DemodParams &P, const DemodState &S, PolyT *poly, RingPos &R, OutCtx &O,
-                                  uint32_t lane, uint32_t row, uint32_t stream, bool valid, const Real (&amp)[8], const Real (&post)[8],
+template <typename Real, typename PolyT, bool TRACE, int NB>
+__device__ inline bool block_fsm(Lane<Real> &L, const DemodParams &P, const DemodState &S, PolyT *poly, RingPos &R, OutCtx &O,
+                                  uint32_t lane, uint32_t row, uint32_t stream, bool valid, const Real (&amp)[NB], const Real (&post)[NB],
                                   uint32_t w) {
   const PolyT qn = (PolyT)~P.pat_q, mask = (PolyT)P.pat_mask;
-  PolyT reg[8];
+  PolyT reg[NB];
   uint32_t ph = R.phase;
   uint32_t matched = L.matched;
   bool rare = false;
   uint32_t last_loud = 0;                                     // 1..8, 0 = none in this block
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
+  for (int j = 0; j < NB; j++) {
     const PolyT rold = poly[ph * 64u + lane];
-    const PolyT r = (PolyT)(rold << 1) | (PolyT)((w >> (7 - j)) & 1u);   // syncSamplesBuffer.put(bit)
+    const PolyT r = (PolyT)(rold << 1) | (PolyT)((w >> (NB - 1 - j)) & 1u);   // syncSamplesBuffer.put(bit)
     reg[j] = r;
     matched += popc((PolyT)((r ^ qn) & mask));
     matched -= popc((PolyT)((rold ^ qn) & mask));
@@ -637,16 +637,16 @@ __device__ inline bool block_fsm8(Lane<Real> &L, const DemodParams &P, const Dem
     ph = (ph + 1 == P.d) ? 0u : ph + 1;
   }
   // 'eod' (fsk.ts:288): no run inside the block is longer than the one a wholly silent block would end with
-  rare |= L.sil_cnt + 8u >= P.eod_min;
+  rare |= L.sil_cnt + (uint32_t)NB >= P.eod_min;
   // ---- bit clock (fsk.ts:331-341): the decision, if one falls into this block, at sample jd
   const int32_t wait0 = (int32_t)L.bit_wait;
   const bool started = L.started != 0;
-  const bool md = started & (wait0 <= 8);
-  rare |= !started & (wait0 <= 8);                            // the clock ran down without a frame (parked again by the per-sample path)
+  const bool md = started & (wait0 <= NB);
+  rare |= !started & (wait0 <= NB);                            // the clock ran down without a frame (parked again by the per-sample path)
   rare |= started & (wait0 < 1);                              // right after a sync (decided with the first sample; at dsSPB 8 a second decision would follow)
   const uint32_t jd = wait0 < 1 ? 1u : (uint32_t)wait0;
-  const uint32_t hi = w >> ((8u - jd) & 31u);                 // bits of samples 1 .. jd
-  const uint32_t ones = L.bit_acc + popc(hi & 0xFFu);
+  const uint32_t hi = w >> (((uint32_t)NB - jd) & 31u);                 // bits of samples 1 .. jd
+  const uint32_t ones = L.bit_acc + popc(hi & ((1u << NB) - 1u));
   const uint32_t cnt = L.bit_reload - (uint32_t)(wait0 - (int32_t)jd);   // bitAccumCount at the decision
   const uint32_t b = (2u * ones > cnt) ? 1u : 0u;             // fsk.ts:336
   const uint32_t pos = L.bit_pos;
@@ -655,9 +655,9 @@ __device__ inline bool block_fsm8(Lane<Real> &L, const DemodParams &P, const Dem
   if (__ballot(rare)) return false;
   // ---- commit
   ph = R.phase;
-  uint32_t apos[8];
+  uint32_t apos[NB];
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
+  for (int j = 0; j < NB; j++) {
     poly[ph * 64u + lane] = reg[j];
     ph = (ph + 1 == P.d) ? 0u : ph + 1;
     apos[j] = R.amp_pos;
@@ -668,7 +668,7 @@ __device__ inline bool block_fsm8(Lane<Real> &L, const DemodParams &P, const Dem
         if (kk < S.trace_cap) {
           S.trace_amp[kk] = (double)amp[j];
           S.trace_post[kk] = (double)post[j];
-          S.trace_bit[kk] = (uint8_t)((w >> (7 - j)) & 1u);
+          S.trace_bit[kk] = (uint8_t)((w >> (NB - 1 - j)) & 1u);
         }
         *S.trace_n = kk + 1;
       }
@@ -676,19 +676,19 @@ __device__ inline bool block_fsm8(Lane<Real> &L, const DemodParams &P, const Dem
   }
   if (valid) {                                                // syncAmplitudeBuffer.put x 8
 #pragma unroll
-    for (int j = 0; j < 8; j++) S.amp_ring[amp_index(apos[j], row, P.n_streams)] = (float)amp[j];
+    for (int j = 0; j < NB; j++) S.amp_ring[amp_index(apos[j], row, P.n_streams)] = (float)amp[j];
   }
   R.phase = ph;
-  R.k += 8;
+  R.k += NB;
   L.matched = matched;
-  L.gsc += 8;
-  L.cad_ctr = (L.cad_ctr + 8u) % P.cadence;
-  L.sil_cnt = last_loud ? 8u - last_loud : L.sil_cnt + 8u;
-  const uint32_t tot = popc(w & 0xFFu), nhi = popc(hi & 0xFFu);
+  L.gsc += NB;
+  L.cad_ctr = (L.cad_ctr + (uint32_t)NB) % P.cadence;
+  L.sil_cnt = last_loud ? (uint32_t)NB - last_loud : L.sil_cnt + (uint32_t)NB;
+  const uint32_t tot = popc(w & ((1u << NB) - 1u)), nhi = popc(hi & ((1u << NB) - 1u));
   const bool emit = md & is_stop;                             // (b == 1: a bad stop bit left through the exit above)
   L.bit_acc = md ? tot - nhi : L.bit_acc + tot;
   L.bit_reload = md ? (uint32_t)(wait0 - (int32_t)jd) + P.d : L.bit_reload;
-  L.bit_wait = md ? (uint32_t)(wait0 - 8) + P.d : (uint32_t)(wait0 - 8);
+  L.bit_wait = md ? (uint32_t)(wait0 - NB) + P.d : (uint32_t)(wait0 - NB);
   // data bits MSB first (see downsampled_bit)
   L.byte_cur |= md ? (b << ((8u - pos) & 31u)) : 0u;
   L.bit_pos = md ? (is_stop ? 0u : pos + 1u) : pos;
@@ -715,6 +715,9 @@ __device__ inline bool block_fsm8(Lane<Real> &L, const DemodParams &P, const Dem
 // precision instruction occupies the pipe for 4 cycles while a lone wave issues one instruction per ~5.7 -- two instruction
 // streams per SIMD instead of one.
 static constexpr uint32_t kPreTiles = 3;
+#ifndef FSK_SPLIT2_BLOCK
+#define FSK_SPLIT2_BLOCK 8      // decimated samples per block of the two-wave kernel's back wave (4 was tried: 736 instead of 864 bytes of spills per lane, and slower still -- 144 against 156 Gsamples/s)
+#endif
 template <typename Real, typename PolyT, bool FRAC, bool UNI, bool TRACE, bool SPLIT2 = false>
 __global__ __launch_bounds__(SPLIT2 ? 128 : 64, (sizeof(Real) == 4 ? FSK_F32_WAVES_PER_SIMD : SPLIT2 ? 2 : 1)) void demod_kernel(DemodParams P, DemodState S, float *__restrict__ samples,
                                                    size_t n, size_t pitch, int vec_ok, int writeback, int append,
@@ -934,13 +937,15 @@ __global__ __launch_bounds__(SPLIT2 ? 128 : 64, (sizeof(Real) == 4 ? FSK_F32_WAV
   // itself restates fsk.ts:278-375 for a lane without such an event: at most ONE bit decision falls into a block (they
   // are dsSPB >= 8 decimated samples apart -- the caller checks), at sample jd = bit_wait on entry.
   // Returns false if the block has to be redone.
-  auto block16 = [&](const float (&x)[16], float (&wbv)[16]) -> bool {
+  // (round 6: NBD decimated samples per block -- eight, or four in the two-wave kernel, whose back wave has 256 registers)
+  constexpr int NBD = SPLIT2 ? FSK_SPLIT2_BLOCK : 8;
+  auto block16 = [&](const float (&x)[2 * NBD], float (&wbv)[2 * NBD]) -> bool {
     const Lane<Real> L0 = L;                                   // everything this block may touch (poly / amplitude ring / output: written at the end)
-    Real amp[8], post[8];
-    float pre16[16];                                            // (traced engines: recorded once the block stands)
-    uint32_t w = 0;                                             // slicer bits, sample 1 in bit 7
+    Real amp[NBD], post[NBD];
+    float pre16[2 * NBD];                                       // (traced engines: recorded once the block stands)
+    uint32_t w = 0;                                             // slicer bits, sample 1 in bit NBD - 1
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < NBD; j++) {
       Real fi0, fq0, fi1, fq1;
       const float y0 = pre_in(x[2 * j], wbv[2 * j]);
       mix_lp<true>(L, C, y0, fi0, fq0);
@@ -950,11 +955,11 @@ __global__ __launch_bounds__(SPLIT2 ? 128 : 64, (sizeof(Real) == 4 ? FSK_F32_WAV
       const bool bit = discriminate(L, C, fi0 + fi1, fq0 + fq1, amp[j], post[j]);
       w = (w << 1) | (bit ? 1u : 0u);
     }
-    if (!block_fsm8<Real, PolyT, TRACE>(L, P, S, poly, R, O, lane, row, stream, valid, amp, post, w)) { L = L0; return false; }
+    if (!block_fsm<Real, PolyT, TRACE, NBD>(L, P, S, poly, R, O, lane, row, stream, valid, amp, post, w)) { L = L0; return false; }
     if (TRACE) {
       if (stream == S.trace_stream) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) trace_pre_put(S, (double)pre16[k]);
+        for (int k = 0; k < 2 * NBD; k++) trace_pre_put(S, (double)pre16[k]);
       }
     }
     return true;
@@ -1057,18 +1062,19 @@ __global__ __launch_bounds__(SPLIT2 ? 128 : 64, (sizeof(Real) == 4 ? FSK_F32_WAV
       // point inside the tile: at the start of a block where it can be, else that block goes chunk by chunk / sample by sample)
       const uint32_t s0 = 4u * c;
       if (sizeof(Real) == 8 && nco_r0 != 0u && nco_r0 == s0) nco_refresh(L, C);
-      const bool r_in16 = sizeof(Real) == 8 && nco_r0 > s0 && nco_r0 < s0 + 16u;
+      constexpr uint32_t BS = 2u * (uint32_t)NBD, CB = BS / 4u;   // samples / four-sample chunks per block
+      const bool r_in16 = sizeof(Real) == 8 && nco_r0 > s0 && nco_r0 < s0 + BS;
       const bool r_in4 = sizeof(Real) == 8 && nco_r0 > s0 && nco_r0 < s0 + 4u;
-      if (sizeof(Real) == 8 && !FRAC && fast16 && (c & 3u) == 0u && 4u * c + 16u <= tile_len && !r_in16) {
-        float x16[16], wb16[16];
+      if (sizeof(Real) == 8 && !FRAC && fast16 && (c & (CB - 1u)) == 0u && 4u * c + BS <= tile_len && !r_in16) {
+        float x16[BS], wb16[BS];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < (int)CB; q++) {
           const float4 u4 = tin[(c + q) * tstride + lane];
           x16[4 * q] = u4.x; x16[4 * q + 1] = u4.y; x16[4 * q + 2] = u4.z; x16[4 * q + 3] = u4.w;
         }
-        if (!block16(x16, wb16)) {                               // something rare in these sixteen samples: the per-sample order
+        if (!block16(x16, wb16)) {                               // something rare in these samples: the per-sample order
 #pragma unroll 1
-          for (int q = 0; q < 4; q++) {
+          for (int q = 0; q < (int)CB; q++) {
             float xq[4] = {x16[4 * q], x16[4 * q + 1], x16[4 * q + 2], x16[4 * q + 3]}, wq[4];
             block4(xq, wq);
             wb16[4 * q] = wq[0]; wb16[4 * q + 1] = wq[1]; wb16[4 * q + 2] = wq[2]; wb16[4 * q + 3] = wq[3];
@@ -1077,9 +1083,9 @@ __global__ __launch_bounds__(SPLIT2 ? 128 : 64, (sizeof(Real) == 4 ? FSK_F32_WAV
         if (writeback && valid && !SPLIT2) {
           float *dst = samples + (size_t)row * pitch + t0 + 4u * c;
 #pragma unroll
-          for (int k = 0; k < 16; k++) dst[k] = wb16[k];
+          for (int k = 0; k < (int)BS; k++) dst[k] = wb16[k];
         }
-        c += 3;
+        c += CB - 1u;
         continue;
       }
       if (fast && lim == 4u && !r_in4) {
