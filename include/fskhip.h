@@ -26,7 +26,7 @@ extern "C" {
  * environment variable any more), fskhip_clock_probe_begin / _end, fskhip_debug_state.  5: fskhip_blk_lanes, option
  * "blk_lanes" (additions only).  6: kernel = seven-wave / auto-r04, options "stage_min_tiles" / "stage_y_slots" / "stage_roles"; the batched
  * IIRFilter of fskhip_next.h (additions only).  7: fskhip_get_faults (additions only). */
-#define FSKHIP_ABI_VERSION 7
+#define FSKHIP_ABI_VERSION 8
 #define FSKHIP_MAX_PATTERN_BYTES 16
 
 enum {
@@ -37,7 +37,9 @@ enum {
   FSKHIP_E_NO_DEVICE = -4,      /* no HIP device / HIP runtime failure at create */
   FSKHIP_E_HIP = -5,            /* HIP runtime error during a call */
   FSKHIP_E_NOMEM = -6,
-  FSKHIP_E_OVERFLOW = -7        /* an output slab was too small; counts still report the true size */
+  FSKHIP_E_OVERFLOW = -7,       /* an output slab was too small; counts still report the true size */
+  FSKHIP_E_HANDOFF = -8         /* ABI 8: a wave of a multi-wave kernel waited for its neighbour beyond the bound and ended the launch
+                                   early ("Hand-off waits" below); sticky, the engine is to be destroyed */
 };
 
 /* arithmetic the demodulator chain computes in */
@@ -337,15 +339,21 @@ int fskhip_clock_probe_begin(fskhip_engine *e, double spin_ms);
 int fskhip_clock_probe_end(fskhip_engine *e, double *shader_ghz, double *covered_ms);
 
 /*
- * Hand-off waits (a property of the multi-wave kernels, not an entry point).  The four- and seven-wave demodulator kernels pass
- * tiles from wave to wave through LDS rings guarded by counters; a wave that finds its input not there yet polls the counter
- * with s_sleep in between, WITHOUT a bound: the producer is a wave of the same workgroup and is always running (every part is
- * played exactly once: the waves settle their parts among themselves at the start), so the wait ends -- but a lost counter
- * update would be a hung kernel, not an error code.  Hosts that need a bound put one on the stream (hipStreamQuery / an
- * event with a timeout) as they would for any kernel; tools/six_check.py and the soak run every case in a child process under
- * a timeout for that reason.  Round 6: the seven-wave kernel checks once per launch, in every wave, that its part map is a
- * permutation (a bad one ends the launch at once, bit 30 of the engine's second statistics word set), and a debug build
- * (-DFSK_SPIN_CAP=<polls>) bounds every one of its polls: a wave that runs into the cap sets bit 31 of that word and ends.
+ * Hand-off waits (a property of the multi-wave kernels, not an entry point).  The two-, four- and seven-wave demodulator kernels,
+ * the exact path's two-wave cut and the wide modulator pass tiles from wave to wave through LDS rings guarded by counters; a wave
+ * that finds its input not there yet polls the counter with s_sleep in between.  The producer is a wave of the same workgroup
+ * and is always running (every part is played exactly once: the waves settle their parts among themselves at the start, the
+ * seven-wave kernel checks its part map in every wave), so a wait ends within a few tiles' work.  ABI 8: the waits are BOUNDED
+ * all the same (csrc/fsk_wait.h) -- a wave that has polled 2^22 times in ONE wait without getting on (>= 0.15 s of shader clock,
+ * four orders of magnitude beyond the longest wait of a healthy launch; polls are counted, not timed, so a preempted queue does
+ * not trip it) sets the engine's hand-off fault word and ends, the waves waiting on it run into their own bound, workgroups of a
+ * persistent launch that wait on a time slice of such a group give up as soon as they see the word, and the launch FINISHES.  The
+ * host reports FSKHIP_E_HANDOFF from fskhip_synchronize, fskhip_get_faults, the _host calls (all of which wait for the device
+ * anyway) and from every later fskhip_demodulate_device (from the statistics copy that trails the launches: no extra wait); it
+ * is sticky -- the streams of that workgroup stopped mid-call -- and the engine is to be destroyed.  A lost counter update is
+ * thus an error code, not a hung GPU; tools/handoff_check.py shows it on a build whose bound is 0 polls
+ * (profiles/r06_handoff_bound.txt), tests/test_gpu_parity.py that healthy launches of every such kernel leave the word clear.
+ * The bound sits on the waits' slow paths only: measured cost nil (same file).
  */
 const char *fskhip_last_error(void);
 int fskhip_abi_version(void);

@@ -14,7 +14,7 @@ async function rejects(p, re) {
 }
 
 async function cpuTests() {
-  assert.strictEqual(M.addon.abiVersion, 7);
+  assert.strictEqual(M.addon.abiVersion, 8);
   const core = new M.FSKCore();
   assert.strictEqual(core.name, 'FSK');
   assert.strictEqual(core.isReady(), false);

@@ -45,7 +45,7 @@ def test_header_symbols_all_exported(lib):
 
 def test_abi_version_and_default_config(lib):
     L = lib.lib()
-    assert L.fskhip_abi_version() == 7
+    assert L.fskhip_abi_version() == 8
     c = lib.Config()
     L.fskhip_default_config(C.byref(c))
     # DEFAULT_FSK_CONFIG fsk.ts:19-33

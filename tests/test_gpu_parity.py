@@ -849,3 +849,45 @@ def test_exact_path_on_two_waves_is_the_one_wave_kernel_bit_for_bit():
     assert np.array_equal(res[0][3], res[1][3])
     for (ra, ia), (rb, ib) in zip(res[0][2], res[1][2]):
         assert np.array_equal(np.asarray(ra).view(np.uint64), np.asarray(rb).view(np.uint64)) and ia == ib
+
+
+@pytest.mark.gpu
+def test_hand_off_fault_word_stays_clear_on_every_multi_wave_kernel():
+    """ABI 8: every hand-off wait of the two-, four- and seven-wave kernels, of the exact path's two-wave cut and of the wide
+    modulator is bounded (csrc/fsk_wait.h): a wave that gets nowhere in 2^22 polls of one wait flags the engine's fault word and ends
+    its launch, and fskhip_synchronize / fskhip_get_faults / the next call report FSKHIP_E_HANDOFF.  A healthy launch never comes near
+    the bound: here every such kernel runs a batch with resets in it, and synchronize() (which raises on the fault word) and
+    faults() stay clean.  (The bound itself is exercised by tools/handoff_check.py on a -DFSK_SPIN_CAP_LOG2=0 build: profiles/.)"""
+    import webaudio_modem_amd as wm
+    from webaudio_modem_amd import _lib
+    assert _lib.E_HANDOFF == -8
+    g = golden()
+    base = g.array("d_noise_bell_10dB_0.in")
+    bell = dict(baudRate=1200, markFrequency=1200, spaceFrequency=2200)
+    S = 200
+    x = np.zeros((S, 2 * base.size + 4000), np.float32)
+    for s in range(S):
+        for k in range(2):
+            o = 37 * (s % 50) + k * (base.size + 900)
+            x[s, o:o + base.size] = base[:x.shape[1] - o] * (0.3 + 0.002 * s)
+    ref = None
+    for prec, opts, expect in ((wm.PRECISION_F32, {"kernel": "four-wave", "blk_resets": 0}, "demod_blk_kernel<"),
+                               (wm.PRECISION_F32, {"kernel": "four-wave", "blk_resets": 1}, "demod_blk_kernel_r<"),
+                               (wm.PRECISION_F32, {"kernel": "seven-wave"}, "demod_blk6_kernel"),
+                               (wm.PRECISION_F32, {"kernel": "two-wave"}, "demod_pipe_kernel"),
+                               (wm.PRECISION_F64, {"exact_waves": 2}, "two waves")):
+        eng = wm.FSKEngine(S, bell, precision=prec, options=opts)
+        rows, _ = eng.demodulate_data(x.copy())
+        assert expect in eng.last_kernel(), (opts, eng.last_kernel())
+        eng.synchronize()
+        assert int(eng.faults().sum()) == 0
+        if ref is None:
+            ref = rows
+            assert sum(len(r) for r in rows) > 10 * S
+        assert rows == ref, opts
+        eng.close()
+    eng = wm.FSKEngine(S, bell, precision=wm.PRECISION_F64)
+    sig = eng.modulate_data([b"hand-off %03d" % s for s in range(S)])
+    eng.synchronize()
+    assert len(sig) == S and all(len(v) > 0 for v in sig)
+    eng.close()

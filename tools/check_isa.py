@@ -10,12 +10,13 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXTRA = os.environ.get("FSK_CHECK_ISA_FLAGS", "").split()   # a measurement build's extra hipcc flags (tools/build_variant.sh)
 
 
 def kernel_resources():
     src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_pipe.hip")
     with tempfile.TemporaryDirectory() as tmp:
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", *EXTRA,
                "-c", src, "-o", os.path.join(tmp, "d.o"), "-Rpass-analysis=kernel-resource-usage"]
         out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
     res, cur = {}, None
@@ -39,7 +40,7 @@ def prefetch_register_hazards():
     src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_pipe.hip")
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "d.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", *EXTRA,
                         "-S", "--cuda-device-only", "-o", asm, src], capture_output=True, text=True, check=True)
         text = open(asm).read()
 
@@ -111,7 +112,7 @@ def pipe_prefetch_hazards(symbol=r"_ZN3fsk17demod_pipe_kernel"):
     src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_pipe.hip")
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "d.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", *EXTRA,
                         "-S", "--cuda-device-only", "-o", asm, src], capture_output=True, text=True, check=True)
         text = open(asm).read()
 
@@ -172,7 +173,7 @@ def blk_checks():
     src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_blk.hip")
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "d.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", *EXTRA,
                         "-S", "--cuda-device-only", "-o", asm, src], capture_output=True, text=True, check=True)
         text = open(asm).read()
 
@@ -270,7 +271,7 @@ def blk6_resources():
     where the four-wave kernel parks it in memory)."""
     src = os.path.join(ROOT, "webaudio_modem_amd", "csrc", "fsk_blk6.hip")
     with tempfile.TemporaryDirectory() as tmp:
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", *EXTRA,
                "-c", src, "-o", os.path.join(tmp, "d.o"), "-Rpass-analysis=kernel-resource-usage"]
         out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
     res, cur = {}, None

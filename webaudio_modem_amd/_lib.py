@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libfskhip.so")   # (measurement tools load other
 
 MAX_PATTERN_BYTES = 16
 OK = 0
-E_INVALID, E_NOT_CONFIGURED, E_UNSUPPORTED, E_NO_DEVICE, E_HIP, E_NOMEM, E_OVERFLOW = -1, -2, -3, -4, -5, -6, -7
+E_INVALID, E_NOT_CONFIGURED, E_UNSUPPORTED, E_NO_DEVICE, E_HIP, E_NOMEM, E_OVERFLOW, E_HANDOFF = -1, -2, -3, -4, -5, -6, -7, -8
 E_BUSY = -8
 PROC_CLEAR_RX_ON_TX_COMPLETE, PROC_GRAPH = 1, 2
 XM_NEED_MORE, XM_EOT, XM_TRUNCATED, XM_INVALID_SEQUENCE, XM_INVALID_CRC, XM_UNEXPECTED_SEQUENCE = 0, 1, 2, 3, 4, 5

@@ -241,7 +241,8 @@ struct fskhip_engine {
   // asynchronous 8-byte copy behind every launch and are looked at, without waiting, before the next one).
   uint32_t blk_medium = 3;       // 0 never, 1 always, 2 (tests) always + redo every such block sample by sample, 3 auto
   bool blk_med_now = false;      // auto's current choice
-  volatile unsigned long long *h_stat = nullptr;   // pinned: {tiles, tiles off the fast loop} as the last completed copy left them
+  volatile unsigned long long *h_stat = nullptr;   // pinned: {tiles, tiles off the fast loop}, {hand-off fault word, -} as the last completed copy left them
+  uint32_t handoff_fault = 0;                       // sticky: a kernel's hand-off wait ran into its bound (csrc/fsk_wait.h)
   uint32_t stat_tiles = 0, stat_rare = 0;          // ... as of the last look
   uint32_t stat_skip = 0;                          // short calls since the last fetch
   // seven waves per group (demod_blk6_kernel, fsk_blk6.hip): the whole-tile kernel of batches small enough to give every workgroup a
@@ -686,15 +687,17 @@ int fskhip_create(const fskhip_config *cfgs, uint32_t n_cfgs, uint32_t n_streams
   if (e->demod_ok && precision == FSKHIP_PRECISION_F64 && !P.wide && !P.frac && demod_split2_lds_bytes(P) > 48 * 1024 && demod_split2_lds_bytes(P) <= 160 * 1024)
     CREATE_TRY(set_demod_split2_lds_limit(demod_split2_lds_bytes(P)));
   if (hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) e->cus = 0;
+  // {tiles, tiles off the fast loop, hand-off fault word, -}: the third word is every multi-wave kernel's (csrc/fsk_wait.h)
+  CREATE_TRY(hipMalloc((void **)&e->S.blk_stat, 4 * sizeof(uint32_t)));
+  CREATE_TRY(hipMemset(e->S.blk_stat, 0, 4 * sizeof(uint32_t)));
+  e->M.stat = e->S.blk_stat;
   if (e->demod_ok && !P.wide && !P.frac && precision == FSKHIP_PRECISION_F32 && demod_pipe_lds_bytes(P) <= 160 * 1024)
     CREATE_TRY(set_pipe_lds_limit(demod_pipe_lds_bytes(P)));
   if (e->demod_ok && precision == FSKHIP_PRECISION_F32 && demod_blk_applicable(P)) {
     CREATE_TRY(set_blk_lds_limit(P));
     CREATE_TRY(hipMalloc((void **)&e->S.blk_stash, sizeof(float) * 28u * (size_t)n_streams));
-    CREATE_TRY(hipMalloc((void **)&e->S.blk_stat, 2 * sizeof(uint32_t)));
-    CREATE_TRY(hipMemset(e->S.blk_stat, 0, 2 * sizeof(uint32_t)));
-    CREATE_TRY(hipHostMalloc((void **)&e->h_stat, sizeof(unsigned long long), hipHostMallocDefault));
-    *e->h_stat = 0ull;
+    CREATE_TRY(hipHostMalloc((void **)&e->h_stat, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    e->h_stat[0] = 0ull; e->h_stat[1] = 0ull;
     e->blk_lanes = demod_blk_lanes(n_streams, device);
     demod_blk_plan(P, (n_streams + e->blk_lanes - 1u) / e->blk_lanes, device, &e->blk_y_slots, &e->blk_resident);
     demod_blk_plan(P, (n_streams + e->blk_lanes - 1u) / e->blk_lanes, device, &e->blk5_y_slots, &e->blk5_resident, 5u);
@@ -872,6 +875,25 @@ uint32_t fskhip_blk_lanes(const fskhip_engine *e) {
 
 // append_first: this launch sequence continues a call that has produced output already (a time slab of
 // fskhip_demodulate_host's pipeline); count_call: it is (the first part of) a demodulateData() call of its own
+// The hand-off fault word (csrc/fsk_wait.h): a wave of a multi-wave kernel got nowhere in FSK_SPIN_CAP polls of one wait and ended
+// its launch early.  Sticky: the streams of that workgroup are mid-call, the engine is to be destroyed.  `blocking`: read the word
+// from the device (the caller has synchronised); otherwise whatever the last completed statistics copy brought (costs nothing).
+static int handoff_check(fskhip_engine *e, bool blocking) {
+  if (e->handoff_fault == 0u) {
+    uint32_t w = 0;
+    if (blocking) {
+      if (e->S.blk_stat && hipMemcpy(&w, e->S.blk_stat + 2, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) w = 0;
+    } else if (e->h_stat) {
+      w = (uint32_t)e->h_stat[1];
+    }
+    e->handoff_fault = w;
+  }
+  if (e->handoff_fault != 0u)
+    return fail(FSKHIP_E_HANDOFF, "a hand-off wait of a multi-wave kernel ran into its bound (fault word %u, last kernel %s): destroy the engine",
+                e->handoff_fault, e->last_kernel);
+  return FSKHIP_OK;
+}
+
 static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_t pitch, uint8_t *d_out,
                              size_t out_pitch, uint32_t *d_out_counts, uint32_t *d_eod_counts, uint32_t flags,
                              void *hip_stream, bool append_first, bool count_call) {
@@ -880,6 +902,7 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
     return fail(FSKHIP_E_INVALID, "fskhip_demodulate_device: null buffer");
   if (pitch < n) return fail(FSKHIP_E_INVALID, "pitch %zu < n_per_stream %zu", pitch, n);
   if (!e->demod_ok) return fail(FSKHIP_E_UNSUPPORTED, "demodulator unsupported for this configuration: %s", e->demod_why.c_str());
+  if (const int hrc = handoff_check(e, false)) return hrc;
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)hip_stream;
   const bool timed = e->timing;
@@ -962,7 +985,7 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
                 hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
                 fetch = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
               }
-              if (fetch) HIP_TRY(hipMemcpyAsync((void *)e->h_stat, e->S.blk_stat, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+              if (fetch) HIP_TRY(hipMemcpyAsync((void *)e->h_stat, e->S.blk_stat, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             }
             static const char *const names6[16] = {
                 "fsk::demod_blk6_kernel<false, 64>", "fsk::demod_blk6_kernel<false, 32>", "fsk::demod_blk6_kernel<false, 16>", "fsk::demod_blk6_kernel<false, 8>",
@@ -985,7 +1008,7 @@ static int demod_device_impl(fskhip_engine *e, float *d_samples, size_t n, size_
               hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
               fetch = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
             }
-            if (fetch) HIP_TRY(hipMemcpyAsync((void *)e->h_stat, e->S.blk_stat, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            if (fetch) HIP_TRY(hipMemcpyAsync((void *)e->h_stat, e->S.blk_stat, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
           }
           static const char *const names[12] = {
               "fsk::demod_blk_kernel<false, false, false>", "fsk::demod_blk_kernel<false, false, true>",
@@ -1139,6 +1162,7 @@ int fskhip_demodulate_host(fskhip_engine *e, float *samples, size_t n, size_t pi
   if (eod_counts) HIP_TRY(hipMemcpyAsync(eod_counts, e->d_eod, sizeof(uint32_t) * S, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (e->copy_stream) HIP_TRY(hipStreamSynchronize(e->copy_stream));
+  if (const int hrc = handoff_check(e, true)) return hrc;
   for (size_t s = 0; s < S; s++)
     if (out_counts[s] > out_pitch) return fail(FSKHIP_E_OVERFLOW, "stream %zu produced %u bytes, slab holds %zu", s, out_counts[s], out_pitch);
   return FSKHIP_OK;
@@ -1212,6 +1236,7 @@ int fskhip_modulate_host(fskhip_engine *e, const uint8_t *payloads, const uint32
   HIP_TRY(hipMemcpy2DAsync(out, out_pitch * sizeof(float), e->d_samples, dpitch * sizeof(float),
                            out_pitch * sizeof(float), S, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  if (const int hrc = handoff_check(e, true)) return hrc;
   for (size_t s = 0; s < S; s++)
     if (out_lens[s] > out_pitch) return fail(FSKHIP_E_OVERFLOW, "stream %zu needs %u samples, slab holds %zu", s, out_lens[s], out_pitch);
   return FSKHIP_OK;
@@ -1275,6 +1300,7 @@ int fskhip_get_faults(fskhip_engine *e, uint8_t *out, uint32_t *n_faulty) {
   if (!e) return fail(FSKHIP_E_NOT_CONFIGURED, "not configured");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
+  if (const int hrc = handoff_check(e, true)) return hrc;
   uint8_t *d_out = nullptr;
   uint32_t *d_n = nullptr;
   HIP_TRY(hipMalloc((void **)&d_out, e->n_streams));
@@ -1411,7 +1437,7 @@ int fskhip_synchronize(fskhip_engine *e) {
   if (!e) return fail(FSKHIP_E_INVALID, "null engine");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
-  return FSKHIP_OK;
+  return handoff_check(e, true);
 }
 
 int fskhip_demod_supported(const fskhip_engine *e) { return e && e->demod_ok ? 1 : 0; }

@@ -309,6 +309,7 @@ __device__ __forceinline__ void demod_blk_body(
     uint32_t *__restrict__ eod_counts, const BlkSched &Z) {
   FSK_ABL_INIT
   FSK_STAMP_DECL
+  FSK_WAIT_DECL
 #ifdef FSK_SCRATCH_PAD       // (measurement builds: private memory nobody touches -- does a larger scratch frame cost resident waves?)
   volatile uint32_t scratch_pad[FSK_SCRATCH_PAD / 4];
   if (n_call == 0xDEADBEEFull) { for (int i = 0; i < FSK_SCRATCH_PAD / 4; i++) scratch_pad[i] = (uint32_t)i; out_counts[0] = scratch_pad[threadIdx.x & 15]; }
@@ -407,8 +408,19 @@ __device__ __forceinline__ void demod_blk_body(
       if (i < Z.groups) e = i;
       else if (i < Z.total) {
         const uint32_t *slot = &Z.q[16u + (i - Z.groups)];
-        while ((e = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(8);
-        e &= 0x7FFFFFFFu;
+        // (bounded like the hand-off waits, fsk_pipe_dev.h: the slice before this one belongs to a workgroup that took its item
+        // earlier and is running; if any workgroup of the launch has given up -- the fault word -- so does this one)
+        uint32_t polls = 0;
+        while ((e = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+          __builtin_amdgcn_s_sleep(8);
+          const bool dead = S.blk_stat && __hip_atomic_load(&S.blk_stat[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+          if (dead || ++polls > (uint32_t)(FSK_SPIN_CAP)) {
+            if (S.blk_stat) __hip_atomic_fetch_or(&S.blk_stat[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            e = 0xFFFFFFFFu;
+            break;
+          }
+        }
+        if (e != 0xFFFFFFFFu) e &= 0x7FFFFFFFu;
       }
       ctr[5] = e;
     }
@@ -503,10 +515,10 @@ __device__ __forceinline__ void demod_blk_body(
       if (WB) asm volatile("s_waitcnt vmcnt(16)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
       else asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
       if (t >= released + 2u) {                             // both staging tiles in use: part 0 has not released tile t - 2
-        FSK_STAMP_W0
+        FSK_STAMP_W0 FSK_WAIT_BEGIN
         while (t >= released + 2u) {
           released = lds_peek(&ctr[7]);
-          if (t >= released + 2u) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_A);
+          if (t >= released + 2u) FSK_SPIN(FSK_BLK_SLEEP_A, S.blk_stat);
         }
         FSK_STAMP_W1
       }
@@ -571,14 +583,14 @@ __device__ __forceinline__ void demod_blk_body(
       lds_peek4_begin(ctr, cv);                             // (read now, looked at after the tile: see lds_peek4_begin)
       lds_peek4_begin(ctr + 4, cw);
       if (staged <= t || hidx + 1u - consumed >= NY) {
-        FSK_STAMP_W0
+        FSK_STAMP_W0 FSK_WAIT_BEGIN
         while (staged <= t) {                               // part 4's tile
           staged = lds_peek(&ctr[6]);
-          if (staged <= t) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_A);
+          if (staged <= t) FSK_SPIN(FSK_BLK_SLEEP_A, S.blk_stat);
         }
         while (hidx + 1u - consumed >= NY) {                // ring full: the back wave (which may still need the slots'
           consumed = lds_peek(&ctr[3]);                     // pre-filter outputs after a reset) has not released them
-          if (hidx + 1u - consumed >= NY) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_A);
+          if (hidx + 1u - consumed >= NY) FSK_SPIN(FSK_BLK_SLEEP_A, S.blk_stat);
         }
         FSK_STAMP_W1
       }
@@ -666,10 +678,10 @@ __device__ __forceinline__ void demod_blk_body(
       v4u32 cv;
       lds_peek4_begin(ctr, cv);                             // (read now, looked at after the tile: see lds_peek4_begin)
       if (hidx + 1u - consumed >= NY) {                     // both of the tile's slots must be free
-        FSK_STAMP_W0
+        FSK_STAMP_W0 FSK_WAIT_BEGIN
         while (hidx + 1u - consumed >= NY) {                // ring full: the back wave (which may still need the slots'
           consumed = lds_peek(&ctr[3]);                     // pre-filter outputs after a reset) has not released them
-          if (hidx + 1u - consumed >= NY) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_A);
+          if (hidx + 1u - consumed >= NY) FSK_SPIN(FSK_BLK_SLEEP_A, S.blk_stat);
         }
         FSK_STAMP_W1
       }
@@ -743,14 +755,14 @@ __device__ __forceinline__ void demod_blk_body(
     while (hidx < nh) {
       if ((hidx & 63u) == 0u) blk_prio<(MED && FSK_BLK_R_BYROLE)>(hidx, wgj, 1u);
       if (produced < hidx + 2u || hidx + 2u - consumed > kBlkSlots) {
-        FSK_STAMP_W0
+        FSK_STAMP_W0 FSK_WAIT_BEGIN
         while (produced < hidx + 2u) {                        // wave 0's tile
           produced = lds_peek(&ctr[0]);
-          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_B);
+          if (produced < hidx + 2u) FSK_SPIN(FSK_BLK_SLEEP_B, S.blk_stat);
         }
         while (hidx + 2u - consumed > kBlkSlots) {           // ring full: wait for the back wave
           consumed = lds_peek(&ctr[3]);
-          if (hidx + 2u - consumed > kBlkSlots) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_B);
+          if (hidx + 2u - consumed > kBlkSlots) FSK_SPIN(FSK_BLK_SLEEP_B, S.blk_stat);
         }
         FSK_STAMP_W1
       }
@@ -853,10 +865,10 @@ __device__ __forceinline__ void demod_blk_body(
     while (hidx < nh) {
       if ((hidx & 63u) == 0u) blk_prio<(MED && FSK_BLK_R_BYROLE)>(hidx, wgj, 2u);
       if (produced < hidx + 2u) {
-        FSK_STAMP_W0
+        FSK_STAMP_W0 FSK_WAIT_BEGIN
         while (produced < hidx + 2u) {
           produced = lds_peek(&ctr[1]);
-          if (produced < hidx + 2u) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_C);
+          if (produced < hidx + 2u) FSK_SPIN(FSK_BLK_SLEEP_C, S.blk_stat);
         }
         FSK_STAMP_W1
       }
@@ -999,10 +1011,10 @@ __device__ __forceinline__ void demod_blk_body(
     while (t < nh) {
       blk_prio<(MED && FSK_BLK_R_BYROLE)>(t & ~15u, wgj, 3u);                            // (t advances in steps of two; the outer loop sees every multiple of 16)
       if (produced < t + 2u) {
-        FSK_STAMP_W0
+        FSK_STAMP_W0 FSK_WAIT_BEGIN
         while (produced < t + 2u) {
           produced = lds_peek(&ctr[2]);
-          if (produced < t + 2u) __builtin_amdgcn_s_sleep(FSK_BLK_SLEEP_D);
+          if (produced < t + 2u) FSK_SPIN(FSK_BLK_SLEEP_D, S.blk_stat);
         }
         FSK_STAMP_W1
       }
@@ -1252,11 +1264,12 @@ __device__ __forceinline__ void demod_blk_body(
       __hip_atomic_fetch_add(&S.blk_stat[0], (uint32_t)n_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(&S.blk_stat[1], rare_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    FSK_WAIT_BEGIN
     while (produced <= nh) {
       produced = lds_peek(&ctr[2]);
-      if (produced <= nh) __builtin_amdgcn_s_sleep(1);
+      if (produced <= nh) FSK_SPIN(1, S.blk_stat);
     }
-    while (lds_peek(&ctr[1]) <= nh) __builtin_amdgcn_s_sleep(1);
+    while (lds_peek(&ctr[1]) <= nh) FSK_SPIN(1, S.blk_stat);
     FrontLane F;
     {
       const v4f fi = fin[lane], fq = fin[64u + lane];

@@ -186,22 +186,9 @@ __device__ __forceinline__ float lp_step(LpLane &L, float a2, float nd, float v,
 
 // (front_agc / front_bp -- front_agc_bp as its two halves -- live in fsk_pipe_dev.h since round 6: fsk_blk.hip's five-wave kernel uses them too)
 
-// Every hand-off wait of this kernel is a poll with s_sleep in between (include/fskhip.h, "Hand-off waits").  Debug builds
-// (-DFSK_SPIN_CAP=<polls>, tools/build_variant.sh) bound them: a wave that has polled that often without getting on sets bit 31 of
-// the engine's second statistics word (blk_stat[1]) and ends -- the waves waiting on IT then run into their own cap -- so that a
-// protocol slip shows as a flagged, finished launch instead of a hung GPU.  The shipped library polls unbounded.
-#ifdef FSK_SPIN_CAP
-#define B6_SPIN(arg)                                                                                          \
-  do {                                                                                                        \
-    __builtin_amdgcn_s_sleep(arg);                                                                            \
-    if (++b6_spins > (uint32_t)(FSK_SPIN_CAP)) {                                                              \
-      if (lane == 0 && S.blk_stat) __hip_atomic_fetch_or(&S.blk_stat[1], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-      __builtin_amdgcn_endpgm();                                                                              \
-    }                                                                                                         \
-  } while (0)
-#else
-#define B6_SPIN(arg) __builtin_amdgcn_s_sleep(arg)
-#endif
+// Every hand-off wait of this kernel is a bounded poll (FSK_SPIN, fsk_pipe_dev.h): a wave that gets nowhere in FSK_SPIN_CAP polls
+// of one wait flags the engine's hand-off fault word and ends, the waves waiting on it follow, the host reports FSKHIP_E_INTERNAL.
+#define B6_SPIN(arg) FSK_SPIN(arg, S.blk_stat)
 #ifndef FSK_B6_SLEEP
 #define FSK_B6_SLEEP 1
 #endif
@@ -266,9 +253,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t role = (Z.rolemap >> (3u * wave)) & 7u;
-#ifdef FSK_SPIN_CAP
-  uint32_t b6_spins = 0;
-#endif
+  FSK_WAIT_DECL
   {
     // every part played exactly once (the host validates "stage_roles" and builds the default map; a map that is no permutation of
     // 0..6 would leave some counter without a writer and six waves waiting on it for good): checked here once per launch by every
@@ -276,7 +261,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
     uint32_t seen = 0;
     for (uint32_t w = 0; w < kB6Waves; w++) seen |= 1u << ((Z.rolemap >> (3u * w)) & 7u);
     if (seen != 0x7Fu) {
-      if (threadIdx.x == 0 && S.blk_stat) __hip_atomic_fetch_or(&S.blk_stat[1], 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0 && S.blk_stat) __hip_atomic_fetch_or(&S.blk_stat[2], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
   }
@@ -365,7 +350,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
     auto do_tile = [&](uint32_t t, v4f &r0, v4f &r1, v4f &r2, v4f &r3) {
       asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
       if (2u * t + 2u - used > 2u * kB6Stage) {
-        FSK_STAMP_W0
+        FSK_STAMP_W0 FSK_WAIT_BEGIN
         while (2u * t + 2u - used > 2u * kB6Stage) {
           used = lds_peek(&ctr[C6_Y]);
           if (2u * t + 2u - used > 2u * kB6Stage) B6_SPIN(FSK_B6_SLEEP);
@@ -415,7 +400,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
     for (uint32_t t = 0; t < nt; t++) {
       const uint32_t hidx = 2u * t;
       if (produced < hidx + 2u || (do_bp && hidx + 1u - consumed >= NY)) {
-        FSK_STAMP_W0
+        FSK_STAMP_W0 FSK_WAIT_BEGIN
         while (produced < hidx + 2u) {
           produced = lds_peek(&ctr[c_in]);
           if (produced < hidx + 2u) B6_SPIN(FSK_B6_SLEEP);
@@ -498,7 +483,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
     for (uint32_t t = 0; t < nt; t++) {
       const uint32_t hidx = 2u * t;
       if (produced < hidx + 2u || hidx + 2u - consumed > 2u * kB6XT) {
-        FSK_STAMP_W0
+        FSK_STAMP_W0 FSK_WAIT_BEGIN
         while (produced < hidx + 2u) {
           produced = lds_peek(&ctr[C6_Y]);
           if (produced < hidx + 2u) B6_SPIN(FSK_B6_SLEEP_RING);
@@ -607,7 +592,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
     for (uint32_t t = 0; t < nt; t++) {
       const uint32_t hidx = 2u * t;
       if (produced < hidx + 2u || hidx + 2u - consumed > 2u * kB6DT) {
-        FSK_STAMP_W0
+        FSK_STAMP_W0 FSK_WAIT_BEGIN
         while (produced < hidx + 2u) {
           produced = lds_peek(&ctr[C6_IQ]);
           if (produced < hidx + 2u) B6_SPIN(FSK_B6_SLEEP_RING);
@@ -751,7 +736,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
       // ---- until tile t can be worked, the frame wave rewinds this one, or the launch is over
       bool over = false;
       {
-        FSK_STAMP_W0
+        FSK_STAMP_W0 FSK_WAIT_BEGIN
         for (;;) {
           v4u32 cv;
           lds_peek4_begin(ctr1, cv);
@@ -857,7 +842,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
         }
         uint32_t pw = 0;
         {
-          FSK_STAMP_W0
+          FSK_STAMP_W0 FSK_WAIT_BEGIN
           for (;;) {
             pw = lds_peek(&ctr[C6_P4]);
             if ((pw >> 24) == gen && (pw & 0xFFFFFFu) >= t + 2u) break;
@@ -916,7 +901,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
           // this wave, so that is the usual case: look again (and wait here while it still is not), then go on with entries read
           // afresh.  Leaving the loop instead cost ~500 cycles per tile (the outer loop's polls, two exposed LDS round trips).
           {
-            FSK_STAMP_W0
+            FSK_STAMP_W0 FSK_WAIT_BEGIN
             for (;;) {
               const uint32_t pw2 = lds_peek(&ctr[C6_P4]);
               if ((pw2 >> 24) == gen && (pw2 & 0xFFFFFFu) >= t + 2u) { produced = pw2 & 0xFFFFFFu; break; }
@@ -956,6 +941,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
         // entry state, as fsk_blk.hip's back wave does it -- the post filter and lastPhase being P4's on entering this tile
         if (!own_post) {
           if (t != 0u) {
+            FSK_WAIT_BEGIN
             for (;;) {                                         // (P4 has produced this tile: its entry state is in the history)
               const uint32_t pw = lds_peek(&ctr[C6_P4]);
               if ((pw >> 24) == gen && (pw & 0xFFFFFFu) >= t + 2u) break;
@@ -969,7 +955,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
         }
         {
           uint32_t p3 = 0;
-          FSK_STAMP_W0
+          FSK_STAMP_W0 FSK_WAIT_BEGIN
           while ((p3 = lds_peek(&ctr[C6_X])) < t + 2u) B6_SPIN(FSK_B6_SLEEP_RING);
           FSK_STAMP_W1
         }
@@ -1101,6 +1087,7 @@ __global__ __launch_bounds__(64 * kB6Waves, 1) void demod_blk6_kernel(
       __hip_atomic_fetch_add(&S.blk_stat[1], rare_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // the other waves' final states
+    FSK_WAIT_BEGIN
     while (lds_peek(&ctr[C6_X]) <= nh) B6_SPIN(1);
     while (lds_peek(&ctr[C6_IQ]) <= nh) B6_SPIN(1);
     if (!own_post) {

@@ -47,6 +47,7 @@
 #include "fsk_params.h"
 #include "fsk_dev.h"
 #include "fsk_f64math.h"
+#include "fsk_wait.h"
 
 #ifndef FSK_FAST_WAVES
 #define FSK_FAST_WAVES 4
@@ -970,6 +971,7 @@ __global__ __launch_bounds__(SPLIT2 ? 128 : 64, (sizeof(Real) == 4 ? FSK_F32_WAV
   // the sixteen-sample block: fp64 only (registers: one wave per SIMD), at most one bit decision per eight decimated samples, none
   // of the opt-in estimates (they hook the per-sample state machine)
   const bool fast16 = fast && sizeof(Real) == 8 && P.d >= 8 && P.cadence > 0 && !P.quality;
+  FSK_WAIT_DECL
   auto ctr_peek = [&](const uint32_t *q) -> uint32_t {
     uint32_t v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)q) : "memory");
@@ -992,9 +994,10 @@ __global__ __launch_bounds__(SPLIT2 ? 128 : 64, (sizeof(Real) == 4 ? FSK_F32_WAV
       }
       cf = (t0 + kTile < n) && tile_is_fast(t0 + kTile);
       if (cf) load_tile_fast(t0 + kTile);
+      FSK_WAIT_BEGIN
       while (ti - consumed >= kPreTiles) {                    // ring full: wave 1 has not released the slot
         consumed = ctr_peek(&pctr[1]);
-        if (ti - consumed >= kPreTiles) __builtin_amdgcn_s_sleep(1);
+        if (ti - consumed >= kPreTiles) FSK_SPIN(1, S.blk_stat);
       }
       float4 *dstt = pring + (ti % kPreTiles) * kChunks * 64u;
       const uint32_t tile_len = (uint32_t)((n - t0) < (size_t)kTile ? (n - t0) : (size_t)kTile);
@@ -1032,9 +1035,10 @@ __global__ __launch_bounds__(SPLIT2 ? 128 : 64, (sizeof(Real) == 4 ? FSK_F32_WAV
     const float4 *tin = stage;                              // this tile's input: [chunk][tstride] float4, lane = stream
     uint32_t tstride = kSlotStride;
     if (SPLIT2) {
+      FSK_WAIT_BEGIN
       while (produced2 <= ti2) {                            // wave 0's tile
         produced2 = ctr_peek(&pctr[0]);
-        if (produced2 <= ti2) __builtin_amdgcn_s_sleep(1);
+        if (produced2 <= ti2) FSK_SPIN(1, S.blk_stat);
       }
       tin = pring + (ti2 % kPreTiles) * kChunks * 64u;
       tstride = 64u;

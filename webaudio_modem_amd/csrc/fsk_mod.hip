@@ -12,6 +12,7 @@
 
 #include "fsk_fdlibm.h"
 #include "fsk_params.h"
+#include "fsk_wait.h"
 
 namespace fsk {
 
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(64 * kModWaves) void modulate_wide_kernel(ModParams
   __syncthreads();
   const uint32_t max_len = max_len_s;
   const uint32_t n_tiles = (max_len + (uint32_t)kTile - 1u) / (uint32_t)kTile;
+  FSK_WAIT_DECL
   auto peek = [&](const uint32_t *p) -> uint32_t {
     uint32_t v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
@@ -356,7 +358,8 @@ __global__ __launch_bounds__(64 * kModWaves) void modulate_wide_kernel(ModParams
       // the slot of tile - kModRing belongs to the same owner: it must have taken that one
       if (tile >= (uint32_t)kModRing) {
         const uint32_t o = tile % (uint32_t)kModOwners;
-        while (peek(&mctr[1u + o]) + (uint32_t)kModRing <= tile) __builtin_amdgcn_s_sleep(1);
+        FSK_WAIT_BEGIN
+        while (peek(&mctr[1u + o]) + (uint32_t)kModRing <= tile) FSK_SPIN(1, M.stat);
       }
       double *h = &hand[tile % (uint32_t)kModRing][0][0];
       h[lane] = phase; h[64 + lane] = w_cur; h[128 + lane] = w_next;
@@ -376,7 +379,8 @@ __global__ __launch_bounds__(64 * kModWaves) void modulate_wide_kernel(ModParams
   for (uint32_t tile = o; tile < n_tiles; tile += (uint32_t)kModOwners) {
     const uint32_t t0 = tile * (uint32_t)kTile;
     const int32_t rel = (int32_t)t0 - (int32_t)sig_begin;
-    while (peek(&mctr[0]) <= tile) __builtin_amdgcn_s_sleep(1);
+    FSK_WAIT_BEGIN
+    while (peek(&mctr[0]) <= tile) FSK_SPIN(1, M.stat);
     const double *h = &hand[tile % (uint32_t)kModRing][0][0];
     const double phase0 = h[lane], w_cur = h[64 + lane], w_next = h[128 + lane];
     post(&mctr[1u + o], tile + 1u);                                   // (taken: the chain wave may reuse the slot)

@@ -156,7 +156,7 @@ struct DemodState {
   uint32_t *cu_ctr;       // u32 [2048]: workgroups started per compute unit (fsk_blk.hip spreads its waves' roles with it)
   float *blk_stash;       // f32 [7][n_streams][4] or null: fsk_blk.hip's block path with resets parks a lane's entry state here
                           // (written per such block, read back only when the block has to be redone sample by sample)
-  uint32_t *blk_stat;     // u32 [2] or null: tiles fsk_blk.hip's back waves have processed, and how many of them left the fast block loop
+  uint32_t *blk_stat;     // u32 [4]: tiles fsk_blk.hip's back waves have processed, how many of them left the fast block loop, the hand-off fault word (fsk_wait.h: bit 0 a wait ran into its bound, bit 1 a bad part map), unused
                           // (running totals; the host picks the next call's kernel by their increments)
   uint32_t *blk_q;        // u32 [16 + groups * 127] or null: fsk_blk.hip's (group, time slice) queue for batches beyond one round
 };
@@ -168,6 +168,7 @@ struct ModParams {
   uint32_t start_bits, stop_bits, parity; // parity 0/1/2
   uint32_t n_pre;         // preamble + sfd bytes
   uint8_t pre[2 * 16];
+  uint32_t *stat;         // the engine's DemodState::blk_stat (the hand-off fault word of modulate_wide_kernel's waits)
   uint32_t exact_sin;     // 1 (fp64 engines): Math.sin by V8's own operation sequence (fsk_fdlibm.h), bit-identical signal;
                           // 0 (fp32 engines): the device library's sin(), ~1.8x faster, may differ by one f32 ulp on ~1e-9 of samples
 };

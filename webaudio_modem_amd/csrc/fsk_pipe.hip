@@ -74,6 +74,7 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
     uint32_t *__restrict__ eod_counts) {
   FSK_ABL_INIT
   FSK_STAMP_DECL
+  FSK_WAIT_DECL
   extern __shared__ float4 lds[];
   v4f *stage = reinterpret_cast<v4f *>(lds);
   v4f *ring = stage + 4 * kSlotStride;
@@ -173,10 +174,10 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
       for (uint32_t hf = 0; hf < 2; hf++) {
         const uint32_t hidx = 2u * t + hf;                  // half tiles produced so far
         if (hidx - consumed >= kPipeSlots) {
-          FSK_STAMP_W0
+          FSK_STAMP_W0 FSK_WAIT_BEGIN
           while (hidx - consumed >= kPipeSlots) {           // ring full: wait for the back wave
             consumed = lds_peek(&ctr[1]);
-            if (hidx - consumed >= kPipeSlots) __builtin_amdgcn_s_sleep(1);
+            if (hidx - consumed >= kPipeSlots) FSK_SPIN(1, S.blk_stat);
           }
           FSK_STAMP_W1
         }
@@ -287,10 +288,10 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
 #pragma unroll 2
     for (uint32_t t = 0; t < nh; t++) {
       if (produced <= t) {
-        FSK_STAMP_W0
+        FSK_STAMP_W0 FSK_WAIT_BEGIN
         while (produced <= t) {
           produced = lds_peek(&ctr[0]);
-          if (produced <= t) __builtin_amdgcn_s_sleep(1);
+          if (produced <= t) FSK_SPIN(1, S.blk_stat);
         }
         FSK_STAMP_W1
       }
@@ -319,9 +320,10 @@ __global__ __launch_bounds__(128) void demod_pipe_kernel(
       lds_post(&ctr[1], t + 1u);                            // slot free (this wave's reads of it are complete)
     }
     FSK_STAMP_END(1)
+    FSK_WAIT_BEGIN
     while (produced <= nh) {
       produced = lds_peek(&ctr[0]);
-      if (produced <= nh) __builtin_amdgcn_s_sleep(1);
+      if (produced <= nh) FSK_SPIN(1, S.blk_stat);
     }
     FrontLane F;
     {

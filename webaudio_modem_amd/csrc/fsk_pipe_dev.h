@@ -9,6 +9,7 @@
 
 #include "fsk_params.h"
 #include "fsk_dev.h"
+#include "fsk_wait.h"
 
 namespace fsk {
 
