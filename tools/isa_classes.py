@@ -88,7 +88,19 @@ def parse_blocks(body):
     """-> list of blocks {name, lines: [(idx, text)], hdr (loop header name this block lies in, innermost)}"""
     blocks, cur = [], {"name": "entry", "lines": [], "note": ""}
     blocks.append(cur)
+    skip_to = None
     for i, l in enumerate(body):
+        # a bounded poll (csrc/fsk_wait.h) is ONE asm statement whose tail -- flag the fault word, s_endpgm -- is jumped over by its
+        # own s_cbranch_scc1 unless the bound is hit: not part of any path priced here
+        if skip_to is not None:
+            if l.strip().startswith(skip_to + ":"):
+                skip_to = None
+            continue
+        mj = re.match(r"\s*s_cbranch_scc1\s+(\.Lfsk_spin_ok\d+)", l)
+        if mj:
+            cur["lines"].append((i, "s_cbranch_scc1 " + mj.group(1)))
+            skip_to = mj.group(1)
+            continue
         ml = re.match(r"\s*(\.LBB\d+_\d+):(.*)$", l)
         if ml:
             cur = {"name": ml.group(1), "lines": [], "note": ml.group(2)}
@@ -126,6 +138,12 @@ def hot_walk(body, blocks, start_block, start_k):
                 # out-of-line code is the loop's back edge: follow it
                 tgt = index[mc.group(1)]
                 if _is_back_edge(blocks, n, tgt, start_block):
+                    n, k, jumped = tgt, 0, True
+                    break
+                # a branch over (or back past) a wait loop -- the compiler places the bounded polls' loops in line, behind a test that
+                # skips them when the tile is there: the hot path takes it
+                ahead = [st2 for bb in [{"lines": b["lines"][k:]}] + blocks[n + 1:(tgt if tgt > n else n + 4)] for _, st2 in bb["lines"]][:30]
+                if any("s_sleep" in st2 for st2 in ahead):
                     n, k, jumped = tgt, 0, True
                     break
         if not jumped:
