@@ -54,6 +54,25 @@ def test_abi_version_and_default_config(lib):
     assert (c.startBits, c.stopBits, c.parity, c.syncThreshold, c.agcEnabled, c.preFilterBandwidth) == (1, 1, 0, 0.85, 1, 800)
 
 
+def test_error_codes_of_the_header_are_the_bindings(lib):
+    """include/fskhip.h's FSKHIP_E_* values and webaudio_modem_amd/_lib.py's E_* constants are one table (ABI 8 added
+    FSKHIP_E_HANDOFF: a hand-off wait of a multi-wave kernel ran into its bound, csrc/fsk_wait.h); the kernels that carry the bound
+    are the ones with hand-off waits -- no bare s_sleep poll is left in them."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "fskhip.h")).read()
+    codes = {m.group(1): int(m.group(2)) for m in re.finditer(r"FSKHIP_(E_[A-Z_]+) = (-\d+)", hdr)}
+    assert codes and codes["E_HANDOFF"] == -8
+    for name, value in codes.items():
+        assert getattr(lib, name) == value, name
+    csrc = os.path.join(ROOT, "webaudio_modem_amd", "csrc")
+    for f in ("fsk_blk.hip", "fsk_blk6.hip", "fsk_pipe.hip", "fsk_demod.hip", "fsk_mod.hip"):
+        src = open(os.path.join(csrc, f)).read()
+        assert "FSK_SPIN(" in src or "B6_SPIN(" in src, f
+        bare = [l for l in src.splitlines() if "__builtin_amdgcn_s_sleep" in l and "//" not in l.split("__builtin_amdgcn_s_sleep")[0]]
+        # (the one left: the persistent launch's wait for another workgroup's time slice, bounded in place -- fsk_blk.hip)
+        assert len(bare) <= (1 if f == "fsk_blk.hip" else 0), (f, bare)
+
+
 def test_config_struct_layout_matches_oracle(lib):
     """fskhip_config and the oracle's fsko_config are the same FSKConfig layout."""
     from oracle import pyoracle as po
