@@ -25,7 +25,8 @@ extern "C" {
  * fskhip_demodulate_host, fskhip_enable_signal_quality / fskhip_get_signal_quality.  4: fskhip_set_option (the library reads no
  * environment variable any more), fskhip_clock_probe_begin / _end, fskhip_debug_state.  5: fskhip_blk_lanes, option
  * "blk_lanes" (additions only).  6: kernel = seven-wave / auto-r04, options "stage_min_tiles" / "stage_y_slots" / "stage_roles"; the batched
- * IIRFilter of fskhip_next.h (additions only).  7: fskhip_get_faults (additions only). */
+ * IIRFilter of fskhip_next.h (additions only).  7: fskhip_get_faults (additions only).  8: FSKHIP_E_HANDOFF -- every hand-off wait of
+ * the multi-wave kernels is bounded ("Hand-off waits" below; an addition: no healthy call returns it). */
 #define FSKHIP_ABI_VERSION 8
 #define FSKHIP_MAX_PATTERN_BYTES 16
 
