@@ -891,3 +891,53 @@ def test_hand_off_fault_word_stays_clear_on_every_multi_wave_kernel():
     eng.synchronize()
     assert len(sig) == S and all(len(v) > 0 for v in sig)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_phase_wrap_within_rounding_of_pi_fp64_follows_the_reference():
+    """tests/golden/soak_67001_phase_wrap.npy is the one stream in ~6 M soak stream-runs (tools/soak.py 1700 67001, round 6; default
+    configuration, frames at 10-20 dB over noise) on which an fp32 engine decoded another byte than the reference for a reason that is
+    neither of the two known marginal decisions: at decimated sample 1869 two consecutive I/Q samples of the noise in front of a frame
+    point in opposite directions and the reference's phase difference is -3.141592052 -- 6.0e-7 from -pi, where fsk.ts:254-256 wraps.
+    fp32 phases carry ~2e-7 of rounding: the fp32 engines wrap the other way, their post filter sees +pi instead of -pi and is
+    somewhere else for the next few dozen samples (the slicer bits from sample 1872 on differ, one decoded byte with them).  That is
+    the discontinuity of the reference's own function, not a defect -- the fp32 byte parity is a measured rate and
+    the soak now classifies this case as it does the other two.  What IS asserted: the exact path gets it right -- the fp64 engine's
+    bytes, 'eod' count and slicer bits are the oracle's on this stream, in one call and cut at the soak's 4096 -- and the fp32
+    engine's amplitudes still agree to 1e-6 of the peak and its post filter to 1e-5 up to the wrap."""
+    import webaudio_modem_amd as wm
+    from oracle import pyoracle as po
+    import os
+    x = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "soak_67001_phase_wrap.npy"))
+    o = po.OracleCore({})
+    o.enable_trace(len(x), len(x))
+    want, want_eod = o.demodulate(x)
+    ot = o.trace()
+    k = 1869
+    assert abs(abs(float(ot["post_in"][k])) - np.pi) < 1e-6 and float(ot["post_in"][k]) < 0          # the case itself
+    assert not np.any(np.abs(np.abs(ot["post_in"][:k]) - np.pi) < 1e-5)                              # ... and the first of its kind
+    tr = {}
+    for prec in (wm.PRECISION_F64, wm.PRECISION_F32):
+        e = wm.FSKEngine(1, {}, precision=prec)
+        e.trace_enable(0, len(x))
+        out, eod = e.demodulate_data(x.reshape(1, -1).copy())
+        tr[prec] = e.trace_read()
+        if prec == wm.PRECISION_F64:
+            assert out[0] == want and int(eod[0]) == want_eod
+        e.close()
+    t64, t32 = tr[wm.PRECISION_F64], tr[wm.PRECISION_F32]
+    n = len(ot["bit"])
+    assert np.array_equal(t64["bit"][:n], ot["bit"]) and np.allclose(t64["post_out"][:n], ot["post_out"], rtol=0, atol=1e-10)
+    # (magnitudes do not see the phase: within 1e-6 of the stream's peak -- this is noise 40 dB under the frames, where the fp32 filters'
+    # own rounding, ~1e-7 of the peak, is more than 1e-5 of the sample)
+    assert np.abs(t32["amp"][:k + 200] - ot["amp"][:k + 200]).max() <= 1e-6 * ot["amp"].max()
+    assert np.allclose(t32["post_out"][:k], ot["post_out"][:k], rtol=0, atol=1e-5)
+    assert abs(t32["post_out"][k] - ot["post_out"][k]) > 1e-2                                        # (documented, not wished for)
+    # cut where the soak cut it
+    e = wm.FSKEngine(1, {}, precision=wm.PRECISION_F64)
+    o2 = po.OracleCore({})
+    for a, b in ((0, 4096), (4096, len(x))):
+        out, eod = e.demodulate_data(x[a:b].reshape(1, -1).copy())
+        ob, oe = o2.demodulate(x[a:b])
+        assert out[0] == ob and int(eod[0]) == oe
+    e.close()

@@ -64,7 +64,10 @@ def fp32_mismatch_is_marginal(cfg_s, xs, resets_seen):
         return False, "no slicer bit differs in a one-call replay"
     k = int(d[0])
     p64, p32 = float(tr[0]["post_out"][k]), float(tr[1]["post_out"][k])
-    if abs(p64) < 1e-6 and abs(p32) < 1e-6:
+    # (round 6, seed 67001: the fp32 side of the test is the accuracy the fp32 post filter is HELD to -- 2e-5 absolute,
+    # tests/test_gpu_parity.py::test_intermediates_match_reference -- not 1e-6: at 300 baud its output crosses zero at 8e-4 per decimated
+    # sample and carries ~1e-5 of rounding; the reference sat 2.4e-8 below zero on a preamble tap, fp32 9.7e-6 above)
+    if abs(p64) < 1e-6 and abs(p32 - p64) <= 2e-5:
         return True, "first differing bit at decimated sample %d: post filter %.3e (fp64) vs %.3e (fp32), magnitude %.3e" % (
             k, p64, p32, float(tr[0]["amp"][k]))
     # round 4 (idle tails): the other decision fp32 can take differently is the silence compare (fsk.ts:285): one amplitude
@@ -85,6 +88,22 @@ def fp32_mismatch_is_marginal(cfg_s, xs, resets_seen):
                     if i + 1 <= k0:
                         return True, ("silence compare within 1e-5 of the threshold %.9g at decimated sample %d (%.9g fp64, %.9g fp32); the engines "
                                       "part at sample %d" % (t, i, a64[i], a32[i], k0))
+    # round 6 (seed 67001, the first in ~6 M stream-runs): the third decision fp32 can take differently is the discriminator's phase
+    # WRAP (fsk.ts:254-256): two consecutive decimated I/Q samples pointing in opposite directions (noise at a low magnitude), the
+    # reference's phase difference within rounding of -pi or +pi -- fp32 lands on the other side, the post filter's input differs by
+    # 2 pi and its output is somewhere else for the next few dozen samples.  Accepted only if the reference (the oracle, traced: it
+    # records the post filter's INPUT) has |phase difference| within 1e-5 of pi at a sample in the 64 in front of the first
+    # differing bit, and the two engines' post filter outputs agree to 1e-4 just before that sample and differ after it.
+    o = po.OracleCore(cfg_s)
+    o.enable_trace(len(xs), len(xs))
+    o.demodulate(np.ascontiguousarray(xs, np.float32))
+    pin = o.trace()["post_in"][:n]
+    q64, q32 = tr[0]["post_out"][:n], tr[1]["post_out"][:n]
+    for i in range(max(1, k - 64), k + 1):
+        if abs(abs(float(pin[i])) - np.pi) <= 1e-5 and abs(q64[i - 1] - q32[i - 1]) <= 1e-4 and abs(q64[i] - q32[i]) > 1e-3:
+            return True, ("phase wrap within 1e-5 of pi at decimated sample %d (the reference's phase difference there: %.9f, magnitude %.3e); post "
+                          "filter %.4e (fp64) vs %.4e (fp32) one sample earlier, %.4e vs %.4e there; first differing bit at %d" % (
+                              i, float(pin[i]), float(tr[0]["amp"][i]), q64[i - 1], q32[i - 1], q64[i], q32[i], k))
     return False, "first differing bit at decimated sample %d: post filter %.3e (fp64) vs %.3e (fp32), magnitude %.3e" % (
         k, p64, p32, float(tr[0]["amp"][k]))
 
@@ -223,7 +242,7 @@ def main(budget=None, seed=None, max_rounds=None):
                         continue
                     os.makedirs("gpurun_out", exist_ok=True)
                     np.save("gpurun_out/soak_fail_%x.npy" % seed, x[s])
-                    what = ("mismatch", cfgs[s], prec, S, s, off, n, int(eod[s]), oe, out[s], ob, log[-12:])
+                    what = ("mismatch", "round %d" % rounds, cfgs[s], prec, S, s, off, n, int(eod[s]), oe, out[s], ob, log[-12:])
                     if prec == wm.PRECISION_F32:
                         ok, why = fp32_mismatch_is_marginal(cfgs[s], x[s], any(l[0].startswith("reset") and (l[0] == "reset all" or l[1] == s) for l in log))
                         if ok:
@@ -270,7 +289,7 @@ def main(budget=None, seed=None, max_rounds=None):
     # measured to be (round 2: two in 1.1 M stream-runs): more than one per 100 000 stream-runs fails the soak
     assert SOFT["marginal"] <= 1 + streams // 100000, ("too many fp32 divergences excused as marginal", SOFT["marginal"], SOFT["marginal_first"])
     print("soak ok: %d rounds, %d stream-runs, seed %#x; fp32 timing differences with identical bytes: %d %s; fp32 streams "
-          "diverging after a slicer decision within 1e-6 of zero: %d %s; rounds with a NaN / Inf sample in one stream: %d (timing differences in those: %d)"
+          "diverging after a marginal decision (slicer input within 1e-6 of zero in the reference / silence compare / phase wrap): %d %s; rounds with a NaN / Inf sample in one stream: %d (timing differences in those: %d)"
           % (rounds, streams, seed, SOFT["n"], SOFT["first"] or "", SOFT["marginal"], SOFT["marginal_first"] or "", HOSTILE["rounds"], HOSTILE["soft"]))
     return rounds, streams, SOFT["n"]
 
