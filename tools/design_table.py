@@ -26,7 +26,7 @@ d = L("c1x"); row("a bank that never syncs (`--workload c1x`)", "`<false,true,tr
 q = c["large_batch"]; row("large batch, 262 144 × 24 000", "`<false,true,true>`", v(q["Msamples_per_s"]), v(q["Msamples_per_s"] * 4 / 1e3), f(q["frac_of_hbm_peak"]), "")
 d = L("mod"); row("**modulateData**, config #5's TX leg, 16 384 × 11 frames (`--workload mod`)", "`modulate_wide_kernel<false>`", "**%s**" % v(d["value"]), v(d["roofline"]["achieved"]) + " written", f(d["roofline"]["frac"]), "0 / 2.67 M samples differ")
 d = L("mod_f64"); row("the same, fp64 engine", "`modulate_wide_kernel<true>`", v(d["value"]), v(d["roofline"]["achieved"]), f(d["roofline"]["frac"]), "bit-identical")
-i = c["iir"]; row("**batched `IIRFilter`**, order 2, 65 536 × 48 000 (`config.iir`; 8 B per sample)", "`iir_kernel` (f32 / f64)", "%s / %s" % (v(i["65536_f32"]["Msamples_per_s"]), v(i["65536_f64"]["Msamples_per_s"])), "%s / %s" % (v(i["65536_f32"]["GB_per_s"]), v(i["65536_f64"]["GB_per_s"])), "**%.1f / %.1f %%**" % (100 * i["65536_f32"]["frac_of_hbm_peak"], 100 * i["65536_f64"]["frac_of_hbm_peak"]), "bit-identical to the reference runs (`-m gpu`)")
+i = c["iir"]; row("**batched `IIRFilter`**, order 2, 65 536 × 48 000 (`config.iir`; 8 B per sample)", "`iir_kernel` (f32 / f64)", "%s / %s" % (v(i["65536_f32"]["Msamples_per_s"]), v(i["65536_f64"]["Msamples_per_s"])), "%s / %s" % (v(i["65536_f32"]["GB_per_s"]), v(i["65536_f64"]["GB_per_s"])), "**%.1f / %.1f %%**" % (100 * i["65536_f32"]["frac_of_hbm_peak"], 100 * i["65536_f64"]["frac_of_hbm_peak"]), "bit-identical to the reference runs (`-m gpu`); 0.62–0.72 over this round's boxes")
 row("the same, 16 384 streams (one wave per CU)", "", "%s / %s" % (v(i["16384_f32"]["Msamples_per_s"]), v(i["16384_f64"]["Msamples_per_s"])), "", "%.1f / %.1f %%" % (100 * i["16384_f32"]["frac_of_hbm_peak"], 100 * i["16384_f64"]["frac_of_hbm_peak"]), "")
 q = c["pcie_inclusive"]; row("PCIe-inclusive (`fskhip_demodulate_host`, 16 384 × 48 000)", "", v(q["Msamples_per_s"]), "%.1f of input" % q["GB_per_s_of_input"], "", "never the headline")
 row("CPU oracle, one core of %d" % m["cpu_baseline"]["host_cpus"], "", "%.1f" % m["cpu_baseline"]["value"], "", "", "")
