@@ -352,7 +352,7 @@ int fskhip_clock_probe_end(fskhip_engine *e, double *shader_ghz, double *covered
  * host reports FSKHIP_E_HANDOFF from fskhip_synchronize, fskhip_get_faults, the _host calls (all of which wait for the device
  * anyway) and from every later fskhip_demodulate_device (from the statistics copy that trails the launches: no extra wait); it
  * is sticky -- the streams of that workgroup stopped mid-call -- and the engine is to be destroyed.  A lost counter update is
- * thus an error code, not a hung GPU; tools/handoff_check.py shows it on a build whose bound is 0 polls
+ * thus an error code, not a hung GPU; tools/handoff_check.py shows it on a build whose bound is one poll
  * (profiles/r06_handoff_bound.txt), tests/test_gpu_parity.py that healthy launches of every such kernel leave the word clear.
  * The bound sits on the waits' slow paths only: measured cost nil (same file).
  */
